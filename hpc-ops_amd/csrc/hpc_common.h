@@ -1,0 +1,97 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of hpc-ops_amd.
+// Wave64 only. No CUDA compatibility layer: this header is HIP-for-CDNA4 code.
+//
+// Replaces the role of the reference's src/utils/utils.cuh (vec_t / load / store /
+// warp reductions / fp8 conversions) with CDNA4 idioms: 64-lane DPP/shuffle
+// reductions, 16-byte vector global accesses, OCP e4m3 hardware conversions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hpc {
+
+constexpr int kWave = 64;
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ---- bf16 <-> f32 (bit tricks; RNE on the way down, NaN preserved) -------------------
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) {
+  return __uint_as_float(static_cast<uint32_t>(h) << 16);
+}
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t w) {
+  return __uint_as_float(w & 0xffff0000u);
+}
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return static_cast<uint16_t>((u >> 16) | 0x40u);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return static_cast<uint16_t>(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return static_cast<uint32_t>(f32_to_bf16(lo)) | (static_cast<uint32_t>(f32_to_bf16(hi)) << 16);
+}
+
+// ---- OCP e4m3fn conversions (gfx950 hardware cvt; saturating to +-448 like the reference's
+// __nv_fp8 casts, SURVEY 7 "hard parts") ------------------------------------------------
+__device__ __forceinline__ float clamp_e4m3(float x) {
+  // v_med3_f32: NaN-propagating is not needed; NaN inputs stay NaN through fminf/fmaxf order.
+  return __builtin_fminf(__builtin_fmaxf(x, -448.0f), 448.0f);
+}
+// packs (a, b) into the low 16 bits of the result.
+__device__ __forceinline__ uint32_t cvt_pk_e4m3(float a, float b) {
+  return static_cast<uint32_t>(
+             __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(a), clamp_e4m3(b), 0, false)) &
+         0xffffu;
+}
+__device__ __forceinline__ uint32_t cvt_4xe4m3(float a, float b, float c, float d) {
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(a), clamp_e4m3(b), 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(c), clamp_e4m3(d), r, true);
+  return static_cast<uint32_t>(r);
+}
+// byte `sel` (0..3) of w -> f32
+template <int kSel>
+__device__ __forceinline__ float e4m3_to_f32(uint32_t w) {
+  return __builtin_amdgcn_cvt_f32_fp8(static_cast<int>(w), kSel);
+}
+
+// ---- wave64 reductions -----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- 16-byte global accesses -------------------------------------------------------------
+__device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+__device__ __forceinline__ u32x4 ld16_nt(const void* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+}
+
+}  // namespace hpc
+
+// Error convention of the C-ABI (include/hpc_amd.h): 0 = launched, negative = refused.
+#define HPC_OK 0
+#define HPC_ERR_UNSUPPORTED (-1)
+#define HPC_ERR_INVALID (-2)
+#define HPC_ERR_LAUNCH (-3)
+
+#define HPC_CHECK_LAUNCH()                               \
+  do {                                                   \
+    if (hipGetLastError() != hipSuccess) return HPC_ERR_LAUNCH; \
+  } while (0)

@@ -1,0 +1,58 @@
+// Library identity + device queries.
+// Replaces reference src/C/version.cc, src/C/built_json.cu:17-43 and get_sm_count()
+// (src/utils/utils.cc:15-41; the reference caches device 0 only, this one is per device).
+#include <hip/hip_runtime.h>
+#include <hip/hip_version.h>
+
+#include <mutex>
+#include <sstream>
+#include <string>
+
+#include "../../include/hpc_amd.h"
+
+#ifndef HPC_VERSION_STR
+#define HPC_VERSION_STR "unknown"
+#endif
+#ifndef HPC_GIT_HASH_STR
+#define HPC_GIT_HASH_STR "unknown"
+#endif
+
+extern "C" const char* hpc_version(void) { return HPC_VERSION_STR; }
+
+extern "C" const char* hpc_built_json(void) {
+  static std::string json = [] {
+    std::ostringstream oss;
+    oss << "{\n";
+    oss << " \"version\": \"" << HPC_VERSION_STR << "\",\n";
+    oss << " \"git-hash\": \"" << HPC_GIT_HASH_STR << "\",\n";
+    oss << " \"hipcc\": \"hip-" << HIP_VERSION_MAJOR << "." << HIP_VERSION_MINOR << "."
+        << HIP_VERSION_PATCH << "\",\n";
+    oss << " \"clang\": \"" << __clang_major__ << "." << __clang_minor__ << "."
+        << __clang_patchlevel__ << "\",\n";
+    oss << " \"offload-arch\": \"gfx950\",\n";
+    oss << " \"stdc++\": \"" << __cplusplus << "\",\n";
+    oss << " \"built-date\": \"" << __DATE__ << "\",\n";
+    oss << " \"built-time\": \"" << __TIME__ << "\",\n";
+    oss << " \"_C\": \"" << __FILE__ << "\"\n";
+    oss << "}\n";
+    return oss.str();
+  }();
+  return json.c_str();
+}
+
+extern "C" int hpc_get_cu_count(int device_id) {
+  static std::mutex mu;
+  static int cache[64];
+  std::lock_guard<std::mutex> lock(mu);
+  if (device_id < 0) {
+    if (hipGetDevice(&device_id) != hipSuccess) return -1;
+  }
+  if (device_id >= 64) return -1;
+  if (cache[device_id] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess)
+      return -1;
+    cache[device_id] = n;
+  }
+  return cache[device_id];
+}

@@ -1,0 +1,84 @@
+"""Loader for libhpc_amd.so — the C-ABI boundary (include/hpc_amd.h).
+
+Plays the role of the reference's `hpc/_C.abi3.so` + `torch.ops.load_library`
+(reference hpc/__init__.py:43-45): it opens the in-tree shared library with ctypes, declares the
+argument types of every `extern "C"` entry point, and owns the `torch.library.Library("hpc")`
+object on which the per-module `_entry_*.py` files register the reference's op schemas
+(reference src/*/entry.cc TORCH_LIBRARY_FRAGMENT blocks).
+
+There is NO fallback: if the library is missing or an entry point is absent, import fails loudly.
+"""
+import ctypes
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
+from pathlib import Path
+
+import torch
+
+_LIB_PATH = Path(__file__).resolve().parent / "libhpc_amd.so"
+if not _LIB_PATH.exists():
+    raise ImportError(
+        f"{_LIB_PATH} not found: build it first with `python hpc-ops_amd/build.py` "
+        "(hipcc --offload-arch=gfx950). hpc has no CPU/eager fallback."
+    )
+
+lib = ctypes.CDLL(str(_LIB_PATH), mode=ctypes.RTLD_GLOBAL)
+
+P = c_void_p
+I = c_int
+L = c_int64
+F = c_float
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud failure
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+# ---- signatures (keep in the order of include/hpc_amd.h) ------------------------------------
+_sig("hpc_version", c_char_p)
+_sig("hpc_built_json", c_char_p)
+_sig("hpc_get_cu_count", I, I)
+_sig("hpc_fused_rmsnorm_with_scale_async", I, P, P, P, P, P, P, F, I, I, I, P)
+
+# torch op namespace `hpc` (reference: TORCH_LIBRARY(hpc, m), src/C/C.cc:5)
+torch_lib = torch.library.Library("hpc", "DEF")
+
+_ERR = {-1: "unsupported configuration", -2: "invalid argument", -3: "HIP launch error"}
+
+
+def check(code: int, what: str) -> None:
+    """Reference convention: TORCH_CHECK(running, "<op> launch failed!") -> RuntimeError."""
+    if code != 0:
+        raise RuntimeError(f"{what} launch failed! ({_ERR.get(code, code)})")
+
+
+def ptr(t):
+    """Raw device pointer of a tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream_of(t: torch.Tensor):
+    """Current HIP stream of t's device (reference: at::cuda::getCurrentCUDAStream(device))."""
+    return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def cu_count(device=None) -> int:
+    idx = -1 if device is None else (device.index if device.index is not None else -1)
+    n = lib.hpc_get_cu_count(idx)
+    if n <= 0:
+        raise RuntimeError("hpc_get_cu_count failed (no HIP device?)")
+    return n
+
+
+def require(cond: bool, msg: str) -> None:
+    if not cond:
+        raise RuntimeError(msg)
+
+
+# version / built_json ops (reference src/C/version.cc, src/C/built_json.cu)
+torch_lib.define("version() -> str")
+torch_lib.define("built_json() -> str")
+torch_lib.impl("version", lambda: lib.hpc_version().decode(), "CompositeExplicitAutograd")
+torch_lib.impl("built_json", lambda: lib.hpc_built_json().decode(), "CompositeExplicitAutograd")
