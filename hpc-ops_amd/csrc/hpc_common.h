@@ -83,6 +83,31 @@ __device__ __forceinline__ u32x4 ld16_nt(const void* p) {
   return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
 }
 
+// ---- wave-uniform reads of read-only tables (task map, page table) ----------------------------------
+// Reading through the constant address space tells hipcc the data is invariant, so a uniform
+// address becomes an s_load (lgkmcnt) instead of a global_load whose vmcnt wait would drain the
+// KV stream that is in flight.
+typedef const int __attribute__((address_space(4))) * cint_ptr;
+__device__ __forceinline__ cint_ptr as_const(const int* p) {
+  return (cint_ptr)(reinterpret_cast<uintptr_t>(p));
+}
+
+// ---- buffer (SRD) loads: wave-uniform 64-bit base in SGPRs + 32-bit lane offset -------------------
+// The base must be provably wave-uniform (built from kernargs / readfirstlane values), otherwise
+// hipcc wraps every access in a waterfall loop.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+// num_records = 0 makes every access out of range: loads return 0 and fetch nothing.
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned num_records = 0xffffffffu) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, num_records, 0x00020000);
+}
+// voff: per-lane byte offset (may carry a compile-time constant), soff: wave-uniform byte offset
+__device__ __forceinline__ u32x4 buf_ld16(rsrc_t rs, int voff, int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+}
+__device__ __forceinline__ u32x2 buf_ld8(rsrc_t rs, int voff, int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+}
+
 }  // namespace hpc
 
 // Error convention of the C-ABI (include/hpc_amd.h): 0 = launched, negative = refused.

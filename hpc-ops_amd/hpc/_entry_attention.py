@@ -1,0 +1,175 @@
+"""torch.ops.hpc.{assign_attention_decode_task, attention_decode_bf16, attention_decode_fp8}.
+
+Mirror of the decode part of reference src/attention/entry.cc (:411-817: checks, scratch
+allocation, stride extraction, schema block :851-873); compute is in libhpc_amd.so
+(csrc/assign_task.hip, csrc/attention_decode_*.hip) behind the C-ABI of include/hpc_amd.h.
+"""
+import ctypes
+
+import torch
+
+from . import _C
+
+_T = _C.torch_lib
+
+_T.define(
+    "assign_attention_decode_task(Tensor num_seq_kvcache, int num_head_kv, int num_seq_q, bool "
+    "new_kv_included, int min_process_len, Tensor? task_map) -> (Tensor)"
+)
+_T.define(
+    "attention_decode_bf16(Tensor q, Tensor! kcache, Tensor! vcache, Tensor block_ids, Tensor "
+    "num_seq_kvcache, int mtp, bool new_kv_included, bool use_splitk, Tensor? task_map, "
+    "Tensor? split_flag, Tensor? output) -> (Tensor)"
+)
+
+_INT_P = ctypes.POINTER(ctypes.c_int)
+
+
+def num_bins(num_seq_q: int, device=None) -> int:
+    """Scheduler bins (= decode workgroups) on this device; reference kCtaPerSmMap * SM count
+    (src/attention/entry.cc:745-746), here CUs * workgroups-per-CU chosen for gfx950."""
+    idx = -1
+    if device is not None and getattr(device, "index", None) is not None:
+        idx = device.index
+    n = _C.lib.hpc_attention_decode_num_bins(int(num_seq_q), idx)
+    _C.require(n > 0, "we only support num_seq_q 1..5 (and a HIP device must be present)")
+    return n
+
+
+def _assign_cpu(num_seq_kvcache, num_head_kv, num_seq_q, new_kv_included, min_process_len, placehold):
+    # reference assign_attention_decode_task_cpu_entry (entry.cc:727-778)
+    _C.require(num_seq_kvcache.device.type == "cpu", "num_seq_kvcache tensor must be cpu")
+    _C.require(num_seq_kvcache.dtype == torch.int32, "num_seq_kvcache dtype must be int32")
+    lens = num_seq_kvcache.contiguous()
+    bins = num_bins(num_seq_q)
+    lp = ctypes.cast(lens.data_ptr(), _INT_P)
+    args = (bins, lens.numel(), int(num_head_kv), int(num_seq_q), int(bool(new_kv_included)),
+            int(min_process_len))
+    rows = _C.lib.hpc_assign_attention_decode_task_rows(lp, *args)
+    _C.check(0 if rows > 0 else rows, "assign_attention_decode_task_sync")
+    task_map = torch.zeros((rows, 48), dtype=torch.int8)
+    rc = _C.lib.hpc_assign_attention_decode_task_sync(
+        lp, *args, ctypes.cast(task_map.data_ptr(), _INT_P), rows
+    )
+    _C.check(0 if rc == rows else (rc if rc < 0 else -2), "assign_attention_decode_task_sync")
+    return task_map
+
+
+def _assign_cuda(num_seq_kvcache, num_head_kv, num_seq_q, new_kv_included, min_process_len, task_map):
+    # reference assign_attention_decode_task_cuda_entry (entry.cc:780-817)
+    _C.require(num_seq_kvcache.is_cuda, "num_seq_kvcache tensor must be cuda")
+    _C.require(num_seq_kvcache.dtype == torch.int32, "num_seq_kvcache dtype must be int32")
+    _C.require(num_seq_kvcache.is_contiguous(), "num_seq_kvcache tensor must be contiguous")
+    _C.require(task_map is not None, "assign_attention_decode_task_cuda must use task_map output.")
+    _C.require(num_seq_kvcache.size(0) <= 4096,
+               "assign_attention_decode_task_cuda only support batch_size <= 4096")
+    bins = num_bins(num_seq_q, num_seq_kvcache.device)
+    rc = _C.lib.hpc_assign_attention_decode_task_async(
+        ctypes.cast(task_map.data_ptr(), _INT_P),
+        ctypes.cast(num_seq_kvcache.data_ptr(), _INT_P),
+        bins, num_seq_kvcache.size(0), int(num_head_kv), int(num_seq_q),
+        int(bool(new_kv_included)), int(min_process_len), _C.stream_of(num_seq_kvcache),
+    )
+    _C.check(rc, "assign_attention_decode_task_async")
+    return task_map
+
+
+_T.impl("assign_attention_decode_task", _assign_cpu, "CPU")
+_T.impl("assign_attention_decode_task", _assign_cuda, "CUDA")
+
+
+def task_workspace_bytes(num_cu, max_num_batch, max_seqlen, num_head_kv, min_process_len):
+    """Byte size + scheduler byte size of the task-map workspace; same arithmetic as reference
+    hpc/attention.py:540-571 (sized for up to 4 bins per CU, so any gfx950 bin count fits)."""
+    k_task, k_max_cta, k_tile = 48, 4, 64
+    max_cta = num_cu * k_max_cta
+    total_tiles = max_num_batch * num_head_kv * ((max_seqlen + k_tile - 1) // k_tile)
+    max_tasks = 0
+    for cta_per_cu in (4, 3, 2, 1):
+        ctas = num_cu * cta_per_cu
+        per = max((total_tiles + ctas - 1) // ctas, min_process_len // k_tile)
+        max_tasks = max(max_tasks, (per + 1) * ctas + 1)
+    chunk_bytes = (max_num_batch * num_head_kv * 4 + k_task - 1) // k_task * k_task
+    cta_pad = (max_cta + 11) // 12 * 12 * 4
+    sched = max_tasks * k_task + chunk_bytes
+    return sched + 2 * cta_pad, sched
+
+
+def _alloc_task_workspace(device, num_cu, max_num_batch, max_seqlen, num_head_kv, min_process_len):
+    total, sched = task_workspace_bytes(num_cu, max_num_batch, max_seqlen, num_head_kv, min_process_len)
+    ws = torch.zeros(total, dtype=torch.int8, device=device)
+    hdr = ws.view(torch.int32)
+    hdr[2] = num_head_kv
+    hdr[3] = max_num_batch
+    hdr[4] = sched
+    return ws
+
+
+def _decode_common_checks(q, kcache, vcache, block_ids, num_seq_kvcache, mtp, max_mtp):
+    _C.require(q.is_cuda, "q tensor must be cuda")
+    _C.require(kcache.is_cuda, "kcache tensor must be cuda")
+    _C.require(vcache.is_cuda, "vcache tensor must be cuda")
+    _C.require(block_ids.is_cuda, "block_ids tensor must be cuda")
+    _C.require(block_ids.is_contiguous(), "block_ids tensor must be contiguous")
+    _C.require(num_seq_kvcache.is_contiguous(), "num_seq_kvcache tensor must be contiguous")
+    _C.require(block_ids.dtype == torch.int32, "block_ids dtype must be int32")
+    _C.require(num_seq_kvcache.dtype == torch.int32, "num_seq_kvcache dtype must be int32")
+    _C.require(0 <= mtp <= max_mtp, "we only support mtp 0.." + str(max_mtp) + ".")
+    num_batch = num_seq_kvcache.size(0)
+    num_seq_q = q.size(0) // num_batch
+    _C.require(num_seq_q == mtp + 1, "every request num_seq_q must be mtp + 1")
+    _C.require(q.size(2) == 128, "we only support head dim 128.")
+    _C.require(q.stride(2) == 1 and q.stride(1) == 128, "q heads must be contiguous")
+    _C.require(kcache.stride(3) == 1 and vcache.stride(3) == 1, "kv cache dims must be contiguous")
+    heads_per_group = q.size(1) // kcache.size(2)
+    _C.require(heads_per_group in (4, 8), "we only support num_head_q / num_head_k == 4 or 8.")
+    return num_batch, num_seq_q, heads_per_group
+
+
+def _schedule_on_the_fly(num_seq_kvcache, block_ids, block_size, num_head_kv, num_seq_q,
+                         new_kv_included):
+    """No task_map given (reference static split-K path, entry.cc:507-563): build the dynamic
+    schedule on the fly with the device scheduler; the page table bounds the sequence length."""
+    dev = num_seq_kvcache.device
+    num_cu = _C.cu_count(dev)
+    max_seq = block_ids.size(1) * block_size + num_seq_q
+    tm = _alloc_task_workspace(dev, num_cu, num_seq_kvcache.size(0), max_seq, num_head_kv, 512)
+    return _assign_cuda(num_seq_kvcache, num_head_kv, num_seq_q, new_kv_included, 512, tm)
+
+
+def _attention_decode_bf16_entry(q, kcache, vcache, block_ids, num_seq_kvcache, mtp,
+                                 new_kv_included, use_splitk, task_map, split_flag, output):
+    num_batch, num_seq_q, group = _decode_common_checks(
+        q, kcache, vcache, block_ids, num_seq_kvcache, mtp, 4)
+    _C.require(q.dtype == torch.bfloat16, "q dtype must be bfloat16")
+    _C.require(kcache.dtype == torch.bfloat16 and vcache.dtype == torch.bfloat16,
+               "kv cache dtype must be bfloat16")
+    block_size = kcache.size(1)
+    _C.require(block_size in (16, 32, 64), "kvcache paged blocksize must be 16, 32 or 64.")
+    num_head_q, num_head_kv = q.size(1), kcache.size(2)
+    if task_map is not None:
+        _C.require(task_map.is_cuda, "task_map tensor must be cuda")
+        _C.require(task_map.is_contiguous(), "task_map tensor must be contiguous")
+        _C.require(task_map.dtype in (torch.int8, torch.int32),
+                   "task_map dtype must be int8 (raw workspace) or int32 (typed)")
+        _C.require(use_splitk, "attention_decode_bf16: splitk must be true with a task_map.")
+    else:
+        task_map = _schedule_on_the_fly(num_seq_kvcache, block_ids, block_size, num_head_kv,
+                                        num_seq_q, new_kv_included)
+    y = output if output is not None else torch.empty(
+        (num_batch * num_seq_q, num_head_q, vcache.size(3)), dtype=torch.bfloat16, device=q.device)
+    bins = num_bins(num_seq_q, q.device)
+    ws_bytes = _C.lib.hpc_attention_decode_workspace_bytes(bins, num_batch, num_head_kv, num_seq_q, group)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+    rc = _C.lib.hpc_attention_decode_bf16_async(
+        _C.ptr(y), _C.ptr(ws), ctypes.cast(task_map.data_ptr(), _INT_P), _C.ptr(q), _C.ptr(kcache),
+        _C.ptr(vcache), ctypes.cast(block_ids.data_ptr(), _INT_P), bins, num_batch, num_seq_q,
+        num_head_q, num_head_kv, q.size(2), vcache.size(3), block_size, block_ids.size(1),
+        y.stride(0), q.stride(0), kcache.stride(0), kcache.stride(1), kcache.stride(2),
+        vcache.stride(0), vcache.stride(1), vcache.stride(2), _C.stream_of(q),
+    )
+    _C.check(rc, "attn decode kernel")
+    return y
+
+
+_T.impl("attention_decode_bf16", _attention_decode_bf16_entry, "CUDA")

@@ -1,0 +1,145 @@
+"""hpc.attention — decode-attention surface of the reference (hpc/attention.py:8-12, :336-696).
+
+Same function names, argument names/defaults and semantics; the kernels behind torch.ops.hpc.* are
+the gfx950 ones of libhpc_amd.so.  Prefill / block-sparse entry points of the reference are out of
+scope of this hot path and intentionally absent.
+"""
+from enum import Enum
+
+import torch
+from torch import Tensor
+
+from . import _C
+from . import _entry_attention as _entry
+
+
+class QuantType(Enum):
+    QPERTOKEN_PERHEAD_KPERTOKEN_PERHEAD_VPERHEAD = 0
+    QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR = 1
+    QPERTENSOR_KPERTENSOR_VPERTENSOR = 2
+    QPERTOKEN_PERHEAD_KPERTOKEN_PERHEAD_VPERHEAD_QKHADAMARD = 3
+
+
+def attention_decode_bf16(
+    q: Tensor,
+    kcache: Tensor,
+    vcache: Tensor,
+    block_ids: Tensor,
+    num_seq_kvcache: Tensor,
+    mtp: int = 0,
+    new_kv_included: bool = False,
+    splitk: bool = True,
+    task_map: Tensor = None,
+    split_flag: Tensor = None,
+    output: Tensor = None,
+) -> Tensor:
+    """Paged decode attention in bfloat16 (reference hpc/attention.py:336-417).
+
+    Args:
+        q: [num_batch * num_seq_q, num_head_q, 128] bfloat16 (num_seq_q = mtp + 1).
+        kcache / vcache: paged caches, logical [num_blocks, block_size, num_head_kv, 128] bfloat16;
+            any block/token/head strides (NHD-contiguous and HND-backed views both work).  Unused
+            slots of a request's last block should be zero (they are masked anyway).
+        block_ids: [num_batch, max_blocks] int32 page table.
+        num_seq_kvcache: [num_batch] int32; tokens in the cache before this step, or including the
+            num_seq_q new ones when new_kv_included.
+        splitk: accepted for API compatibility; the schedule is always the dynamic tile schedule.
+        task_map: workspace from get_attention_decode_task_workspace filled by
+            assign_attention_decode_task (scheduled on the fly when None).
+        split_flag: unused on MI355X (the reference's static path spins on it).
+        output: optional preallocated [num_batch * num_seq_q, num_head_q, 128] bfloat16.
+    """
+    return torch.ops.hpc.attention_decode_bf16(
+        q, kcache, vcache, block_ids, num_seq_kvcache, mtp, new_kv_included, splitk, task_map,
+        split_flag, output,
+    )
+
+
+def get_attention_decode_task_workspace(
+    max_num_batch: int, max_seqlen: int, num_head_kv: int, min_process_len: int = 512
+):
+    """Allocate the task-map workspace (reference hpc/attention.py:520-582; same byte layout).
+
+    Returns int8 [task_map_byte_size] on the current device with header ints 2..4 pre-filled
+    (num_head_kv, max_num_batch, scheduler byte size).
+    """
+    dev = torch.device("cuda", torch.cuda.current_device())
+    num_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    return _entry._alloc_task_workspace(
+        dev, num_cu, max_num_batch, max_seqlen, num_head_kv, min_process_len
+    )
+
+
+def assign_attention_decode_task(
+    num_seq_kvcache: Tensor,
+    task_map: Tensor,
+    num_head_kv: int,
+    mtp: int,
+    new_kv_included: bool,
+    min_process_len: int = 512,
+) -> Tensor:
+    """Fill `task_map` for one decode step (reference hpc/attention.py:585-626).
+
+    NOTE: as in the reference, the 4th argument is passed to the op as num_seq_q (callers pass
+    num_seq_q = mtp + 1 here, tests/test_attention_decode_bf16.py:105-121 of the reference).
+    `num_seq_kvcache` may live on the GPU (device scheduler) or on the CPU (host scheduler, then
+    three byte ranges are copied into the device workspace); both give byte-identical maps.
+    """
+    if num_seq_kvcache.device.type == "cpu":
+        task_map_host = torch.ops.hpc.assign_attention_decode_task(
+            num_seq_kvcache, num_head_kv, mtp, new_kv_included, min_process_len, None
+        )
+        flat = task_map_host.reshape(-1)
+        task_map[:8].copy_(flat[:8], non_blocking=True)
+        task_map[20:24].copy_(flat[20:24], non_blocking=True)  # max chunks per request
+        task_map[48 : flat.numel()].copy_(flat[48:], non_blocking=True)
+        return task_map
+    return torch.ops.hpc.assign_attention_decode_task(
+        num_seq_kvcache, num_head_kv, mtp, new_kv_included, min_process_len, task_map
+    )
+
+
+def print_attention_decode_task(task_map: Tensor) -> None:
+    """Pretty-print a task map (reference hpc/attention.py:629-696)."""
+    stride = 12
+    task = task_map.view(torch.int32).reshape(-1)
+    task = task[: task.numel() // stride * stride].reshape(-1, stride).cpu()
+    per1, bins = int(task[0][0]), int(task[0][1])
+    num_head_kv, max_num_batch = int(task[0][2]), int(task[0][3])
+    chunk_row = 1 + bins * per1
+    chunks = task[chunk_row:].reshape(-1)[: num_head_kv * max_num_batch]
+    print(
+        f"\n[Dynamic Decode Attn Task Map] num_tile_per_cta={per1 - 1}, num_head_kv={num_head_kv}, "
+        f"max_num_batch={max_num_batch}, num_total_ctas={bins}"
+    )
+    print(f"num_chunks[ihead_kv, ibatch]:\n{chunks.reshape(num_head_kv, max_num_batch)}\n")
+    idx, empty = 0, 0
+    for icta in range(bins):
+        rows = task[1 + icta * per1 : 1 + (icta + 1) * per1]
+        if int(rows[0][0]) < 0 or int(rows[0][1]) < 0:
+            empty += 1
+            continue
+        print(f"#######CTA{icta}########")
+        ntask, seqkv = 0, 0
+        for row in rows[: per1 - 1]:
+            r = [int(v) for v in row]
+            if r[0] < 0 or r[1] < 0:
+                break
+            print(
+                f"task:{idx}, ihead_kv:{r[0]}, ibatch:{r[1]}, ichunk:{r[2]}, iseq_start:{r[3]}, "
+                f"num_seqkv:{r[4]}, num_seqkvcache:{r[5]}, num_tile_kv:{r[6]}, "
+                f"num_tile_full:{r[7]}, is_casual_chunk:{r[8]}"
+            )
+            idx += 1
+            ntask += 1
+            seqkv += r[4]
+        print(f"CTA:{icta}, num_tasks:{ntask}, total_seqkv:{seqkv}")
+    print(f"[idle] {empty}/{bins} bins were empty")
+
+
+@torch.library.register_fake("hpc::attention_decode_bf16")
+def attention_decode_bf16_fake(
+    q, kcache, vcache, block_ids, num_seq_kvcache, mtp, new_kv_included, splitk,
+    task_map=None, split_flag=None, output=None,
+):
+    return torch.empty_like(q)

@@ -43,6 +43,59 @@ int hpc_fused_rmsnorm_with_scale_async(const void* input, const void* weight, vo
                                        const void* scale, float eps, int batch_size,
                                        int hidden_state, int is_moe, hpc_stream_t stream);
 
+/* ---- decode attention: dynamic split-KV tile scheduler ----------------------------------------
+ * reference: assign_attention_decode_task_{sync,async}, src/attention/decode/decode.h:37-46,
+ *            src/attention/decode/assign_task.cu:333-492, CPU entry packing src/attention/entry.cc:727-778,
+ *            record/bins constants src/attention/decode/sched_task_info.h:18-36.
+ * Task-map layout (int32 rows of 12) is the reference's; see hpc-ops_amd/csrc/sched_task_info.h.
+ *
+ * hpc_attention_decode_num_bins: number of scheduler bins (= decode workgroups) on `device_id`
+ *   for num_seq_q in 1..5 (reference: kCtaPerSmMap[sm][num_seq_q-1] * get_sm_count()).
+ * hpc_attention_decode_tile_n:   KV tokens per scheduling tile (64).
+ * hpc_assign_attention_decode_task_rows / _sync: host scheduler. `_rows` returns the number of
+ *   48-byte rows the host image needs (1 + bins*(tiles_per_bin+1) + ceil(Hkv*B*4/48)); `_sync`
+ *   fills `task_map` (>= rows*12 ints) like the reference CPU entry and returns rows.
+ * hpc_assign_attention_decode_task_async: device scheduler; `task_map` is the workspace of
+ *   hpc.get_attention_decode_task_workspace (header ints 2..4 pre-filled by the allocator),
+ *   num_seq_kvcache is a device pointer.  Byte-identical to the host scheduler. */
+int hpc_attention_decode_num_bins(int num_seq_q, int device_id);
+int hpc_attention_decode_tile_n(void);
+int hpc_assign_attention_decode_task_rows(const int* num_seq_kvcache, int num_total_ctas,
+                                          int num_batch, int num_head_kv, int num_seq_q,
+                                          int new_kv_included, int min_process_len);
+int hpc_assign_attention_decode_task_sync(const int* num_seq_kvcache, int num_total_ctas,
+                                          int num_batch, int num_head_kv, int num_seq_q,
+                                          int new_kv_included, int min_process_len, int* task_map,
+                                          int task_map_rows);
+int hpc_assign_attention_decode_task_async(int* task_map, const int* num_seq_kvcache,
+                                           int num_total_ctas, int num_batch, int num_head_kv,
+                                           int num_seq_q, int new_kv_included, int min_process_len,
+                                           hpc_stream_t stream);
+
+/* ---- decode attention (paged KV, D = 128, GQA group 4 or 8) ----------------------------------------
+ * reference: attention_decode_bf16_async / attention_decode_fp8_async,
+ *            src/attention/decode/decode.h:17-35 (kernels under src/attention/decode/sm90/).
+ * q [B*Sq, Hq, 128] (row stride ldQ elements), kcache/vcache logical [blocks, block_size, Hkv, 128]
+ * with element strides (block, token, head), block_ids int32 [B, num_seq_max_blocks],
+ * y bf16 [B*Sq, Hq, 128] (row stride ldY).  `task_map_ptr` is a task map produced by the
+ * scheduler above for the same num_seq_kvcache / num_seq_q / new_kv_included; `num_bins` must be
+ * its header[1].  `workspace` holds the fp32 split-KV partials: hpc_attention_decode_workspace_bytes
+ * bytes, no initialisation needed (the reference allocates lse/split_out per call,
+ * src/attention/entry.cc:492-499; here it is 2 slots per bin instead of splitk slots per request).
+ * The split-KV combine runs inside the call (second kernel on the same stream). */
+int64_t hpc_attention_decode_workspace_bytes(int num_bins, int num_batch, int num_head_kv,
+                                             int num_seq_q, int heads_per_group);
+int hpc_attention_decode_bf16_async(void* y_ptr, void* workspace, const int* task_map_ptr,
+                                    const void* q_ptr, const void* kcache_ptr,
+                                    const void* vcache_ptr, const int* block_ids_ptr, int num_bins,
+                                    int num_batch, int num_seq_q, int num_head_q, int num_head_kv,
+                                    int num_dim_qk, int num_dim_v, int block_size,
+                                    int num_seq_max_blocks, int ldY, int ldQ,
+                                    int64_t kcache_block_stride, int64_t kcache_token_stride,
+                                    int64_t kcache_head_stride, int64_t vcache_block_stride,
+                                    int64_t vcache_token_stride, int64_t vcache_head_stride,
+                                    hpc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

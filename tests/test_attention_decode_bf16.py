@@ -1,0 +1,124 @@
+"""Parity of hpc.attention_decode_bf16 (HIP via the C-ABI) with the CPU oracle.
+Cases, generator, seeds and tolerance follow reference tests/test_attention_decode_bf16.py:62-247
+(atol 0.016), plus GQA group 8 with 8 kv heads (BASELINE config C2 family), page sizes 16/32,
+mtp > 0 without new_kv_included, and requests that split over many bins."""
+import math
+
+import pytest
+import torch
+
+from utils import allclose
+
+
+def _build_case(num_batch, num_seq_q, lens_before, block_size, kv_head_q_head, kvcache_shape, seed=41):
+    """lens_before: int32 [B] tokens in cache before the Sq new ones. Returns CPU tensors."""
+    torch.manual_seed(seed)
+    num_head_kv, num_head_q = kv_head_q_head
+    D = 128
+    q = torch.randn((num_batch * num_seq_q, num_head_q, D), dtype=torch.bfloat16) / math.sqrt(D)
+    k = torch.randn((num_batch * num_seq_q, num_head_kv, D), dtype=torch.bfloat16) / math.sqrt(D)
+    v = torch.randn((num_batch * num_seq_q, num_head_kv, D), dtype=torch.bfloat16)
+    nblocks = (lens_before + num_seq_q + block_size - 1) // block_size
+    total_blocks = int(nblocks.sum())
+    max_num_blocks = int(total_blocks * 1.2) + 4
+    kvcache = torch.randn(max_num_blocks, 2, block_size, num_head_kv, D, dtype=torch.bfloat16)
+    packed = torch.randperm(max_num_blocks)[:total_blocks].to(torch.int32)
+    block_ids = torch.full((num_batch, int(nblocks.max())), -123456, dtype=torch.int32)
+    cu = 0
+    kr = k.reshape(num_batch, num_seq_q, num_head_kv, D)
+    vr = v.reshape(num_batch, num_seq_q, num_head_kv, D)
+    for i in range(num_batch):
+        nb = int(nblocks[i])
+        block_ids[i, :nb] = packed[cu : cu + nb]
+        cu += nb
+        for s in range(num_seq_q):
+            si = s + int(lens_before[i])
+            kvcache[block_ids[i, si // block_size], 0, si % block_size] = kr[i, s]
+            kvcache[block_ids[i, si // block_size], 1, si % block_size] = vr[i, s]
+    return q, kvcache, block_ids, nblocks
+
+
+def _run(num_batch, num_seq_q, lens_before, block_size, kv_head_q_head, new_kv_included,
+         use_output, use_dynamic_sched, kvcache_shape, min_process_len=64):
+    import hpc
+    from oracle import attention as oattn
+
+    num_head_kv, num_head_q = kv_head_q_head
+    q, kvcache, block_ids, nblocks = _build_case(
+        num_batch, num_seq_q, lens_before, block_size, kv_head_q_head, kvcache_shape)
+    gt = oattn.ref_attn_with_paged_kvcache(q, kvcache, block_ids, nblocks, num_seq_q, lens_before)
+
+    kv_dev = kvcache.cuda()
+    if kvcache_shape == "HND":
+        kv_dev = kv_dev.permute(0, 1, 3, 2, 4).contiguous().permute(0, 1, 3, 2, 4)
+    lens_dev = lens_before.cuda()
+    lens_in = lens_dev + num_seq_q if new_kv_included else lens_dev
+    task_map = None
+    if use_dynamic_sched:
+        task_map = hpc.get_attention_decode_task_workspace(
+            num_batch, int(lens_before.max()) + num_seq_q, num_head_kv, min_process_len=min_process_len)
+        hpc.assign_attention_decode_task(lens_in, task_map, num_head_kv, num_seq_q, new_kv_included,
+                                         min_process_len=min_process_len)
+    out = torch.empty_like(q).cuda() if use_output else None
+    my = hpc.attention_decode_bf16(
+        q.cuda(), kv_dev[:, 0], kv_dev[:, 1], block_ids.cuda(), lens_in, mtp=num_seq_q - 1,
+        new_kv_included=new_kv_included, splitk=True, task_map=task_map, output=out)
+    torch.cuda.synchronize()
+    if use_output:
+        assert my.data_ptr() == out.data_ptr()
+    assert allclose(gt, my.cpu(), atol=0.016)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_batch", [1, 16, 200])
+@pytest.mark.parametrize("num_seq_q", [1, 2])
+@pytest.mark.parametrize("max_seq_kv", [1024, 4096])
+@pytest.mark.parametrize("kv_head_q_head", [(1, 8), (4, 32)])
+@pytest.mark.parametrize("use_dynamic_sched", [False, True])
+@pytest.mark.parametrize("kvcache_shape", ["NHD", "HND"])
+def test_attn_bf16_reference_grid(num_batch, num_seq_q, max_seq_kv, kv_head_q_head,
+                                  use_dynamic_sched, kvcache_shape):
+    torch.manual_seed(41)
+    lens = torch.randint(1, max_seq_kv, (num_batch,), dtype=torch.int32)
+    _run(num_batch, num_seq_q, lens, 64, kv_head_q_head, True, False, use_dynamic_sched, kvcache_shape)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block_size", [16, 32, 64])
+@pytest.mark.parametrize("kv_head_q_head", [(2, 8), (8, 64)])
+@pytest.mark.parametrize("num_seq_q,new_kv_included", [(1, False), (2, True), (2, False)])
+def test_attn_bf16_pages_groups(block_size, kv_head_q_head, num_seq_q, new_kv_included):
+    if kv_head_q_head == (8, 64) and num_seq_q * 8 > 16:
+        pytest.skip("q rows > 16")
+    torch.manual_seed(7)
+    lens = torch.randint(1, 700, (9,), dtype=torch.int32)
+    lens[0] = 1
+    lens[1] = 63
+    lens[2] = 64
+    lens[3] = 65
+    _run(9, num_seq_q, lens, block_size, kv_head_q_head, new_kv_included, True, True, "NHD")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lens", [[8191] * 8, [16000, 3, 130, 65, 4097], [40000]])
+def test_attn_bf16_split_requests(lens):
+    """long requests split over many bins -> fp32 partials + combine kernel"""
+    lens = torch.tensor(lens, dtype=torch.int32)
+    _run(len(lens), 1, lens, 64, (2, 16), True, False, True, "HND")
+    _run(len(lens), 2, lens, 64, (2, 16), True, False, True, "NHD")
+
+
+@pytest.mark.gpu
+def test_attn_bf16_errors():
+    import hpc
+
+    q = torch.randn(2, 8, 64, dtype=torch.bfloat16, device="cuda")
+    kv = torch.randn(4, 64, 1, 64, dtype=torch.bfloat16, device="cuda")
+    bid = torch.zeros(2, 2, dtype=torch.int32, device="cuda")
+    lens = torch.tensor([3, 4], dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError):  # head dim 64
+        hpc.attention_decode_bf16(q, kv, kv, bid, lens)
+    q = torch.randn(2, 3, 128, dtype=torch.bfloat16, device="cuda")
+    kv = torch.randn(4, 64, 1, 128, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(RuntimeError):  # group 3
+        hpc.attention_decode_bf16(q, kv, kv, bid, lens)

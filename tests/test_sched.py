@@ -1,0 +1,137 @@
+"""Decode scheduler: oracle pinned on golden vectors made from the reference's own function;
+product host scheduler (C-ABI) == oracle; product device scheduler == host scheduler (GPU)."""
+import ctypes
+import hashlib
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests" / "golden"))
+from sched_cases import cases  # noqa: E402
+
+CASES = cases()
+IDS = [c[0] for c in CASES]
+_IP = ctypes.POINTER(ctypes.c_int)
+
+
+def _golden():
+    return np.load(ROOT / "tests" / "golden" / "sched_golden.npz")
+
+
+def _product_host_map(lens, bins, hkv, sq, nkv, minlen):
+    lib = ctypes.CDLL(str(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so"))
+    lens = np.ascontiguousarray(lens, dtype=np.int32)
+    lp = lens.ctypes.data_as(_IP)
+    rows = lib.hpc_assign_attention_decode_task_rows(lp, bins, len(lens), hkv, sq, int(nkv), minlen)
+    assert rows > 0
+    out = np.full((rows, 12), -7, dtype=np.int32)
+    got = lib.hpc_assign_attention_decode_task_sync(lp, bins, len(lens), hkv, sq, int(nkv), minlen,
+                                                    out.ctypes.data_as(_IP), rows)
+    assert got == rows
+    return out
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_oracle_matches_reference_golden(case):
+    from oracle import sched
+
+    name, lens, bins, hkv, sq, nkv, minlen = case
+    g = _golden()
+    ora = sched.task_map_oracle(lens, bins, hkv, sq, nkv, minlen)
+    sha = np.frombuffer(hashlib.sha256(ora.tobytes()).digest(), np.uint8)
+    assert np.array_equal(sha, g[name + "__sha"])
+    if name + "__map" in g:
+        assert np.array_equal(ora, g[name + "__map"])
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_product_host_scheduler_matches_oracle(case):
+    from oracle import sched
+
+    name, lens, bins, hkv, sq, nkv, minlen = case
+    ora = sched.task_map_oracle(lens, bins, hkv, sq, nkv, minlen)
+    mine = _product_host_map(lens, bins, hkv, sq, nkv, minlen)
+    assert mine.shape == ora.shape
+    assert np.array_equal(mine, ora)
+
+
+def test_oracle_matches_reference_build_when_present():
+    from oracle import sched
+
+    if not sched.have_ref():
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    rng = np.random.default_rng(123)
+    for _ in range(60):
+        B = int(rng.integers(1, 80))
+        sq = int(rng.integers(1, 6))
+        lens = np.maximum(rng.integers(0, 3000, B).astype(np.int32), sq)
+        bins, hkv = int(rng.integers(1, 700)), int(rng.integers(1, 9))
+        nkv = bool(rng.integers(0, 2))
+        if not nkv:
+            lens = lens - sq
+        minlen = int(rng.choice([64, 128, 512]))
+        ref = sched.mask_pad(sched.task_map_ref(lens, bins, hkv, sq, nkv, minlen), bins)
+        ora = sched.task_map_oracle(lens, bins, hkv, sq, nkv, minlen)
+        assert np.array_equal(ref, ora)
+
+
+def test_schedule_covers_every_tile_exactly_once():
+    """size-independent property at BASELINE sizes: tasks tile each (head, request) exactly."""
+    from oracle import sched
+
+    rng = np.random.default_rng(5)
+    lens = rng.integers(128, 32768, 64).astype(np.int32)
+    bins, hkv = 512, 8
+    tm = _product_host_map(lens, bins, hkv, 1, True, 64)
+    per1 = tm[0, 0]
+    cover = np.zeros((hkv, len(lens)), dtype=np.int64)
+    nchunk = np.zeros((hkv, len(lens)), dtype=np.int64)
+    for b in range(bins):
+        used = 0
+        for i in range(per1):
+            r = tm[1 + b * per1 + i]
+            if r[0] < 0:
+                break
+            assert r[3] == cover[r[0], r[1]]  # chunks are contiguous and in order
+            assert r[2] == nchunk[r[0], r[1]]
+            cover[r[0], r[1]] += r[4]
+            nchunk[r[0], r[1]] += 1
+            used += r[6]
+        assert used <= per1 - 1
+    assert np.array_equal(cover, np.broadcast_to(lens, cover.shape))
+    tab = tm[1 + bins * per1 :].reshape(-1)[: hkv * len(lens)].reshape(hkv, len(lens))
+    assert np.array_equal(tab, nchunk)
+    assert tm[0, 5] == nchunk.max()
+    assert np.array_equal(tm, sched.task_map_oracle(lens, bins, hkv, 1, True, 64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_device_scheduler_matches_host_bytes(case):
+    """reference tests/test_attention_decode_bf16.py:123-131: CPU-vs-GPU byte equality of the
+    scheduler prefix of the task map (here for every case, with this GPU's own bin count)."""
+    import torch
+
+    import hpc
+    from oracle import sched
+
+    name, lens, _, hkv, sq, nkv, minlen = case
+    lens_t = torch.from_numpy(np.ascontiguousarray(lens, dtype=np.int32))
+    B = len(lens)
+    ws_cpu = hpc.get_attention_decode_task_workspace(B, int(lens.max()) + sq + 64, hkv, minlen)
+    ws_gpu = hpc.get_attention_decode_task_workspace(B, int(lens.max()) + sq + 64, hkv, minlen)
+    hpc.assign_attention_decode_task(lens_t, ws_cpu, hkv, sq, nkv, minlen)
+    hpc.assign_attention_decode_task(lens_t.cuda(), ws_gpu, hkv, sq, nkv, minlen)
+    torch.cuda.synchronize()
+    bins = int(ws_gpu.view(torch.int32)[1])
+    per1 = int(ws_gpu.view(torch.int32)[0])
+    need = (per1 * bins + 1) * 48 + (B * hkv * 4 + 47) // 48 * 48
+    assert torch.equal(ws_cpu[:need].cpu(), ws_gpu[:need].cpu())
+    # and both equal the oracle with this bin count
+    ora = sched.task_map_oracle(lens, bins, hkv, sq, nkv, minlen)
+    got = ws_gpu.view(torch.int32).cpu().numpy()[: ora.size].reshape(ora.shape).copy()
+    got[0, 2:5] = 0  # allocator-owned header ints
+    assert np.array_equal(got, ora)
