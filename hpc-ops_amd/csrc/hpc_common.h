@@ -101,11 +101,14 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned num_recor
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, num_records, 0x00020000);
 }
 // voff: per-lane byte offset (may carry a compile-time constant), soff: wave-uniform byte offset
+// kAux: cache policy bits of the buffer instruction (0 = default, 2 = nt "streaming, read once")
+template <int kAux = 0>
 __device__ __forceinline__ u32x4 buf_ld16(rsrc_t rs, int voff, int soff) {
-  return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+  return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, kAux);
 }
+template <int kAux = 0>
 __device__ __forceinline__ u32x2 buf_ld8(rsrc_t rs, int voff, int soff) {
-  return __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0);
+  return __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, kAux);
 }
 
 }  // namespace hpc

@@ -56,3 +56,13 @@ extern "C" int hpc_get_cu_count(int device_id) {
   }
   return cache[device_id];
 }
+
+// Tuning knobs (development hook, not part of the reference surface): small integer registers
+// read by the launchers.  key 0: decode KV load cache policy (0 = nt/default choice, 1 = temporal).
+static int g_tuning[16];
+extern "C" int hpc_tuning_set(int key, int value) {
+  if (key < 0 || key >= 16) return -2;
+  g_tuning[key] = value;
+  return 0;
+}
+extern "C" int hpc_tuning_get(int key) { return (key < 0 || key >= 16) ? 0 : g_tuning[key]; }

@@ -40,6 +40,8 @@ def _sig(name, restype, *argtypes):
 _sig("hpc_version", c_char_p)
 _sig("hpc_built_json", c_char_p)
 _sig("hpc_get_cu_count", I, I)
+_sig("hpc_tuning_set", I, I, I)
+_sig("hpc_tuning_get", I, I)
 _sig("hpc_fused_rmsnorm_with_scale_async", I, P, P, P, P, P, P, F, I, I, I, P)
 IP = ctypes.POINTER(c_int)
 _sig("hpc_attention_decode_num_bins", I, I, I)
@@ -50,6 +52,8 @@ _sig("hpc_assign_attention_decode_task_async", I, IP, IP, I, I, I, I, I, I, P)
 _sig("hpc_attention_decode_workspace_bytes", L, I, I, I, I, I)
 _sig("hpc_attention_decode_bf16_async", I, P, P, IP, P, P, P, IP, I, I, I, I, I, I, I, I, I, I, I,
      L, L, L, L, L, L, P)
+_sig("hpc_attention_decode_fp8_async", I, P, P, IP, P, P, P, IP, P, P, P, I, I, I, I, I, I, I, I, I, I,
+     I, I, I, L, L, L, L, L, L, L, L, L, P)
 
 # torch op namespace `hpc` (reference: TORCH_LIBRARY(hpc, m), src/C/C.cc:5)
 torch_lib = torch.library.Library("hpc", "DEF")

@@ -22,6 +22,13 @@ _T.define(
     "Tensor? split_flag, Tensor? output) -> (Tensor)"
 )
 
+_T.define(
+    "attention_decode_fp8(Tensor q, Tensor! kcache, Tensor! vcache, Tensor block_ids, Tensor "
+    "num_seq_kvcache, Tensor qscale, Tensor kscale, Tensor vscale, int mtp, bool "
+    "new_kv_included, int quant_type, bool use_splitk, Tensor? task_map, Tensor? split_flag, "
+    "Tensor? output) -> (Tensor)"
+)
+
 _INT_P = ctypes.POINTER(ctypes.c_int)
 
 
@@ -173,3 +180,52 @@ def _attention_decode_bf16_entry(q, kcache, vcache, block_ids, num_seq_kvcache, 
 
 
 _T.impl("attention_decode_bf16", _attention_decode_bf16_entry, "CUDA")
+
+
+def _attention_decode_fp8_entry(q, kcache, vcache, block_ids, num_seq_kvcache, qscale, kscale,
+                                vscale, mtp, new_kv_included, quant_type, use_splitk, task_map,
+                                split_flag, output):
+    # reference attention_decode_fp8_entry, src/attention/entry.cc:569-725
+    num_batch, num_seq_q, group = _decode_common_checks(
+        q, kcache, vcache, block_ids, num_seq_kvcache, mtp, 3)
+    _C.require(q.dtype == torch.float8_e4m3fn, "q dtype must be fp8_e4m3fn")
+    _C.require(kcache.element_size() == 1, "kcache tensor element type size must be fp8_e4m3")
+    _C.require(vcache.element_size() == 1, "vcache tensor element type size must be fp8_e4m3")
+    _C.require(qscale.dtype == torch.float32 and vscale.dtype == torch.float32,
+               "qscale / vscale must be float32")
+    _C.require(quant_type in (0, 1), "quant_type must be QPERTOKEN_PERHEAD_KPERTOKEN_PERHEAD_VPERHEAD "
+               "or QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR")
+    block_size = kcache.size(1)
+    if quant_type == 0:
+        _C.require(block_size in (32, 64), "kvcache paged blocksize must be 32 or 64.")
+        _C.require(kscale.dim() == 4 and kscale.stride(3) == 1 and kscale.element_size() == 1,
+                   "per-token kscale must be the byte view of the K-cache tail rows")
+        ks = (kscale.stride(0), kscale.stride(1), kscale.stride(2))
+    else:
+        _C.require(block_size in (16, 32, 64), "kvcache paged blocksize must be 16, 32 or 64.")
+        _C.require(kscale.dtype == torch.float32 and kscale.numel() >= 1, "kscale must be float32 [1]")
+        ks = (0, 0, 0)
+    num_head_q, num_head_kv = q.size(1), kcache.size(2)
+    if task_map is None:
+        task_map = _schedule_on_the_fly(num_seq_kvcache, block_ids, block_size, num_head_kv,
+                                        num_seq_q, new_kv_included)
+    else:
+        _C.require(task_map.is_cuda and task_map.is_contiguous(), "task_map tensor must be cuda, contiguous")
+    y = output if output is not None else torch.empty(
+        (num_batch * num_seq_q, num_head_q, vcache.size(3)), dtype=torch.bfloat16, device=q.device)
+    bins = num_bins(num_seq_q, q.device)
+    ws_bytes = _C.lib.hpc_attention_decode_workspace_bytes(bins, num_batch, num_head_kv, num_seq_q, group)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+    rc = _C.lib.hpc_attention_decode_fp8_async(
+        _C.ptr(y), _C.ptr(ws), ctypes.cast(task_map.data_ptr(), _INT_P), _C.ptr(q), _C.ptr(kcache),
+        _C.ptr(vcache), ctypes.cast(block_ids.data_ptr(), _INT_P), _C.ptr(qscale), _C.ptr(kscale),
+        _C.ptr(vscale), int(quant_type), bins, num_batch, num_seq_q, num_head_q, num_head_kv,
+        q.size(2), vcache.size(3), block_size, block_ids.size(1), qscale.stride(0), y.stride(0),
+        q.stride(0), kcache.stride(0), kcache.stride(1), kcache.stride(2), vcache.stride(0),
+        vcache.stride(1), vcache.stride(2), ks[0], ks[1], ks[2], _C.stream_of(q),
+    )
+    _C.check(rc, "attn decode kernel")
+    return y
+
+
+_T.impl("attention_decode_fp8", _attention_decode_fp8_entry, "CUDA")

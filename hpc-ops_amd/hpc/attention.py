@@ -55,6 +55,41 @@ def attention_decode_bf16(
     )
 
 
+def attention_decode_fp8(
+    q: Tensor,
+    kcache: Tensor,
+    vcache: Tensor,
+    block_ids: Tensor,
+    num_seq_kvcache: Tensor,
+    qscale: Tensor,
+    kscale: Tensor,
+    vscale: Tensor,
+    mtp: int = 0,
+    new_kv_included: bool = False,
+    quant_type: QuantType = QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR,
+    splitk: bool = True,
+    task_map: Tensor = None,
+    split_flag: Tensor = None,
+    output: Tensor = None,
+) -> Tensor:
+    """Paged decode attention with FP8 (e4m3) Q/K/V (reference hpc/attention.py:420-517):
+    softmax(Q K^T * qscale * kscale / sqrt(head_dim)) V * vscale, bfloat16 output.
+
+    Args (beyond attention_decode_bf16):
+        q: [num_batch * num_seq_q, num_head_q, 128] float8_e4m3fn.
+        kcache / vcache: paged caches of 1-byte elements (float8_e4m3fn).
+        qscale: float32 [num_batch * num_seq_q, num_head_q] per-token per-head Q scale.
+        kscale: float32 [1] (QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR) or the view of the K-cache
+            tail rows `kcache_full[:, block_size:]` holding per-token per-head fp32 scales
+            (QPERTOKEN_PERHEAD_KPERTOKEN_PERHEAD_VPERHEAD).
+        vscale: float32 [1] or [num_head_kv].
+    """
+    return torch.ops.hpc.attention_decode_fp8(
+        q, kcache, vcache, block_ids, num_seq_kvcache, qscale, kscale, vscale, mtp,
+        new_kv_included, quant_type.value, splitk, task_map, split_flag, output,
+    )
+
+
 def get_attention_decode_task_workspace(
     max_num_batch: int, max_seqlen: int, num_head_kv: int, min_process_len: int = 512
 ):
@@ -143,3 +178,11 @@ def attention_decode_bf16_fake(
     task_map=None, split_flag=None, output=None,
 ):
     return torch.empty_like(q)
+
+
+@torch.library.register_fake("hpc::attention_decode_fp8")
+def attention_decode_fp8_fake(
+    q, kcache, vcache, block_ids, num_seq_kvcache, qscale, kscale, vscale, mtp, new_kv_included,
+    quant_type, splitk, task_map=None, split_flag=None, output=None,
+):
+    return torch.empty_like(q, dtype=torch.bfloat16)

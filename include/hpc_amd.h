@@ -32,6 +32,11 @@ const char* hpc_built_json(void);
  * here per device, not a device-0 cache). */
 int hpc_get_cu_count(int device_id);
 
+/* Development tuning registers (no reference counterpart): key 0..15 -> small int read by the
+ * launchers (see csrc/library.hip).  Defaults (all 0) are the shipped configuration. */
+int hpc_tuning_set(int key, int value);
+int hpc_tuning_get(int key);
+
 /* ---- RMSNorm (+fp8 quant) ------------------------------------------------------------------
  * reference: fused_rmsnorm_with_scale_async, src/normalization/fused_rmsnorm_with_scale.h:19-22
  *            kernel src/normalization/fused_rmsnorm_with_scale.cu:14-137.
@@ -95,6 +100,27 @@ int hpc_attention_decode_bf16_async(void* y_ptr, void* workspace, const int* tas
                                     int64_t kcache_head_stride, int64_t vcache_block_stride,
                                     int64_t vcache_token_stride, int64_t vcache_head_stride,
                                     hpc_stream_t stream);
+/* FP8 (OCP e4m3fn) variant.  q e4m3 [B*Sq, Hq, 128]; qscale f32 [B*Sq, qscale_pad_stride] (row
+ * b*Sq+s, column q head); quant_type 1 (QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR): kscale f32[1],
+ * vscale f32[1]; quant_type 0 (QPERTOKEN_PERHEAD_KPERTOKEN_PERHEAD_VPERHEAD): kscale_ptr = base of
+ * the K-scale rows that follow the block_size token rows of every K page (row r of head h holds
+ * the fp32 scales of tokens 32r..32r+31 as 128 raw bytes; byte strides given explicitly - the
+ * reference reads them through a TMA view, sm90/dynamic/...qkpertoken..._dynamic.cu:84-91),
+ * vscale f32[Hkv].  Numerics: P~ = e4m3(256 * 2^(s - running max)), O = sum(P~ V)/sum(p) * vscale/256.
+ * num_seq_q <= 4.  block_size 16/32/64 for quant_type 1, 32/64 for quant_type 0. */
+int hpc_attention_decode_fp8_async(void* y_ptr, void* workspace, const int* task_map_ptr,
+                                   const void* q_ptr, const void* kcache_ptr,
+                                   const void* vcache_ptr, const int* block_ids_ptr,
+                                   const float* qscale_ptr, const void* kscale_ptr,
+                                   const float* vscale_ptr, int quant_type, int num_bins,
+                                   int num_batch, int num_seq_q, int num_head_q, int num_head_kv,
+                                   int num_dim_qk, int num_dim_v, int block_size,
+                                   int num_seq_max_blocks, int qscale_pad_stride, int ldY, int ldQ,
+                                   int64_t kcache_block_stride, int64_t kcache_token_stride,
+                                   int64_t kcache_head_stride, int64_t vcache_block_stride,
+                                   int64_t vcache_token_stride, int64_t vcache_head_stride,
+                                   int64_t kscale_block_stride, int64_t kscale_row_stride,
+                                   int64_t kscale_head_stride, hpc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -37,3 +37,113 @@ def ref_attn_with_paged_kvcache(q, kvcache, block_ids, nblocks, num_seq_q, num_s
         y = torch.matmul(F.softmax(p, dim=-1), v_batch)
         out[bi] = y.transpose(0, 1).to(out.dtype)
     return out.reshape(-1, num_head_q, head_dim)
+
+
+def ref_attn_paged_separate(q, k_cache, v_cache, block_ids, kv_lens_total, num_seq_q, rows=None):
+    """Same oracle for separate K / V caches [nblk, P, Hkv, D] and lens that already include the
+    Sq new tokens (the reference benchmark generator's layout,
+    benchmark/attention_decode/bench_attention_decode_bf16.py:125-154).  `rows` restricts the
+    computation to a subset of requests (bounded CPU-baseline sample)."""
+    num_batch = kv_lens_total.shape[0]
+    num_head_q, head_dim = q.shape[1], q.shape[2]
+    P, num_head_kv = k_cache.shape[1], k_cache.shape[2]
+    group = num_head_q // num_head_kv
+    qb = q.reshape(num_batch, num_seq_q, num_head_q, head_dim)
+    rows = range(num_batch) if rows is None else rows
+    outs = []
+    for bi in rows:
+        seqlen = int(kv_lens_total[bi])
+        nb = (seqlen + P - 1) // P
+        blk = block_ids[bi, :nb].long()
+        qf = qb[bi].transpose(0, 1).float()
+        kf = (k_cache[blk].reshape(-1, num_head_kv, head_dim).transpose(0, 1)[:, :seqlen]
+              .repeat_interleave(group, dim=0)).float()
+        vf = (v_cache[blk].reshape(-1, num_head_kv, head_dim).transpose(0, 1)[:, :seqlen]
+              .repeat_interleave(group, dim=0)).float()
+        p = qf @ kf.transpose(-1, -2) / math.sqrt(head_dim)
+        sq = num_seq_q
+        causal = torch.cat(
+            [torch.ones(sq, seqlen - sq, dtype=torch.bool),
+             torch.tril(torch.ones(sq, sq, dtype=torch.bool))], dim=-1).unsqueeze(0)
+        p = p.masked_fill(~causal, float("-inf"))
+        y = torch.matmul(F.softmax(p, dim=-1), vf)
+        outs.append(y.transpose(0, 1).to(q.dtype))
+    return torch.stack(outs, 0)
+
+
+# ---- FP8 decode oracles --------------------------------------------------------------------------
+def quant_paged_cache_pertoken(cache, block_size):
+    """reference tests/test_attention_decode_qkpertoken_perhead_vperhead_fp8.py:14-36.
+    cache [nblk, P + P*4/128, Hkv, 128] (float): returns (fp8 cache incl. scale rows, scale view)."""
+    num_blocks, head_dim, num_head_kv = cache.shape[0], cache.shape[-1], cache.shape[-2]
+    scale = cache[:, :block_size].float().abs().max(-1)[0] / 448
+    cache_fp8 = torch.empty_like(cache, dtype=torch.float8_e4m3fn)
+    cache_fp8[:, :block_size] = (cache[:, :block_size] / scale[:, :, :, None]).to(torch.float8_e4m3fn)
+    scale = (scale.permute(0, 2, 1).contiguous().view(torch.float8_e4m3fn)
+             .reshape(num_blocks, num_head_kv, -1, head_dim).permute(0, 2, 1, 3).contiguous())
+    cache_fp8[:, block_size:] = scale
+    return cache_fp8, cache_fp8[:, block_size:]
+
+
+def quant_paged_cache_perhead(cache, block_size):
+    """reference tests/test_attention_decode_qkpertoken_perhead_vperhead_fp8.py:38-50."""
+    num_head_kv = cache.shape[-2]
+    scale = (cache[:, :block_size].float().abs().permute(2, 0, 1, 3).reshape(num_head_kv, -1)
+             .max(-1)[0] / 448)
+    cache_fp8 = (cache.float() / scale[None, None, :, None]).to(torch.float8_e4m3fn)
+    return cache_fp8, scale * 0.1
+
+
+def ref_attn_fp8(q, kvcache, block_ids, nblocks, num_seq_q, num_seq_kvcache, q_scale, k_scale,
+                 v_scale, k_per_token, literal_qscale_row=False):
+    """FP8 decode oracle.  k_per_token False: reference
+    tests/test_attention_decode_qpertoken_perhead_kvpertensor_fp8.py:14-79 (k_scale, v_scale [1]);
+    True: tests/test_attention_decode_qkpertoken_perhead_vperhead_fp8.py:53-133 (k_scale = byte view
+    of the cache tail rows [nblk, rows, Hkv, 128], v_scale [Hkv]).
+    q e4m3 [B*Sq, Hq, D]; kvcache e4m3 [nblk, 2, P, Hkv, D] (token rows only).
+    The reference test indexes q_scale[bi] (row bi of [B*Sq, Hq]) for every q row of request bi -
+    right only for Sq == 1 and hidden by its tolerance; the kernels use row bi*Sq+s
+    (reference ..._kernels.cuh:280-293).  Default here is the kernel's indexing;
+    literal_qscale_row=True reproduces the test's."""
+    num_batch = num_seq_kvcache.shape[0]
+    num_head_q, head_dim = q.shape[1], q.shape[2]
+    num_head_kv = kvcache.shape[3]
+    group = num_head_q // num_head_kv
+    qb = q.reshape(num_batch, -1, num_head_q, head_dim)
+    qs = q_scale.reshape(num_batch, -1, num_head_q)
+    out = torch.empty(qb.shape, dtype=torch.bfloat16)
+    for bi in range(num_batch):
+        sq = num_seq_q
+        q_batch = qb[bi].transpose(0, 1).float()
+        blk = block_ids[bi, : int(nblocks[bi])].long()
+        seqlen = sq + int(num_seq_kvcache[bi])
+        k_batch = (kvcache[blk, 0].reshape(-1, num_head_kv, head_dim).transpose(0, 1)[:, :seqlen]
+                   .repeat_interleave(group, dim=0)).float()
+        v_batch = (kvcache[blk, 1].reshape(-1, num_head_kv, head_dim).transpose(0, 1)[:, :seqlen]
+                   .repeat_interleave(group, dim=0)).float()
+        p = q_batch @ k_batch.transpose(-1, -2) / math.sqrt(head_dim)
+        if literal_qscale_row:
+            p = p * q_scale[bi][:, None, None]
+        else:
+            p = p * qs[bi].transpose(0, 1)[:, :, None]  # [Hq, Sq, 1]
+        if k_per_token:
+            ksb = (k_scale[blk].contiguous().view(torch.float32).permute(0, 1, 3, 2)
+                   .reshape(-1, num_head_kv).transpose(0, 1)[:, :seqlen]
+                   .repeat_interleave(group, dim=0)).float()
+            p = p * ksb.unsqueeze(1)
+        else:
+            p = p * k_scale
+        causal = torch.cat(
+            [torch.ones(sq, seqlen - sq, dtype=torch.bool),
+             torch.tril(torch.ones(sq, sq, dtype=torch.bool))], dim=-1).unsqueeze(0)
+        p = p.masked_fill(~causal, float("-inf"))
+        w = torch.exp(p - p.max(dim=-1)[0][:, :, None])
+        gsum = w.sum(dim=-1)[:, :, None]
+        w = (w * 256.0).to(torch.float8_e4m3fn).float()
+        y = torch.matmul(w, v_batch) / gsum
+        if k_per_token:
+            y = y * v_scale[:, None, None].repeat_interleave(group, dim=0) / 256.0
+        else:
+            y = y * (v_scale / 256.0)
+        out[bi] = y.transpose(0, 1).to(torch.bfloat16)
+    return out.reshape(-1, num_head_q, head_dim)

@@ -1,0 +1,117 @@
+"""Parity of hpc.attention_decode_fp8 (HIP via the C-ABI) with the CPU oracles.
+Generators / tolerances follow reference
+tests/test_attention_decode_qpertoken_perhead_kvpertensor_fp8.py:82-298 (atol 0.2) and
+tests/test_attention_decode_qkpertoken_perhead_vperhead_fp8.py:262-470 (atol 0.1)."""
+import math
+
+import pytest
+import torch
+
+from utils import allclose
+
+
+def _case(num_batch, num_seq_q, lens_before, block_size, kv_head_q_head, k_per_token, seed=41):
+    torch.manual_seed(seed)
+    num_head_kv, num_head_q = kv_head_q_head
+    D = 128
+    q = torch.randn((num_batch * num_seq_q, num_head_q, D), dtype=torch.bfloat16) / math.sqrt(D)
+    q_scale = q.float().abs().max(-1)[0] / 10
+    q8 = (q / q_scale[:, :, None]).to(torch.float8_e4m3fn)
+    nblocks = (lens_before + num_seq_q + block_size - 1) // block_size
+    total_blocks = int(nblocks.sum())
+    max_num_blocks = int(total_blocks * 1.2) + 4
+    scale_rows = block_size * 4 // D if k_per_token else 0
+    if k_per_token:
+        kv = torch.randn(max_num_blocks, 2, block_size + scale_rows, num_head_kv, D, dtype=torch.bfloat16)
+    else:
+        kv = torch.randn(max_num_blocks, 2, block_size, num_head_kv, D, dtype=torch.bfloat16) / math.sqrt(D)
+    packed = torch.randperm(max_num_blocks)[:total_blocks].to(torch.int32)
+    block_ids = torch.full((num_batch, int(nblocks.max())), -999999, dtype=torch.int32)
+    cu = 0
+    for i in range(num_batch):
+        nb = int(nblocks[i])
+        block_ids[i, :nb] = packed[cu : cu + nb]
+        cu += nb
+    return q8, q_scale, kv, block_ids, nblocks
+
+
+def _run(num_batch, num_seq_q, lens_before, block_size, kv_head_q_head, k_per_token, new_kv_included,
+         use_dynamic_sched, kvcache_shape, atol):
+    import hpc
+    from oracle import attention as oattn
+
+    num_head_kv, num_head_q = kv_head_q_head
+    q8, q_scale, kv, block_ids, nblocks = _case(
+        num_batch, num_seq_q, lens_before, block_size, kv_head_q_head, k_per_token)
+    if k_per_token:
+        kc, _ = oattn.quant_paged_cache_pertoken(kv[:, 0], block_size)
+        vc, v_scale = oattn.quant_paged_cache_perhead(kv[:, 1], block_size)
+        kv8 = torch.empty_like(kv, dtype=torch.float8_e4m3fn)
+        kv8[:, 0] = kc
+        kv8[:, 1] = vc
+        k_scale = kv8[:, 0, block_size:]
+        v_scale = torch.randn(num_head_kv, dtype=torch.float32)
+        qt = hpc.QuantType.QPERTOKEN_PERHEAD_KPERTOKEN_PERHEAD_VPERHEAD
+    else:
+        kv8 = kv.to(torch.float8_e4m3fn)
+        k_scale = torch.randn(1, dtype=torch.float32)
+        v_scale = torch.randn(1, dtype=torch.float32)
+        qt = hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR
+    gt = oattn.ref_attn_fp8(q8, kv8[:, :, :block_size], block_ids, nblocks, num_seq_q, lens_before,
+                            q_scale, k_scale, v_scale, k_per_token)
+
+    kv_dev = kv8.cuda()
+    if kvcache_shape == "HND":
+        kv_dev = kv_dev.view(torch.uint8).permute(0, 1, 3, 2, 4).contiguous().permute(0, 1, 3, 2, 4).view(
+            torch.float8_e4m3fn)
+    kcache, vcache = kv_dev[:, 0, :block_size], kv_dev[:, 1, :block_size]
+    ks_dev = kv_dev[:, 0, block_size:] if k_per_token else k_scale.cuda()
+    lens_dev = lens_before.cuda()
+    lens_in = lens_dev + num_seq_q if new_kv_included else lens_dev
+    task_map = None
+    if use_dynamic_sched:
+        task_map = hpc.get_attention_decode_task_workspace(
+            num_batch, int(lens_before.max()) + num_seq_q, num_head_kv, min_process_len=1024)
+        hpc.assign_attention_decode_task(lens_in, task_map, num_head_kv, num_seq_q, new_kv_included,
+                                         min_process_len=1024)
+    my = hpc.attention_decode_fp8(
+        q8.cuda(), kcache, vcache, block_ids.cuda(), lens_in, q_scale.cuda(), ks_dev, v_scale.cuda(),
+        mtp=num_seq_q - 1, new_kv_included=new_kv_included, quant_type=qt, splitk=True,
+        task_map=task_map)
+    torch.cuda.synchronize()
+    assert my.dtype == torch.bfloat16
+    assert allclose(gt, my.cpu(), atol=atol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_batch", [1, 16, 50])
+@pytest.mark.parametrize("num_seq_q", [1, 2, 3, 4])
+@pytest.mark.parametrize("kv_head_q_head", [(1, 8), (4, 32)])
+@pytest.mark.parametrize("use_dynamic_sched", [True, False])
+@pytest.mark.parametrize("kvcache_shape", ["NHD", "HND"])
+def test_attn_fp8_kvpertensor(num_batch, num_seq_q, kv_head_q_head, use_dynamic_sched, kvcache_shape):
+    torch.manual_seed(41)
+    max_seq_kv = 1024 if num_batch > 16 else 4096
+    lens = torch.randint(1, max_seq_kv, (num_batch,), dtype=torch.int32)
+    _run(num_batch, num_seq_q, lens, 64, kv_head_q_head, False, True, use_dynamic_sched,
+         kvcache_shape, 0.2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_batch", [1, 16])
+@pytest.mark.parametrize("num_seq_q", [1, 2, 4])
+@pytest.mark.parametrize("kv_head_q_head", [(1, 8), (4, 32), (2, 8)])
+@pytest.mark.parametrize("use_dynamic_sched", [True, False])
+@pytest.mark.parametrize("kvcache_shape", ["NHD", "HND"])
+def test_attn_fp8_kpertoken(num_batch, num_seq_q, kv_head_q_head, use_dynamic_sched, kvcache_shape):
+    torch.manual_seed(41)
+    lens = torch.randint(1, 2048, (num_batch,), dtype=torch.int32)
+    _run(num_batch, num_seq_q, lens, 64, kv_head_q_head, True, True, use_dynamic_sched,
+         kvcache_shape, 0.1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k_per_token,block_size", [(False, 16), (False, 32), (True, 32)])
+def test_attn_fp8_small_pages_and_split(k_per_token, block_size):
+    lens = torch.tensor([9000, 3, 130, 65, 2049], dtype=torch.int32)
+    _run(5, 2, lens, block_size, (2, 16), k_per_token, False, True, "NHD", 0.2 if not k_per_token else 0.1)
