@@ -50,7 +50,6 @@ def _run(num_batch, num_seq_q, lens_before, block_size, kv_head_q_head, k_per_to
         kv8[:, 0] = kc
         kv8[:, 1] = vc
         k_scale = kv8[:, 0, block_size:]
-        v_scale = torch.randn(num_head_kv, dtype=torch.float32)
         qt = hpc.QuantType.QPERTOKEN_PERHEAD_KPERTOKEN_PERHEAD_VPERHEAD
     else:
         kv8 = kv.to(torch.float8_e4m3fn)
