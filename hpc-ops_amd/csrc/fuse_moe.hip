@@ -1,0 +1,409 @@
+// Fused MoE (FP8, 128-block scales) pipeline pieces for gfx950: routing prep, SiLU*up + block
+// quant, top-k reduce, and the 5-stage orchestrator.
+//
+// Replaces reference src/fuse_moe/count_and_gather_for_blockwise.cu (count / scan / gather),
+// src/activation/activation.cu:282-355 (act_mul_and_blockwise_quant_fusemoe_kernel),
+// src/fuse_moe/reduce.cu:17-81 and src/fuse_moe/fuse_moe.cu:62-116 (fuse_moe_blockwise_async).
+//
+// MI355X design notes:
+//  * Routing is DETERMINISTIC: slot = arrival order in flattened (token, k) order, exactly the
+//    reference test oracle's order (tests/test_fuse_moe_blockwise.py:55-66); the reference kernel
+//    slots with atomics (count_and_gather_for_blockwise.cu:208-214).  One workgroup per local expert
+//    scans topk_ids with wave ballots + prefix popcounts, so topk_pos is bit-exact and repeatable.
+//  * The fused path is gather-free: the first GEMM reads token rows through row_index (pos ->
+//    token) and x_scale rows directly - no copy of x, no transposed scale scatter.  The standalone
+//    count_and_gather op still produces the reference's gathered / transposed layouts.
+//  * Everything is launched back to back on one stream (hipGraph-capturable, no host sync).
+#include "hpc_common.h"
+#include "../../include/hpc_amd.h"
+
+extern "C" int hpc_group_gemm_blockwise_fp8_async(
+    void* y_ptr, const void* x_ptr, const void* w_ptr, const void* seqlens_ptr,
+    const void* cu_seqlens_ptr, const void* xscale_ptr, const void* wscale_ptr,
+    const void* row_index_ptr, const void* col_base_ptr, int num_group, int m, int n, int k,
+    int num_block_k_pad4, int tile_m, int64_t xscale_row_stride, int64_t xscale_kb_stride,
+    hipStream_t stream);
+
+namespace hpc {
+namespace moe {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ int block_sum(int v, int* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// seqlens[e] = #{i : ids[i] == first_expert + e}
+__global__ __launch_bounds__(kThreads) void count_kernel(const int* __restrict__ ids, int n,
+                                                         int first_expert, int* __restrict__ seqlens) {
+  __shared__ int red[4];
+  const int target = first_expert + blockIdx.x;
+  int c = 0;
+  for (int i = threadIdx.x; i < n; i += kThreads) c += ids[i] == target;
+  c = block_sum(c, red);
+  if (threadIdx.x == 0) seqlens[blockIdx.x] = c;
+}
+
+// Stable slotting of expert blockIdx.x: topk_pos[i] = cu_seqlens[e] + (# earlier i' with the same
+// expert); row_index[pos] = token.  Block 0 also writes cu_seqlens / tiles / cu_tiles; entries whose
+// expert is not local get topk_pos = -1.
+__global__ __launch_bounds__(kThreads) void slot_kernel(
+    const int* __restrict__ ids, int n, int num_topk, int first_expert, int num_expert, int tile_m,
+    const int* __restrict__ seqlens, int* __restrict__ cu_seqlens, int* __restrict__ tiles,
+    int* __restrict__ cu_tiles, int* __restrict__ topk_pos, int* __restrict__ row_index) {
+  __shared__ int red[4];
+  __shared__ int wave_cnt[4];
+  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int part = 0;
+  for (int j = tid; j < e; j += kThreads) part += seqlens[j];
+  const int cu = block_sum(part, red);
+
+  if (e == 0) {
+    if (tid == 0) {
+      int c = 0, ct = 0;
+      for (int j = 0; j < num_expert; ++j) {
+        cu_seqlens[j] = c;
+        const int t = (seqlens[j] + tile_m - 1) / tile_m;
+        tiles[j] = t;
+        cu_tiles[j] = ct;
+        c += seqlens[j];
+        ct += t;
+      }
+      cu_seqlens[num_expert] = c;
+      cu_tiles[num_expert] = ct;
+    }
+  }
+  const int target = first_expert + e;
+  int running = 0;
+  for (int base = 0; base < n; base += kThreads) {
+    const int i = base + tid;
+    const int id = i < n ? ids[i] : -1;
+    const bool match = id == target;
+    const unsigned long long bal = __ballot(match);
+    const int pre = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __builtin_popcountll(bal);
+    __syncthreads();
+    int off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int c = wave_cnt[w];
+      off += w < wave ? c : 0;
+      tot += c;
+    }
+    if (match) {
+      const int pos = cu + running + off + pre;
+      topk_pos[i] = pos;
+      row_index[pos] = i / num_topk;
+    }
+    // non-local experts: exactly one block owns entry i
+    if (i < n && (id < first_expert || id >= first_expert + num_expert) && (i % num_expert) == e)
+      topk_pos[i] = -1;
+    running += tot;
+    __syncthreads();
+  }
+}
+
+// tiles[g] = ceil(seqlens[g] / tile_m), cu_tiles = exclusive scan (standalone group-GEMM entry;
+// reference src/group_gemm/group_gemm_blockwise_fp8.cu:19-86 computes the same inside its kernel)
+__global__ void tiles_kernel(const int* __restrict__ seqlens, int num_group, int tile_m,
+                             int* __restrict__ tiles, int* __restrict__ cu_tiles) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int ct = 0;
+  for (int j = 0; j < num_group; ++j) {
+    const int t = (seqlens[j] + tile_m - 1) / tile_m;
+    tiles[j] = t;
+    cu_tiles[j] = ct;
+    ct += t;
+  }
+  cu_tiles[num_group] = ct;
+}
+
+// Copies routed rows into the expert-contiguous buffer and scatters x_scale into the reference's
+// transposed, tile-padded layout xs_t[kb][cu_tiles[e]*tile_m + slot]
+// (reference blockwise_gather_kernel, count_and_gather_for_blockwise.cu:181-376).
+__global__ __launch_bounds__(kThreads) void gather_kernel(
+    const uint8_t* __restrict__ x, const float* __restrict__ x_scale, const int* __restrict__ ids,
+    const int* __restrict__ topk_pos, const int* __restrict__ cu_seqlens,
+    const int* __restrict__ cu_tiles, int n, int num_topk, int first_expert, int hidden, int tile_m,
+    int m_pad, uint8_t* __restrict__ xg, float* __restrict__ xs_t) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int pos = topk_pos[i];
+  if (pos < 0) return;
+  const int lane = threadIdx.x & 63;
+  const int tok = i / num_topk, e = ids[i] - first_expert;
+  const uint8_t* src = x + static_cast<long>(tok) * hidden;
+  uint8_t* dst = xg + static_cast<long>(pos) * hidden;
+  for (int c = lane * 16; c < hidden; c += 64 * 16) st16(dst + c, ld16(src + c));
+  const int col = cu_tiles[e] * tile_m + (pos - cu_seqlens[e]);
+  const int nkb = hidden >> 7;
+  for (int kb = lane; kb < nkb; kb += 64)
+    xs_t[static_cast<long>(kb) * m_pad + col] = x_scale[static_cast<long>(tok) * nkb + kb];
+}
+
+// a = silu(gate) * up in fp32 on the bf16 GEMM output, per 128 columns: scale = amax/448,
+// q = e4m3(a / (scale + 1e-8)).  16 lanes x 8 columns = one quant block.
+// out_scale[row * os_row_stride + jb * os_blk_stride].
+__global__ __launch_bounds__(kThreads) void act_mul_blockwise_quant_kernel(
+    const uint16_t* __restrict__ gate_up, const int* __restrict__ num_rows_ptr, int max_rows,
+    int inter, uint8_t* __restrict__ out, float* __restrict__ out_scale, long os_row_stride,
+    long os_blk_stride, const int* __restrict__ row_to_col) {
+  const int row = blockIdx.y;
+  const int rows = num_rows_ptr ? min(*num_rows_ptr, max_rows) : max_rows;
+  if (row >= rows) return;
+  const int c8 = blockIdx.x * kThreads + threadIdx.x;  // chunk of 8 columns
+  const bool ok = c8 * 8 < inter;
+  const uint16_t* gp = gate_up + static_cast<long>(row) * 2 * inter;
+  float a[8];
+  float amax = 0.f;
+  if (ok) {
+    const u32x4 gv = ld16(gp + c8 * 8), uv = ld16(gp + inter + c8 * 8);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g0 = bf16lo_to_f32(gv[j]), g1 = bf16hi_to_f32(gv[j]);
+      const float u0 = bf16lo_to_f32(uv[j]), u1 = bf16hi_to_f32(uv[j]);
+      a[2 * j] = g0 / (1.0f + __expf(-g0)) * u0;
+      a[2 * j + 1] = g1 / (1.0f + __expf(-g1)) * u1;
+      amax = fmaxf(amax, fmaxf(fabsf(a[2 * j]), fabsf(a[2 * j + 1])));
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  if (!ok) return;
+  const float scale = amax / 448.0f;
+  const float inv = 1.0f / (scale + 1e-8f);
+  u32x2 q;
+  q[0] = cvt_4xe4m3(a[0] * inv, a[1] * inv, a[2] * inv, a[3] * inv);
+  q[1] = cvt_4xe4m3(a[4] * inv, a[5] * inv, a[6] * inv, a[7] * inv);
+  *reinterpret_cast<u32x2*>(out + static_cast<long>(row) * inter + c8 * 8) = q;
+  if ((threadIdx.x & 15) == 0) {
+    const long r = row_to_col ? row_to_col[row] : row;
+    out_scale[r * os_row_stride + (c8 >> 4) * os_blk_stride] = scale;
+  }
+}
+
+// y[t] = bf16( sum_j topk_scale[t,j] * float(x[topk_pos[t,j]]) + float(shared[t]) ), pos < 0 skipped
+// (reference reduce_kernel, src/fuse_moe/reduce.cu:17-81).
+__global__ __launch_bounds__(kThreads) void reduce_kernel(
+    const uint16_t* __restrict__ x, const int* __restrict__ topk_pos,
+    const float* __restrict__ topk_scale, const uint16_t* __restrict__ shared, int num_topk,
+    int hidden, uint16_t* __restrict__ y) {
+  __shared__ int s_pos[128];
+  __shared__ float s_scale[128];
+  const int t = blockIdx.y;
+  if (threadIdx.x < num_topk) {
+    s_pos[threadIdx.x] = topk_pos[static_cast<long>(t) * num_topk + threadIdx.x];
+    s_scale[threadIdx.x] = topk_scale[static_cast<long>(t) * num_topk + threadIdx.x];
+  }
+  __syncthreads();
+  const int c = (blockIdx.x * kThreads + threadIdx.x) * 8;
+  if (c >= hidden) return;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int j = 0; j < num_topk; ++j) {
+    const int pos = s_pos[j];
+    if (pos < 0) continue;
+    const float sc = s_scale[j];
+    const u32x4 v = ld16(x + static_cast<long>(pos) * hidden + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[2 * i] = fmaf(bf16lo_to_f32(v[i]), sc, acc[2 * i]);
+      acc[2 * i + 1] = fmaf(bf16hi_to_f32(v[i]), sc, acc[2 * i + 1]);
+    }
+  }
+  if (shared) {
+    const u32x4 v = ld16(shared + static_cast<long>(t) * hidden + c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc[2 * i] += bf16lo_to_f32(v[i]);
+      acc[2 * i + 1] += bf16hi_to_f32(v[i]);
+    }
+  }
+  u32x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(acc[2 * i], acc[2 * i + 1]);
+  st16(y + static_cast<long>(t) * hidden + c, o);
+}
+
+}  // namespace moe
+}  // namespace hpc
+
+using namespace hpc::moe;
+
+// ---- routing prep --------------------------------------------------------------------------------
+extern "C" int hpc_moe_count_and_slot_async(const void* topk_ids, int num_tokens, int num_topk,
+                                            int num_expert, int rank_ep, int tile_m,
+                                            void* seqlens, void* cu_seqlens, void* tiles,
+                                            void* cu_tiles, void* topk_pos, void* row_index,
+                                            hipStream_t stream) {
+  if (!topk_ids || !seqlens || !cu_seqlens || !tiles || !cu_tiles || !topk_pos || !row_index)
+    return HPC_ERR_INVALID;
+  if (num_expert <= 0 || num_topk <= 0 || tile_m <= 0 || num_tokens < 0) return HPC_ERR_INVALID;
+  const int n = num_tokens * num_topk;
+  const int first = rank_ep * num_expert;
+  count_kernel<<<num_expert, kThreads, 0, stream>>>(static_cast<const int*>(topk_ids), n, first,
+                                                    static_cast<int*>(seqlens));
+  HPC_CHECK_LAUNCH();
+  slot_kernel<<<num_expert, kThreads, 0, stream>>>(
+      static_cast<const int*>(topk_ids), n, num_topk, first, num_expert, tile_m,
+      static_cast<const int*>(seqlens), static_cast<int*>(cu_seqlens), static_cast<int*>(tiles),
+      static_cast<int*>(cu_tiles), static_cast<int*>(topk_pos), static_cast<int*>(row_index));
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}
+
+extern "C" int hpc_moe_gather_blockwise_async(const void* x, const void* x_scale,
+                                              const void* topk_ids, const void* topk_pos,
+                                              const void* cu_seqlens, const void* cu_tiles,
+                                              int num_tokens, int num_topk, int num_expert,
+                                              int rank_ep, int hidden, int tile_m, int m_pad,
+                                              void* x_gathered, void* xscale_t, hipStream_t stream) {
+  if (!x || !x_scale || !topk_ids || !topk_pos || !cu_seqlens || !cu_tiles || !x_gathered || !xscale_t)
+    return HPC_ERR_INVALID;
+  if (hidden & 127) return HPC_ERR_UNSUPPORTED;
+  const int n = num_tokens * num_topk;
+  if (n == 0) return HPC_OK;
+  gather_kernel<<<(n + 3) / 4, kThreads, 0, stream>>>(
+      static_cast<const uint8_t*>(x), static_cast<const float*>(x_scale),
+      static_cast<const int*>(topk_ids), static_cast<const int*>(topk_pos),
+      static_cast<const int*>(cu_seqlens), static_cast<const int*>(cu_tiles), n, num_topk,
+      rank_ep * num_expert, hidden, tile_m, m_pad, static_cast<uint8_t*>(x_gathered),
+      static_cast<float*>(xscale_t));
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}
+
+extern "C" int hpc_moe_tiles_async(const void* seqlens, int num_group, int tile_m, void* tiles,
+                                   void* cu_tiles, hipStream_t stream) {
+  if (!seqlens || !tiles || !cu_tiles || num_group <= 0 || tile_m <= 0) return HPC_ERR_INVALID;
+  tiles_kernel<<<1, 64, 0, stream>>>(static_cast<const int*>(seqlens), num_group, tile_m,
+                                     static_cast<int*>(tiles), static_cast<int*>(cu_tiles));
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}
+
+// ---- activation + block quant ---------------------------------------------------------------------
+extern "C" int hpc_act_mul_and_blockwise_quant_async(void* out_ptr, void* out_scale_ptr,
+                                                     const void* gate_up_ptr,
+                                                     const void* num_rows_ptr, int max_rows,
+                                                     int intermediate_size, int64_t scale_row_stride,
+                                                     int64_t scale_block_stride,
+                                                     const void* row_to_col_ptr, hipStream_t stream) {
+  if (!out_ptr || !out_scale_ptr || !gate_up_ptr) return HPC_ERR_INVALID;
+  if (intermediate_size <= 0 || (intermediate_size & 127)) return HPC_ERR_UNSUPPORTED;
+  if (max_rows <= 0) return HPC_OK;
+  dim3 grid((intermediate_size / 8 + kThreads - 1) / kThreads, max_rows);
+  act_mul_blockwise_quant_kernel<<<grid, kThreads, 0, stream>>>(
+      static_cast<const uint16_t*>(gate_up_ptr), static_cast<const int*>(num_rows_ptr), max_rows,
+      intermediate_size, static_cast<uint8_t*>(out_ptr), static_cast<float*>(out_scale_ptr),
+      scale_row_stride, scale_block_stride, static_cast<const int*>(row_to_col_ptr));
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}
+
+// ---- top-k reduce ------------------------------------------------------------------------------------
+extern "C" int hpc_moe_reduce_async(void* y_ptr, const void* x_ptr, const void* topk_pos_ptr,
+                                    const void* topk_scale_ptr, const void* shared_output_ptr,
+                                    int num_tokens, int num_topk, int hidden_size,
+                                    hipStream_t stream) {
+  if (!y_ptr || !x_ptr || !topk_pos_ptr || !topk_scale_ptr) return HPC_ERR_INVALID;
+  if (num_topk <= 0 || num_topk > 128 || (hidden_size & 7)) return HPC_ERR_UNSUPPORTED;
+  if (num_tokens <= 0) return HPC_OK;
+  dim3 grid((hidden_size / 8 + kThreads - 1) / kThreads, num_tokens);
+  reduce_kernel<<<grid, kThreads, 0, stream>>>(
+      static_cast<const uint16_t*>(x_ptr), static_cast<const int*>(topk_pos_ptr),
+      static_cast<const float*>(topk_scale_ptr), static_cast<const uint16_t*>(shared_output_ptr),
+      num_topk, hidden_size, static_cast<uint16_t*>(y_ptr));
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}
+
+// ---- fused pipeline -------------------------------------------------------------------------------------
+namespace {
+struct MoeWs {
+  int64_t seqlens, cu_seqlens, tiles, cu_tiles, topk_pos, row_index, gate_up_out, down_in,
+      down_in_scale, down_out, total;
+};
+inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+MoeWs moe_ws_layout(int num_tokens, int num_topk, int hidden, int inter2, int num_expert) {
+  MoeWs w;
+  const int64_t m = static_cast<int64_t>(num_tokens) * num_topk;
+  const int64_t inter = inter2 / 2;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    const int64_t o = off;
+    off += align256(bytes);
+    return o;
+  };
+  w.seqlens = take(4 * num_expert);
+  w.cu_seqlens = take(4 * (num_expert + 1));
+  w.tiles = take(4 * num_expert);
+  w.cu_tiles = take(4 * (num_expert + 1));
+  w.topk_pos = take(4 * m);
+  w.row_index = take(4 * m);
+  w.gate_up_out = take(2 * m * inter2);
+  w.down_in = take(m * inter);
+  w.down_in_scale = take(4 * m * (inter / 128));
+  w.down_out = take(2 * m * hidden);
+  w.total = off;
+  return w;
+}
+}  // namespace
+
+extern "C" int64_t hpc_fuse_moe_blockwise_workspace_bytes(int num_tokens, int num_topk,
+                                                          int hidden_size, int intermediate_size2,
+                                                          int num_expert) {
+  if (num_tokens < 0 || num_topk <= 0 || hidden_size <= 0 || intermediate_size2 <= 0 || num_expert <= 0)
+    return HPC_ERR_INVALID;
+  return moe_ws_layout(num_tokens, num_topk, hidden_size, intermediate_size2, num_expert).total;
+}
+
+extern "C" int hpc_fuse_moe_blockwise_async(
+    void* y_ptr, void* workspace, const void* x_ptr, const void* x_scale_ptr,
+    const void* gate_up_weight_ptr, const void* gate_up_weight_scale_ptr,
+    const void* down_weight_ptr, const void* down_weight_scale_ptr, const void* topk_ids_ptr,
+    const void* topk_scale_ptr, const void* shared_output_ptr, int num_tokens, int hidden_size,
+    int intermediate_size2, int num_topk, int num_expert_total, int num_expert, int gate_up_ws_pad4,
+    int down_ws_pad4, int rank_ep, hipStream_t stream) {
+  if (!y_ptr || !workspace || !x_ptr || !x_scale_ptr || !gate_up_weight_ptr ||
+      !gate_up_weight_scale_ptr || !down_weight_ptr || !down_weight_scale_ptr || !topk_ids_ptr ||
+      !topk_scale_ptr)
+    return HPC_ERR_INVALID;
+  if ((hidden_size & 127) || (intermediate_size2 & 255) || num_topk > 128) return HPC_ERR_UNSUPPORTED;
+  if (num_tokens <= 0) return HPC_OK;
+  (void)num_expert_total;
+  const int inter = intermediate_size2 / 2;
+  const int m = num_tokens * num_topk;
+  const MoeWs w = moe_ws_layout(num_tokens, num_topk, hidden_size, intermediate_size2, num_expert);
+  char* ws = static_cast<char*>(workspace);
+  int rc = hpc_moe_count_and_slot_async(topk_ids_ptr, num_tokens, num_topk, num_expert, rank_ep, 16,
+                                        ws + w.seqlens, ws + w.cu_seqlens, ws + w.tiles,
+                                        ws + w.cu_tiles, ws + w.topk_pos, ws + w.row_index, stream);
+  if (rc) return rc;
+  // gate_up: rows come straight from x through row_index, scales from x_scale[token][kb]
+  rc = hpc_group_gemm_blockwise_fp8_async(ws + w.gate_up_out, x_ptr, gate_up_weight_ptr,
+                                          ws + w.seqlens, ws + w.cu_seqlens, x_scale_ptr,
+                                          gate_up_weight_scale_ptr, ws + w.row_index, nullptr,
+                                          num_expert, m, intermediate_size2, hidden_size,
+                                          gate_up_ws_pad4, 16, hidden_size / 128, 1, stream);
+  if (rc) return rc;
+  rc = hpc_act_mul_and_blockwise_quant_async(
+      ws + w.down_in, ws + w.down_in_scale, ws + w.gate_up_out,
+      reinterpret_cast<const int*>(ws + w.cu_seqlens) + num_expert, m, inter, inter / 128, 1, nullptr,
+      stream);
+  if (rc) return rc;
+  rc = hpc_group_gemm_blockwise_fp8_async(ws + w.down_out, ws + w.down_in, down_weight_ptr,
+                                          ws + w.seqlens, ws + w.cu_seqlens, ws + w.down_in_scale,
+                                          down_weight_scale_ptr, nullptr, nullptr, num_expert, m,
+                                          hidden_size, inter, down_ws_pad4, 16, inter / 128, 1, stream);
+  if (rc) return rc;
+  return hpc_moe_reduce_async(y_ptr, ws + w.down_out, ws + w.topk_pos, topk_scale_ptr,
+                              shared_output_ptr, num_tokens, num_topk, hidden_size, stream);
+}

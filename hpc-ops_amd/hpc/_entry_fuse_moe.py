@@ -1,0 +1,162 @@
+"""torch.ops.hpc.{fuse_moe_blockwise_fp8, fuse_moe_blockwise, reduce, group_gemm_blockwise_fp8}.
+
+Mirror of reference src/fuse_moe/entry.cc:445-684 (fuse_moe_blockwise_entry, reduce_entry) and
+src/group_gemm/entry.cc:91-168 (group_gemm_blockwise_fp8_entry): same schemas, checks and output
+allocation; compute is in libhpc_amd.so (csrc/fuse_moe.hip, csrc/group_gemm_blockwise.hip).
+"""
+import torch
+
+from . import _C
+
+_T = _C.torch_lib
+_F8 = torch.float8_e4m3fn
+
+_T.define(
+    "fuse_moe_blockwise_fp8(Tensor x, Tensor x_scale, Tensor gate_up_weight, Tensor "
+    "gate_up_weight_scale, Tensor down_weight, Tensor down_weight_scale, Tensor topk_ids, "
+    "Tensor topk_scale, Tensor ? shared_output, int rank_ep, int num_expert_total, Tensor ? "
+    "output) -> (Tensor)"
+)
+_T.define(
+    "fuse_moe_blockwise(Tensor x, Tensor x_scale, Tensor gate_up_weight, Tensor "
+    "gate_up_weight_scale, Tensor down_weight, Tensor down_weight_scale, Tensor topk_ids, Tensor "
+    "topk_scale, Tensor ? shared_output, int rank_ep, int num_expert_total, Tensor ? output) -> (Tensor)"
+)
+_T.define("reduce(Tensor x, Tensor topk_pos, Tensor topk_scale, Tensor ? shared_output) -> (Tensor)")
+_T.define(
+    "group_gemm_blockwise_fp8(Tensor x, Tensor weight, Tensor seqlens, Tensor cu_seqlens, Tensor "
+    "x_scale, Tensor w_scale, int num_seq_per_group_avg, Tensor? output, Tensor? tma_desc, "
+    "Tensor? task_map_workspace) -> (Tensor)"
+)
+
+
+def aligned_size(avg: int) -> int:
+    """tileM ladder of the reference (src/fuse_moe/entry.cc:525-543): defines the tile-padded column
+    layout of transposed x_scale tensors."""
+    for lim, val in ((8, 8), (16, 16), (32, 32), (48, 48), (64, 64), (96, 48), (128, 32), (144, 48)):
+        if avg <= lim:
+            return val
+    return 64
+
+
+def _cuda_contig(t, name):
+    _C.require(t.is_cuda, f"{name} tensor must be cuda")
+    _C.require(t.is_contiguous(), f"{name} tensor must be contiguous")
+
+
+def _fuse_moe_blockwise_entry(x, x_scale, gate_up_weight, gate_up_weight_scale, down_weight,
+                              down_weight_scale, topk_ids, topk_scale, shared_output, rank_ep,
+                              num_expert_total, output):
+    _C.require(x.dtype == _F8 and gate_up_weight.dtype == _F8 and down_weight.dtype == _F8,
+               "x, gate_up_weight and down_weight dtype must be fp8_e4m3")
+    _C.require(topk_ids.dtype == torch.int32, "topk_ids dtype must be int32")
+    _C.require(gate_up_weight_scale.dtype == torch.float32 and down_weight_scale.dtype == torch.float32
+               and topk_scale.dtype == torch.float32 and x_scale.dtype == torch.float32,
+               "gate_up_scale, down_scale, x_scale and topk_scale dtype must be float32")
+    for t, n in ((x, "x"), (x_scale, "x_scale"), (gate_up_weight, "gate_up_weight"),
+                 (gate_up_weight_scale, "gate_up_weight_scale"), (down_weight, "down_weight"),
+                 (down_weight_scale, "down_weight_scale"), (topk_ids, "topk_ids"),
+                 (topk_scale, "topk_scale")):
+        _cuda_contig(t, n)
+    _C.require(x.size(0) == topk_ids.size(0), "x and topk_ids must share the same num_tokens")
+    _C.require(topk_ids.shape == topk_scale.shape, "topk_ids and topk_scale must share the same shape")
+    _C.require(x.size(1) == gate_up_weight.size(2), "x and weight must share the same k")
+    _C.require(gate_up_weight.size(0) == down_weight.size(0),
+               "gate_up_weight and down_weight must share the same num_expert")
+    _C.require(x_scale.size(0) == x.size(0) and x_scale.size(1) == x.size(1) // 128,
+               "x_scale must be per 128 blockwise quant")
+    _C.require(gate_up_weight_scale.size(1) == gate_up_weight.size(1) // 128
+               and gate_up_weight_scale.size(2) == (gate_up_weight.size(2) // 128 + 3) // 4 * 4,
+               "gate_up_weight must be per 128 blockwise quant and must be aligned to 4")
+    _C.require(down_weight_scale.size(1) == down_weight.size(1) // 128
+               and down_weight_scale.size(2) == (down_weight.size(2) // 128 + 3) // 4 * 4,
+               "down_weight must be per 128 blockwise quant and must be aligned to 4")
+    _C.require(down_weight.size(1) == x.size(1) and down_weight.size(2) * 2 == gate_up_weight.size(1),
+               "down_weight must be [num_expert, hidden, intermediate]")
+    num_tokens, hidden = x.shape
+    num_experts, inter2 = gate_up_weight.size(0), gate_up_weight.size(1)
+    num_topk = topk_ids.size(1)
+    _C.require(num_topk <= 128, "num_topk must less than or equal to 128")
+    if shared_output is not None:
+        _cuda_contig(shared_output, "shared_output")
+        _C.require(shared_output.dtype == torch.bfloat16, "shared_output tensor dtype must be bfloat16")
+        _C.require(tuple(shared_output.shape) == (num_tokens, hidden),
+                   "shared_output tensor shape must be same as x tensor")
+    if output is not None:
+        _C.require(tuple(output.shape) == (num_tokens, hidden), "output shape must be [num_tokens, hidden_size]")
+        _C.require(output.dtype == torch.bfloat16 and output.is_cuda, "output must be a cuda bfloat16 tensor")
+        y = output
+    else:
+        y = torch.empty((num_tokens, hidden), dtype=torch.bfloat16, device=x.device)
+    nbytes = _C.lib.hpc_fuse_moe_blockwise_workspace_bytes(num_tokens, num_topk, hidden, inter2, num_experts)
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device)
+    rc = _C.lib.hpc_fuse_moe_blockwise_async(
+        _C.ptr(y), _C.ptr(ws), _C.ptr(x), _C.ptr(x_scale), _C.ptr(gate_up_weight),
+        _C.ptr(gate_up_weight_scale), _C.ptr(down_weight), _C.ptr(down_weight_scale),
+        _C.ptr(topk_ids), _C.ptr(topk_scale), _C.ptr(shared_output), num_tokens, hidden, inter2,
+        num_topk, int(num_expert_total), num_experts, gate_up_weight_scale.size(2),
+        down_weight_scale.size(2), int(rank_ep), _C.stream_of(x),
+    )
+    _C.check(rc, "fuse_moe_blockwise_async")
+    return y
+
+
+_T.impl("fuse_moe_blockwise_fp8", _fuse_moe_blockwise_entry, "CUDA")
+_T.impl("fuse_moe_blockwise", _fuse_moe_blockwise_entry, "CUDA")
+
+
+def _reduce_entry(x, topk_pos, topk_scale, shared_output):
+    _cuda_contig(x, "x")
+    _cuda_contig(topk_pos, "topk_pos")
+    _cuda_contig(topk_scale, "topk_scale")
+    _C.require(x.dtype == torch.bfloat16, "x dtype must be bfloat16")
+    _C.require(topk_pos.dtype == torch.int32 and topk_scale.dtype == torch.float32,
+               "topk_pos must be int32 and topk_scale float32")
+    _C.require(topk_pos.shape == topk_scale.shape, "topk_pos and topk_scale must share the same shape")
+    if shared_output is not None:
+        _cuda_contig(shared_output, "shared_output")
+        _C.require(shared_output.dtype == torch.bfloat16, "shared_output dtype must be bfloat16")
+    num_tokens, num_topk = topk_pos.shape
+    y = torch.empty((num_tokens, x.size(1)), dtype=torch.bfloat16, device=x.device)
+    rc = _C.lib.hpc_moe_reduce_async(_C.ptr(y), _C.ptr(x), _C.ptr(topk_pos), _C.ptr(topk_scale),
+                                     _C.ptr(shared_output), num_tokens, num_topk, x.size(1),
+                                     _C.stream_of(x))
+    _C.check(rc, "reduce_async")
+    return y
+
+
+_T.impl("reduce", _reduce_entry, "CUDA")
+
+
+def _group_gemm_blockwise_fp8_entry(x, weight, seqlens, cu_seqlens, x_scale, w_scale,
+                                    num_seq_per_group_avg, output, tma_desc, task_map_workspace):
+    for t, n in ((x, "x"), (weight, "weight"), (seqlens, "seqlens"), (cu_seqlens, "cu_seqlens")):
+        _C.require(t.is_cuda, f"{n} tensor must be cuda")
+    _C.require(x.is_contiguous() and weight.is_contiguous(), "x / weight tensor must be contiguous")
+    _C.require(x.dtype == _F8 and weight.dtype == _F8, "x and weight dtype must be fp8_e4m3")
+    _C.require(seqlens.dtype == torch.int32 and cu_seqlens.dtype == torch.int32,
+               "seqlens and cu_seqlens dtype must be int32")
+    _C.require(x_scale.dtype == torch.float32 and w_scale.dtype == torch.float32,
+               "x_scale and w_scale dtype must be float32")
+    _C.require(x_scale.is_contiguous() and w_scale.is_contiguous(), "scales must be contiguous")
+    _C.require(seqlens.size(0) == weight.size(0), "seqlens and weight must share the same num_group")
+    _C.require(x.size(1) == weight.size(2), "x and weight must share the same k")
+    _C.require(w_scale.size(2) % 4 == 0, "w_scale must be multiple of 4")
+    m, k = x.shape
+    n, num_group, m_pad = weight.size(1), seqlens.size(0), x_scale.size(1)
+    y = output if output is not None else torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
+    tile_m = aligned_size(int(num_seq_per_group_avg))
+    tiles = torch.empty(num_group, dtype=torch.int32, device=x.device)
+    cu_tiles = torch.empty(num_group + 1, dtype=torch.int32, device=x.device)
+    s = _C.stream_of(x)
+    _C.check(_C.lib.hpc_moe_tiles_async(_C.ptr(seqlens), num_group, tile_m, _C.ptr(tiles),
+                                        _C.ptr(cu_tiles), s), "group_gemm tiles")
+    rc = _C.lib.hpc_group_gemm_blockwise_fp8_async(
+        _C.ptr(y), _C.ptr(x), _C.ptr(weight), _C.ptr(seqlens), _C.ptr(cu_seqlens), _C.ptr(x_scale),
+        _C.ptr(w_scale), None, _C.ptr(cu_tiles), num_group, m, n, k, w_scale.size(2), tile_m, 1,
+        m_pad, s)
+    _C.check(rc, "group_gemm_blockwise_fp8_async")
+    return y
+
+
+_T.impl("group_gemm_blockwise_fp8", _group_gemm_blockwise_fp8_entry, "CUDA")

@@ -1,0 +1,80 @@
+"""hpc.fuse_moe — fused-MoE surface of the reference (hpc/fuse_moe.py:88-262), blockwise FP8 path."""
+import torch
+from torch import Tensor
+
+from . import _entry_fuse_moe  # noqa: F401  (registers the ops)
+
+
+def reduce(x: Tensor, topk_pos: Tensor, topk_scale: Tensor, shared_output: Tensor = None) -> Tensor:
+    """y[t] = sum_j topk_scale[t, j] * x[topk_pos[t, j]] (+ shared_output[t]); topk_pos < 0 skipped.
+
+    x bf16 [total_num_seq, hidden]; topk_pos int32 / topk_scale float32 [num_seq, num_topk];
+    returns bf16 [num_seq, hidden] (reference hpc/fuse_moe.py:88-130).
+    """
+    return torch.ops.hpc.reduce(x, topk_pos, topk_scale, shared_output)
+
+
+def fuse_moe_blockwise_fp8(
+    x: Tensor,
+    x_scale: Tensor,
+    gate_up_weight: Tensor,
+    gate_up_weight_scale: Tensor,
+    down_weight: Tensor,
+    down_weight_scale: Tensor,
+    topk_ids: Tensor,
+    topk_scale: Tensor,
+    rank_ep: int,
+    num_expert_total: int,
+    shared_output: Tensor = None,
+) -> Tensor:
+    """Run blockwise FP8 FusedMoE (reference hpc/fuse_moe.py:202-229).
+
+    x e4m3 [T, H] with x_scale f32 [T, H/128]; gate_up_weight e4m3 [E, 2I, H] with scales
+    [E, 2I/128, pad4(H/128)]; down_weight e4m3 [E, H, I] with scales [E, H/128, pad4(I/128)];
+    topk_ids int32 [T, k] (global expert ids; local experts are [rank_ep*E, (rank_ep+1)*E)),
+    topk_scale f32 [T, k]; optional shared_output bf16 [T, H].  Returns bf16 [T, H].
+    """
+    return torch.ops.hpc.fuse_moe_blockwise_fp8(
+        x, x_scale, gate_up_weight, gate_up_weight_scale, down_weight, down_weight_scale, topk_ids,
+        topk_scale, shared_output, rank_ep, num_expert_total, None,
+    )
+
+
+def fuse_moe_blockwise(
+    x: Tensor,
+    x_scale: Tensor,
+    gate_up_weight: Tensor,
+    gate_up_weight_scale: Tensor,
+    down_weight: Tensor,
+    down_weight_scale: Tensor,
+    topk_ids: Tensor,
+    topk_scale: Tensor,
+    rank_ep: int,
+    num_expert_total: int,
+    shared_output: Tensor = None,
+    output: Tensor = None,
+) -> Tensor:
+    """Run blockwise FP8 FusedMoE into an optional preallocated output (reference :232-262)."""
+    return torch.ops.hpc.fuse_moe_blockwise(
+        x, x_scale, gate_up_weight, gate_up_weight_scale, down_weight, down_weight_scale, topk_ids,
+        topk_scale, shared_output, rank_ep, num_expert_total, output,
+    )
+
+
+@torch.library.register_fake("hpc::reduce")
+def reduce_fake(x, topk_pos, topk_scale, shared_output):
+    return torch.empty((topk_pos.size(0), x.size(1)), dtype=torch.bfloat16, device=x.device)
+
+
+@torch.library.register_fake("hpc::fuse_moe_blockwise_fp8")
+def fuse_moe_blockwise_fp8_fake(x, x_scale, gate_up_weight, gate_up_weight_scale, down_weight,
+                                down_weight_scale, topk_ids, topk_scale, shared_output, rank_ep,
+                                num_expert_total, output):
+    return torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+
+
+@torch.library.register_fake("hpc::fuse_moe_blockwise")
+def fuse_moe_blockwise_fake(x, x_scale, gate_up_weight, gate_up_weight_scale, down_weight,
+                            down_weight_scale, topk_ids, topk_scale, shared_output, rank_ep,
+                            num_expert_total, output):
+    return torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)

@@ -1,0 +1,37 @@
+"""hpc.group_gemm — grouped FP8 GEMM surface (reference hpc/group_gemm.py:134-199, blockwise)."""
+import torch
+from torch import Tensor
+
+from . import _entry_fuse_moe  # noqa: F401
+
+
+def group_gemm_blockwise_fp8(
+    x: Tensor,
+    weight: Tensor,
+    seqlens: Tensor,
+    cu_seqlens: Tensor,
+    x_scale: Tensor,
+    w_scale: Tensor,
+    num_seq_per_group_avg: int = 32,
+    output: Tensor = None,
+    tma_desc: Tensor = None,
+    task_map_workspace: Tensor = None,
+) -> Tensor:
+    """Grouped GEMM, FP8 operands with 128-block scales (reference hpc/group_gemm.py:134-199).
+
+    x e4m3 [total_seq, K]; weight e4m3 [G, N, K]; seqlens int32 [G]; cu_seqlens int32 [G+1];
+    x_scale f32 [K/128, total_seq_pad] in the reference's tile-padded column layout (group g starts
+    at column cu_tiles[g]*tileM, tileM from num_seq_per_group_avg); w_scale f32
+    [G, N/128, pad4(K/128)].  Returns bf16 [total_seq, N].  tma_desc / task_map_workspace are
+    accepted for API compatibility and ignored (no TMA on gfx950).
+    """
+    return torch.ops.hpc.group_gemm_blockwise_fp8(
+        x, weight, seqlens, cu_seqlens, x_scale, w_scale, num_seq_per_group_avg, output, tma_desc,
+        task_map_workspace,
+    )
+
+
+@torch.library.register_fake("hpc::group_gemm_blockwise_fp8")
+def group_gemm_blockwise_fp8_fake(x, weight, seqlens, cu_seqlens, x_scale, w_scale,
+                                  num_seq_per_group_avg, output, tma_desc, task_map_workspace):
+    return torch.empty((x.shape[0], weight.shape[1]), dtype=torch.bfloat16, device=x.device)

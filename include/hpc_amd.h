@@ -122,6 +122,71 @@ int hpc_attention_decode_fp8_async(void* y_ptr, void* workspace, const int* task
                                    int64_t kscale_block_stride, int64_t kscale_row_stride,
                                    int64_t kscale_head_stride, hpc_stream_t stream);
 
+/* ---- grouped FP8 GEMM with 128-block scales -------------------------------------------------------
+ * reference: group_gemm_blockwise_fp8_async, src/group_gemm/group_gemm.h:12-29
+ *            (kernel src/group_gemm/kernels.cuh:532-892; scatter-A variant cp_async/group_gemm_fp8_scatter.cu).
+ * Y[m, n] = bf16( sum_kb (sum_{k in kb} X[row(m),k] W[g,n,k]) * xs(m,kb) * ws[g, n/128, kb] ) for the
+ * seqlens[g] rows starting at cu_seqlens[g].  x e4m3 [rows, k]; w e4m3 [G, n, k]; ws f32
+ * [G, n/128, num_block_k_pad4]; y bf16 [m, n].  n, k multiples of 128.
+ * row_index (nullable): x / xs row of output row m (gather-free MoE), else row(m) = m.
+ * xs addressing in floats: xs[term * xscale_row_stride + kb * xscale_kb_stride] with
+ *   term = row(m)                       when col_base == NULL  (row-major [rows, k/128]: strides k/128, 1)
+ *   term = col_base[g]*tile_m + slot    when col_base != NULL  (reference layout [k/128, m_pad],
+ *                                        col_base = cu_tiles: strides 1, m_pad). */
+int hpc_group_gemm_blockwise_fp8_async(void* y_ptr, const void* x_ptr, const void* w_ptr,
+                                       const void* seqlens_ptr, const void* cu_seqlens_ptr,
+                                       const void* xscale_ptr, const void* wscale_ptr,
+                                       const void* row_index_ptr, const void* col_base_ptr,
+                                       int num_group, int m, int n, int k, int num_block_k_pad4,
+                                       int tile_m, int64_t xscale_row_stride,
+                                       int64_t xscale_kb_stride, hpc_stream_t stream);
+
+/* ---- fused MoE pieces ---------------------------------------------------------------------------
+ * reference: src/fuse_moe/fuse_moe.h:15-62 (count_and_gather_async / blockwise_count_and_gather_async,
+ *            reduce_async, fuse_moe_blockwise_async), src/activation/activation.h:15-53.
+ * hpc_moe_count_and_slot_async: seqlens[e], cu_seqlens[E+1], tiles[e] = ceil(seqlens/tile_m),
+ *   cu_tiles[E+1], topk_pos[T,k] (stable arrival order, -1 for experts outside
+ *   [rank_ep*E, (rank_ep+1)*E)), row_index[pos] = token.  All int32 device buffers.
+ * hpc_moe_tiles_async: tiles / cu_tiles from seqlens only.
+ * hpc_moe_gather_blockwise_async: x_gathered[pos] = x[token]; xscale_t[kb][cu_tiles[e]*tile_m+slot].
+ * hpc_act_mul_and_blockwise_quant_async: gate_up bf16 [rows, 2*I] -> out e4m3 [rows, I],
+ *   out_scale[r*scale_row_stride + jb*scale_block_stride] (r = row_to_col[row] or row); rows =
+ *   min(*num_rows_ptr, max_rows) when num_rows_ptr != NULL (device int).
+ * hpc_moe_reduce_async: y[t] = bf16(sum_j topk_scale[t,j]*x[topk_pos[t,j]] + shared[t]). */
+int hpc_moe_count_and_slot_async(const void* topk_ids, int num_tokens, int num_topk, int num_expert,
+                                 int rank_ep, int tile_m, void* seqlens, void* cu_seqlens,
+                                 void* tiles, void* cu_tiles, void* topk_pos, void* row_index,
+                                 hpc_stream_t stream);
+int hpc_moe_tiles_async(const void* seqlens, int num_group, int tile_m, void* tiles, void* cu_tiles,
+                        hpc_stream_t stream);
+int hpc_moe_gather_blockwise_async(const void* x, const void* x_scale, const void* topk_ids,
+                                   const void* topk_pos, const void* cu_seqlens,
+                                   const void* cu_tiles, int num_tokens, int num_topk,
+                                   int num_expert, int rank_ep, int hidden, int tile_m, int m_pad,
+                                   void* x_gathered, void* xscale_t, hpc_stream_t stream);
+int hpc_act_mul_and_blockwise_quant_async(void* out_ptr, void* out_scale_ptr, const void* gate_up_ptr,
+                                          const void* num_rows_ptr, int max_rows,
+                                          int intermediate_size, int64_t scale_row_stride,
+                                          int64_t scale_block_stride, const void* row_to_col_ptr,
+                                          hpc_stream_t stream);
+int hpc_moe_reduce_async(void* y_ptr, const void* x_ptr, const void* topk_pos_ptr,
+                         const void* topk_scale_ptr, const void* shared_output_ptr, int num_tokens,
+                         int num_topk, int hidden_size, hpc_stream_t stream);
+/* Whole blockwise pipeline (count/slot -> gate_up GEMM -> SiLU*up + quant -> down GEMM -> reduce);
+ * `workspace` >= hpc_fuse_moe_blockwise_workspace_bytes(...) bytes, uninitialised.
+ * intermediate_size2 = gate_up_weight.size(1) = 2*I (as in the reference entry, fuse_moe/entry.cc:520). */
+int64_t hpc_fuse_moe_blockwise_workspace_bytes(int num_tokens, int num_topk, int hidden_size,
+                                               int intermediate_size2, int num_expert);
+int hpc_fuse_moe_blockwise_async(void* y_ptr, void* workspace, const void* x_ptr,
+                                 const void* x_scale_ptr, const void* gate_up_weight_ptr,
+                                 const void* gate_up_weight_scale_ptr, const void* down_weight_ptr,
+                                 const void* down_weight_scale_ptr, const void* topk_ids_ptr,
+                                 const void* topk_scale_ptr, const void* shared_output_ptr,
+                                 int num_tokens, int hidden_size, int intermediate_size2,
+                                 int num_topk, int num_expert_total, int num_expert,
+                                 int gate_up_ws_pad4, int down_ws_pad4, int rank_ep,
+                                 hpc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,100 @@
+"""Fused-MoE (FP8 blockwise) oracles — TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+CPU restatements of the PyTorch-eager references of reference tests/test_fuse_moe_blockwise.py:
+  gather_expert_inputs              :23-78   (stable slotting in flattened (token, k) order)
+  group_gemm_blockwise              :81-138  (per 128x128 block: fp32 dot * xs * ws, bf16 round)
+  act_mul_and_blockwise_quant       :141-199 (x/(1+exp(-x)) * up; scale = amax/448; 1/(scale+1e-8))
+  reduce                            :202-217
+  fuse_moe_blockwise_fp8            :220-262
+The per-block GEMM uses an fp32 matmul on the upcast e4m3 operands instead of torch._scaled_mm
+with unit scales (same products - e4m3 x e4m3 is exact in fp32 - different summation order).
+"""
+import torch
+
+
+def gather_expert_inputs(x, x_scale, topk_ids, num_expert, rank_ep):
+    num_tokens, num_topk = topk_ids.shape
+    start, end = rank_ep * num_expert, (rank_ep + 1) * num_expert
+    flat = topk_ids.flatten()
+    counts = torch.zeros(num_expert, dtype=torch.int32)
+    for e in range(num_expert):
+        counts[e] = int((flat == start + e).sum())
+    cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(counts, 0).to(torch.int32)])
+    y = torch.zeros((num_tokens * num_topk, x.shape[1]), dtype=x.dtype)
+    y_scale = torch.zeros((num_tokens * num_topk, x_scale.size(1)), dtype=torch.float32)
+    token_pos = torch.full((num_tokens, num_topk), -1, dtype=torch.int32)
+    fill = torch.zeros(num_expert, dtype=torch.int64)
+    yb, xb = y.view(torch.uint8), x.view(torch.uint8)
+    for idx, ie in enumerate(flat.tolist()):
+        if start <= ie < end:
+            pos = int(cu[ie - start]) + int(fill[ie - start])
+            yb[pos] = xb[idx // num_topk]
+            y_scale[pos] = x_scale[idx // num_topk]
+            token_pos[idx // num_topk, idx % num_topk] = pos
+            fill[ie - start] += 1
+    return y, y_scale, token_pos, counts, cu
+
+
+def group_gemm_blockwise(x, w, seqlens, cu_seqlens, xscale, wscale):
+    """x e4m3 [M, K]; w e4m3 [G, N, K]; xscale f32 [M, K/128] (row-major); wscale [G, N/128, >=K/128]."""
+    m, k = x.shape
+    num_group, n, _ = w.shape
+    kb = k // 128
+    y = torch.zeros((m, n), dtype=torch.bfloat16)
+    for i in range(num_group):
+        s, cnt = int(cu_seqlens[i]), int(seqlens[i])
+        if cnt == 0:
+            continue
+        xg = x[s : s + cnt].float().reshape(cnt, kb, 128)
+        wg = w[i].float().reshape(n, kb, 128)
+        part = torch.einsum("mbk,nbk->mnb", xg, wg)                     # [cnt, n, kb]
+        ws = wscale[i][:, :kb].repeat_interleave(128, dim=0)            # [n, kb]
+        out = torch.zeros((cnt, n), dtype=torch.float32)
+        for b in range(kb):                                             # same += order as the reference
+            out += part[:, :, b] * xscale[s : s + cnt, b].unsqueeze(1) * ws[:, b].unsqueeze(0)
+        y[s : s + cnt] = out.to(torch.bfloat16)
+    return y
+
+
+def act_mul_and_blockwise_quant(gate_up_out):
+    gate, up = torch.chunk(gate_up_out.float(), 2, dim=1)
+    out = gate / (1 + (-gate).exp()) * up
+    rows, feats = out.shape
+    nblk = (feats + 127) // 128
+    q = torch.empty(rows, feats, dtype=torch.float8_e4m3fn)
+    scales = torch.empty(rows, nblk, dtype=torch.float32)
+    for b in range(nblk):
+        blk = out[:, b * 128 : (b + 1) * 128]
+        scale = blk.abs().amax(dim=1, keepdim=True) / 448.0
+        inv = 1.0 / (scale + 1e-8)
+        scales[:, b] = scale.squeeze(1)
+        q[:, b * 128 : (b + 1) * 128] = (blk * inv).to(torch.float8_e4m3fn)
+    return q, scales
+
+
+def reduce(x_bf16, topk_pos, topk_scale, shared_output=None):
+    num_tokens, num_topk = topk_pos.shape
+    pos = topk_pos.long().clamp_min(0)
+    rows = x_bf16.float()[pos]                                           # [T, k, H]
+    w = (topk_scale.float() * (topk_pos >= 0)).unsqueeze(-1)
+    acc = torch.zeros(num_tokens, x_bf16.shape[1], dtype=torch.float32)
+    for j in range(num_topk):                                            # same accumulation order
+        acc += rows[:, j] * w[:, j]
+    if shared_output is not None:
+        acc += shared_output.float()
+    return acc.to(torch.bfloat16)
+
+
+def fuse_moe_blockwise_fp8(x, x_scale, gate_up_weight, gate_up_weight_scale, down_weight,
+                           down_weight_scale, topk_ids, topk_scale, rank_ep, num_expert,
+                           shared_output=None, return_intermediates=False):
+    num_expert_local = gate_up_weight.size(0)
+    gi, gis, topk_pos, seqlens, cu = gather_expert_inputs(x, x_scale, topk_ids, num_expert_local, rank_ep)
+    g = group_gemm_blockwise(gi, gate_up_weight, seqlens, cu, gis, gate_up_weight_scale)
+    di, dis = act_mul_and_blockwise_quant(g)
+    d = group_gemm_blockwise(di, down_weight, seqlens, cu, dis, down_weight_scale)
+    y = reduce(d, topk_pos, topk_scale, shared_output)
+    if return_intermediates:
+        return y, dict(topk_pos=topk_pos, seqlens=seqlens, cu_seqlens=cu, gate_up=g, down_in=di,
+                       down_in_scale=dis, down_out=d)
+    return y

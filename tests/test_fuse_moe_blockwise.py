@@ -1,0 +1,137 @@
+"""Parity of hpc.fuse_moe_blockwise_fp8 / reduce / group_gemm_blockwise_fp8 with the CPU oracle.
+Generators and tolerance follow reference tests/test_fuse_moe_blockwise.py:265-350 (rtol=atol=0.01)
+and tests/test_group_gemm_blockwise.py:50-120."""
+import pytest
+import torch
+
+from utils import allclose
+
+F8 = torch.float8_e4m3fn
+
+
+def _inputs(num_tokens, num_topk, hidden, inter, num_expert, size_ep, shared, seed=41):
+    torch.manual_seed(seed)
+    topk_ids = torch.multinomial(torch.ones((num_tokens, num_expert)), num_topk, replacement=False).to(torch.int32)
+    topk_ids, _ = torch.sort(topk_ids, dim=1)
+    topk_scale = torch.rand((num_tokens, num_topk))
+    topk_scale = topk_scale / topk_scale.sum(dim=1, keepdim=True)
+    x = (torch.randn((num_tokens, hidden)) / 100).to(F8)
+    x_scale = torch.randn((num_tokens, hidden // 128))
+    el = num_expert // size_ep
+    guw = torch.randn((el, inter * 2, hidden)).to(F8)
+    guws = torch.randn((el, inter * 2 // 128, (hidden // 128 + 3) // 4 * 4))
+    dw = torch.randn((el, hidden, inter)).to(F8)
+    dws = torch.randn((el, hidden // 128, (inter // 128 + 3) // 4 * 4))
+    so = torch.randn((num_tokens, hidden), dtype=torch.bfloat16) if shared else None
+    return x, x_scale, guw, guws, dw, dws, topk_ids, topk_scale, so
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_tokens", [1, 7, 128, 700])
+@pytest.mark.parametrize("inter", [512, 256])
+@pytest.mark.parametrize("rank_ep,size_ep", [(0, 1), (1, 4), (0, 8)])
+@pytest.mark.parametrize("shared", [False, True])
+def test_fuse_moe_blockwise_fp8(num_tokens, inter, rank_ep, size_ep, shared):
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    num_expert, num_topk, hidden = 128, 8, 512
+    args = _inputs(num_tokens, num_topk, hidden, inter, num_expert, size_ep, shared)
+    x, x_scale, guw, guws, dw, dws, topk_ids, topk_scale, so = args
+    gt = omoe.fuse_moe_blockwise_fp8(x, x_scale, guw, guws, dw, dws, topk_ids, topk_scale, rank_ep,
+                                     num_expert, so)
+    dev = [t.cuda() if t is not None else None for t in args]
+    my = hpc.fuse_moe_blockwise_fp8(dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], dev[6], dev[7],
+                                    rank_ep, num_expert, dev[8])
+    torch.cuda.synchronize()
+    assert allclose(gt.float(), my.cpu().float(), rtol=0.01, atol=0.01)
+    out = torch.empty_like(my)
+    my2 = hpc.fuse_moe_blockwise(dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], dev[6], dev[7],
+                                 rank_ep, num_expert, dev[8], out)
+    torch.cuda.synchronize()
+    assert my2.data_ptr() == out.data_ptr() and torch.equal(my2, my)  # deterministic routing
+
+
+@pytest.mark.gpu
+def test_moe_routing_is_bit_exact():
+    """routing indices must be bit-exact (BASELINE north_star): compare the device prep with the
+    oracle's stable slotting through the C-ABI."""
+    import hpc  # noqa: F401
+    from hpc import _C
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(3)
+    T, k, E, rank, size_ep = 333, 8, 128, 1, 4
+    el = E // size_ep
+    ids = torch.sort(torch.multinomial(torch.ones((T, E)), k, replacement=False).to(torch.int32), dim=1)[0]
+    x = torch.zeros((T, 128)).to(F8)
+    _, _, pos_ref, cnt_ref, cu_ref = omoe.gather_expert_inputs(x, torch.zeros(T, 1), ids, el, rank)
+    d = ids.cuda()
+    i32 = dict(dtype=torch.int32, device="cuda")
+    seqlens, cu = torch.empty(el, **i32), torch.empty(el + 1, **i32)
+    tiles, cut = torch.empty(el, **i32), torch.empty(el + 1, **i32)
+    pos, rowidx = torch.empty(T, k, **i32), torch.full((T * k,), -7, **i32)
+    rc = _C.lib.hpc_moe_count_and_slot_async(_C.ptr(d), T, k, el, rank, 16, _C.ptr(seqlens), _C.ptr(cu),
+                                             _C.ptr(tiles), _C.ptr(cut), _C.ptr(pos), _C.ptr(rowidx),
+                                             _C.stream_of(d))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(pos.cpu(), pos_ref)
+    assert torch.equal(seqlens.cpu(), cnt_ref) and torch.equal(cu.cpu(), cu_ref)
+    assert torch.equal(tiles.cpu(), (cnt_ref + 15) // 16)
+    total = int(cu_ref[-1])
+    flat_pos = pos_ref.flatten()
+    expect = torch.full((T * k,), -7, dtype=torch.int32)
+    sel = flat_pos >= 0
+    expect[flat_pos[sel].long()] = (torch.arange(T * k)[sel] // k).to(torch.int32)
+    assert torch.equal(rowidx.cpu()[:total], expect[:total])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_group,actual_m,n,k", [(16, 30, 1024, 4096), (8, 5, 256, 512),
+                                                    (4, 70, 384, 1408)])
+def test_group_gemm_blockwise(num_group, actual_m, n, k):
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(0)
+    seqlens = torch.full((num_group,), actual_m, dtype=torch.int32)
+    seqlens[-1] = max(actual_m - 3, 0)
+    total = int(seqlens.sum())
+    x = (torch.randn((total, k)) / 10).to(F8)
+    w = (torch.randn((num_group, n, k)) / 10).to(F8)
+    kb = k // 128
+    xs_rows = torch.randn((total, kb))
+    wscale = torch.randn((num_group, n // 128, (kb + 3) // 4 * 4))
+    cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
+    gt = omoe.group_gemm_blockwise(x, w, seqlens, cu, xs_rows, wscale)
+    # reference layout: [K/128, m_pad_total], group g at column cu_tiles[g]*tileM
+    tile_m = hpc._entry_fuse_moe.aligned_size(actual_m)
+    tiles = (seqlens + tile_m - 1) // tile_m
+    cu_tiles = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(tiles, 0)])
+    xs_t = torch.zeros((kb, int(cu_tiles[-1]) * tile_m + 64))
+    for g in range(num_group):
+        c0 = int(cu_tiles[g]) * tile_m
+        xs_t[:, c0 : c0 + int(seqlens[g])] = xs_rows[int(cu[g]) : int(cu[g]) + int(seqlens[g])].t()
+    my = hpc.group_gemm_blockwise_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), xs_t.cuda(),
+                                      wscale.cuda(), num_seq_per_group_avg=actual_m)
+    torch.cuda.synchronize()
+    assert allclose(gt.float(), my.cpu().float(), rtol=0.01, atol=0.02)
+
+
+@pytest.mark.gpu
+def test_reduce():
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(1)
+    T, k, H = 37, 8, 640
+    x = torch.randn(T * k, H, dtype=torch.bfloat16)
+    pos = torch.randperm(T * k).reshape(T, k).to(torch.int32)
+    pos[::3, 2] = -1
+    sc = torch.rand(T, k)
+    so = torch.randn(T, H, dtype=torch.bfloat16)
+    for shared in (None, so):
+        gt = omoe.reduce(x, pos, sc, shared)
+        my = hpc.reduce(x.cuda(), pos.cuda(), sc.cuda(), None if shared is None else shared.cuda())
+        assert allclose(gt.float(), my.cpu().float(), rtol=0.01, atol=0.01)
