@@ -64,6 +64,18 @@ _sig("hpc_moe_reduce_async", I, P, P, P, P, P, I, I, I, P)
 _sig("hpc_fuse_moe_blockwise_workspace_bytes", L, I, I, I, I, I)
 _sig("hpc_fuse_moe_blockwise_async", I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P)
 
+PP = ctypes.POINTER(c_void_p)
+_sig("hpc_comm_create", I, I, I, I, c_char_p)
+_sig("hpc_comm_destroy", I, I)
+_sig("hpc_comm_barrier", I, I)
+_sig("hpc_comm_allgather", I, I, P, L, P)
+_sig("hpc_comm_info", I, I, IP, IP, IP)
+_sig("hpc_comm_create_tensor_sync", I, I, L, PP)
+_sig("hpc_comm_lookup_peers", I, P, PP, IP)
+_sig("hpc_fuse_allreduce_rmsnorm_high_throughput_async", I, PP, PP, PP, P, P, P, F, I, I, I, I, I, P)
+_sig("hpc_fuse_allreduce_rmsnorm_low_latency_async", I, P, P, P, P, P, P, P, P, F, I, I, I, I, L, P)
+_sig("hpc_allreduce_timeouts", I)
+
 # torch op namespace `hpc` (reference: TORCH_LIBRARY(hpc, m), src/C/C.cc:5)
 torch_lib = torch.library.Library("hpc", "DEF")
 

@@ -187,6 +187,49 @@ int hpc_fuse_moe_blockwise_async(void* y_ptr, void* workspace, const void* x_ptr
                                  int gate_up_ws_pad4, int down_ws_pad4, int rank_ep,
                                  hpc_stream_t stream);
 
+/* ---- communicator: socket rendezvous + symmetric device buffers (HIP IPC over xGMI) ---------------
+ * reference: src/communicator/{communicator,channel,listener,connector,protocol}.cc (rank-0 star over
+ *            an abstract unix socket "unix://name" / bare name, or "tcp://ip:port"),
+ *            multicast_communicator.cc:21-153 (CreateTensorSync), entry.cc:18-90 (torch class).
+ * hpc_comm_create returns a handle > 0 (negative = error); device_id < 0 = no HIP device (host-only
+ * rendezvous, used by the CPU tests).  hpc_comm_create_tensor_sync is collective: allocates nbytes of
+ * uncached device memory on every rank, exchanges IPC handles, ptrs_out[r] = rank r's buffer mapped
+ * in this process (there is no multicast object on xGMI).  hpc_comm_lookup_peers translates an
+ * address inside a local symmetric buffer into the same offset of every rank's buffer (returns the
+ * world size or -1). */
+int hpc_comm_create(int rank, int world_size, int device_id, const char* name);
+int hpc_comm_destroy(int handle);
+int hpc_comm_barrier(int handle);
+int hpc_comm_allgather(int handle, const void* in, int64_t nbytes, void* out);
+int hpc_comm_info(int handle, int* rank, int* world_size, int* device_id);
+int hpc_comm_create_tensor_sync(int handle, int64_t nbytes, void** ptrs_out);
+int hpc_comm_lookup_peers(const void* ptr, void** peer_ptrs, int* rank_out);
+
+/* ---- fused AllReduce + residual + RMSNorm (bf16) over peer memory ------------------------------------
+ * reference: fuse_allreduce_rmsnorm_high_throughput_async, src/allreduce/
+ *            fuse_allreduce_rmsnorm_high_throughput.h:11-17 (kernel .cu:15-99), and
+ *            fuse_allreduce_rmsnorm_low_latency_async, fuse_allreduce_rmsnorm_low_latency.h:29-49,503-504.
+ * R = bf16(sum_r x_r + residual); out = bf16(float(R) * rsqrt(mean(R^2) + eps) * w).
+ * High throughput: this rank owns `num_rows` token rows; peer_x_ptrs[p] / peer_out_ptrs[p] address
+ *   those rows inside rank p's symmetric input / output buffers, peer_signal_ptrs[p] rank p's signal
+ *   pad (>= num_max_blocks * world_size uint32, zero-initialised).  All ranks must use the same
+ *   num_max_blocks.  hidden <= 16384, world_size <= 8.  (The reference supports H in {4096,5120,7168}.)
+ * Low latency (Lamport, token t owned by rank t % world_size): data_buffer_ptrs_dev = device int64
+ *   table of the ranks' workspace bases, workspace = 3 slots x 2 stages, pre-filled with 0x80000000
+ *   words by the caller, buffer_flags_dev = 9 x uint32 {cur, dirty, bytes per slot, 0, bytes to clear
+ *   x4, arrive} advanced on the device.
+ * hpc_allreduce_timeouts: number of bounded spins that gave up since load (0 in a healthy run). */
+int hpc_fuse_allreduce_rmsnorm_high_throughput_async(
+    const void* const* peer_x_ptrs, void* const* peer_out_ptrs, void* const* peer_signal_ptrs,
+    const void* residual_ptr, void* out_residual_ptr, const void* weight_ptr, float rms_norm_eps,
+    int num_rows, int hidden_size, int rank, int world_size, int num_max_blocks, hpc_stream_t stream);
+int hpc_fuse_allreduce_rmsnorm_low_latency_async(
+    void* output_ptr, void* residual_out_ptr, const void* input_ptr, const void* data_buffer_ptrs_dev,
+    void* local_workspace_ptr, void* buffer_flags_dev, const void* residual_in_ptr,
+    const void* weight_ptr, float rms_norm_eps, int num_tokens, int hidden_size, int rank,
+    int world_size, int64_t workspace_bytes, hpc_stream_t stream);
+int hpc_allreduce_timeouts(void);
+
 #ifdef __cplusplus
 }
 #endif
