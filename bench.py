@@ -57,12 +57,12 @@ def algorithmic_bytes(w):
     return kv + qo
 
 
-def cpu_baseline(q, k_cache, v_cache, block_ids, kv_lens, w, sample_requests=8):
+def cpu_baseline(q, k_cache, v_cache, block_ids, kv_lens, w, sample_requests=4):
     """The reference's PyTorch-eager oracle (oracle/attention.py) timed on the host cores over a
     bounded sample of the same workload (first `sample_requests` requests)."""
     from oracle import attention as oattn
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)  # more threads than this only adds contention for this op
     torch.set_num_threads(cores)
     rows = list(range(min(sample_requests, w["batch"])))
     qc, kc, vc = q.cpu(), k_cache.cpu(), v_cache.cpu()
@@ -80,6 +80,104 @@ def cpu_baseline(q, k_cache, v_cache, block_ids, kv_lens, w, sample_requests=8):
     }
 
 
+def timed(fn, iters=30, warm=5):
+    """median microseconds per call from events on the current stream"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
+    ev[0].record()
+    for i in range(iters):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))
+    return ts[len(ts) // 2] * 1e3
+
+
+def extra_decode(dev, hpc):
+    """secondary decode numbers: HND layout at the headline shape, FP8 (BASELINE configs[2])."""
+    out = {}
+    w = dict(WORKLOAD)
+    B, P, D, Hkv, Hq, S = w["batch"], 64, 128, w["num_head_kv"], w["num_head_q"], w["seq_kv"]
+    torch.manual_seed(41)
+    nb = S // P
+    nblk = int(B * nb * 1.2) + B + 8
+    q = torch.randn(B, Hq, D, dtype=torch.bfloat16, device=dev) / math.sqrt(D)
+    k = (torch.randn(nblk, Hkv, P, D, dtype=torch.bfloat16, device=dev) / math.sqrt(D)).permute(0, 2, 1, 3)
+    v = torch.randn(nblk, Hkv, P, D, dtype=torch.bfloat16, device=dev).permute(0, 2, 1, 3)
+    bid = torch.randperm(nblk, device=dev)[: B * nb].to(torch.int32).reshape(B, nb).contiguous()
+    lens = torch.full((B,), S, dtype=torch.int32, device=dev)
+    tm = hpc.get_attention_decode_task_workspace(B, S, Hkv, 64)
+    hpc.assign_attention_decode_task(lens, tm, Hkv, 1, True, 64)
+    o = torch.empty_like(q)
+    us = timed(lambda: hpc.attention_decode_bf16(q, k, v, bid, lens, 0, True, True, tm, None, o))
+    kvb = B * S * Hkv * 256 * 2
+    out["decode_bf16_hnd_layout"] = {"us": round(us, 1), "GBps": round(kvb / us / 1e3, 1)}
+    del k, v
+    # FP8, q per-token/per-head, kv per-tensor, mixed lengths log-uniform in [128, 32768] (seed 41)
+    g = torch.Generator().manual_seed(41)
+    lens_c = torch.exp(torch.rand(B, generator=g) * (math.log(32768) - math.log(128)) + math.log(128)).to(torch.int32)
+    nbl = (lens_c + P - 1) // P
+    nblk = int(int(nbl.sum()) * 1.2) + B + 8
+    q8 = (torch.randn(B, Hq, D, device=dev) ).to(torch.float8_e4m3fn)
+    qs = torch.rand(B, Hq, device=dev) * 0.01 + 0.005
+    k8 = torch.randn(nblk, P, Hkv, D, device=dev).to(torch.float8_e4m3fn)
+    v8 = torch.randn(nblk, P, Hkv, D, device=dev).to(torch.float8_e4m3fn)
+    bid = torch.zeros(B, int(nbl.max()), dtype=torch.int32, device=dev)
+    perm = torch.randperm(nblk, device=dev).to(torch.int32)
+    off = 0
+    for i, n in enumerate(nbl.tolist()):
+        bid[i, :n] = perm[off : off + n]
+        off += n
+    lens = lens_c.to(dev)
+    ks = torch.tensor([0.02], device=dev)
+    vs = torch.tensor([0.03], device=dev)
+    tm = hpc.get_attention_decode_task_workspace(B, int(lens_c.max()), Hkv, 512)
+    hpc.assign_attention_decode_task(lens, tm, Hkv, 1, True, 512)
+    o = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=dev)
+    us = timed(lambda: hpc.attention_decode_fp8(q8, k8, v8, bid, lens, qs, ks, vs, 0, True,
+                                               hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, True, tm, None, o))
+    us_sched = timed(lambda: hpc.assign_attention_decode_task(lens, tm, Hkv, 1, True, 512))
+    kvb = int(lens_c.sum()) * Hkv * 256
+    out["decode_fp8_mixed_128_32k"] = {"us": round(us, 1), "GBps": round(kvb / us / 1e3, 1),
+                                       "hbm_frac_of_8TBps": round(kvb / us / 1e3 / HBM_PEAK_GBPS, 4),
+                                       "scheduler_us": round(us_sched, 1), "kv_bytes": kvb,
+                                       "config": "batch 64, 8 KV / 64 Q heads, fp8 q per-token/per-head, kv per-tensor, "
+                                                 "NHD pages of 64, lens log-uniform[128,32768] seed 41"}
+    return out
+
+
+def extra_moe(dev, hpc, tokens=(16, 64, 256)):
+    """fused MoE FP8 blockwise, BASELINE configs[3]: 64 experts top-8, hidden 4096, ffn 11008."""
+    E, k, H, I = 64, 8, 4096, 11008
+    torch.manual_seed(41)
+    f8 = torch.float8_e4m3fn
+
+    def rnd8(*shape):  # random e4m3 bytes without a multi-GB fp32 temporary
+        t = torch.randint(-80, 80, shape, dtype=torch.int8, device=dev)
+        return t.view(f8)
+
+    guw, dw = rnd8(E, 2 * I, H), rnd8(E, H, I)
+    guws = torch.rand(E, 2 * I // 128, (H // 128 + 3) // 4 * 4, device=dev) * 0.02
+    dws = torch.rand(E, H // 128, (I // 128 + 3) // 4 * 4, device=dev) * 0.02
+    res = {}
+    for T in tokens:
+        ids = torch.sort(torch.multinomial(torch.ones(T, E, device=dev), k).to(torch.int32), dim=1)[0]
+        sc = torch.rand(T, k, device=dev)
+        sc = sc / sc.sum(1, keepdim=True)
+        x = (torch.randn(T, H, device=dev) / 100).to(f8)
+        xs = torch.rand(T, H // 128, device=dev)
+        us = timed(lambda: hpc.fuse_moe_blockwise_fp8(x, xs, guw, guws, dw, dws, ids, sc, 0, E), iters=10, warm=2)
+        hit = int(torch.unique(ids).numel())
+        wbytes = hit * (2 * I * H + H * I)
+        flops = 2.0 * T * k * (2 * I * H + H * I)
+        res[f"T{T}"] = {"us": round(us, 1), "TFLOPS": round(flops / us / 1e6, 2),
+                        "weight_GBps": round(wbytes / us / 1e3, 1),
+                        "hbm_frac_of_8TBps": round(wbytes / us / 1e3 / HBM_PEAK_GBPS, 4), "experts_hit": hit}
+    return {"fuse_moe_blockwise_fp8_E64_top8_H4096_I11008": res}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +185,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -164,6 +263,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
+    extras = {}
+    if rank == 0 and not args.no_extras:
+        del graph
+        for fn in (extra_decode, extra_moe):
+            try:
+                extras.update(fn(dev, hpc))
+            except Exception as e:  # noqa: BLE001
+                extras[fn.__name__] = {"error": repr(e)[:200]}
+            torch.cuda.empty_cache()
+        graph = None if args.no_graph else True
+
     if rank == 0:
         nbytes = algorithmic_bytes(w)
         ms_per_step = wall / args.steps * 1e3
@@ -195,6 +305,7 @@ def main():
                 "kernel": "hpc::decode::decode_bf16_kernel<1> (+ combine), HIP events per launch",
             },
             "cpu_baseline": cpu,
+            "extras": extras,
         }
         print(json.dumps(line))
     if dist_on:
