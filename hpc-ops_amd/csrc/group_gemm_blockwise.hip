@@ -9,10 +9,12 @@
 // stream of the weights (HBM-bound).  Same swap as the reference - weights on the
 // MFMA M axis, tokens on N (v_mfma_f32_16x16x32_fp8_fp8, 16 tokens per pass) - but no TMA /
 // warp specialisation: each WAVE owns 32 weight rows of one expert and streams them HBM -> VGPR
-// with 16-byte non-temporal buffer loads, 8 k-blocks (8 KB) deep, no LDS, no barriers.  The few
-// activation rows come from L2 at the same prefetch depth (vmcnt retires in order, so a shallower
-// X pipeline would drain the weight stream).  Per 128-wide k block the fp32 partial is rescaled by
-// xs*ws and accumulated (reference kernels.cuh:806-836).  8 waves/CU x 16 KB of weights in flight.
+// with 16-byte non-temporal buffer loads (4 stages of 256 B per row = 32 KB in flight per wave).
+// The activation tile (16/32/64 tokens) of the expert is shared by the 4 waves of a workgroup
+// through a small double-buffered LDS tile, fetched at the same prefetch depth as the weights
+// (vmcnt retires in order, so a shallower activation pipeline would drain the weight stream).
+// Per 128-wide k block the fp32 partial is rescaled by xs*ws and accumulated (reference
+// kernels.cuh:806-836).
 #include "hpc_common.h"
 #include "../../include/hpc_amd.h"
 
@@ -34,59 +36,99 @@ struct Args {
 };
 
 constexpr int kThreads = 256;
-constexpr int kDepth = 4;  // k-blocks (4 KB of weights each) in flight per wave
+constexpr int kDepth = 4;     // stages in flight per wave; one stage = 2 k-blocks = 256 B per weight row
+constexpr int kXRow = 272;    // LDS bytes per staged activation row (256 + 16: conflict-free b128 reads)
 
 __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
   return static_cast<long>(static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32));
 }
 
-__global__ __launch_bounds__(kThreads, 2) void gemm_blockwise_stream_kernel(const Args a) {
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+// kMT = token blocks of 16 served per pass over the weights (1, 2 or 4); kR = 16-row weight blocks
+// per wave (1 or 2): the workgroup tile is 64*kR rows.
+//
+// Workgroup = 4 waves = one 64*kR-row weight tile of one expert (inside one 128-row scale block).  Each
+// wave streams its own 16*kR weight rows HBM -> VGPR in MFMA A-operand layout (non-temporal buffer
+// loads, kDepth stages = 32 KB in flight per wave, 256 B per row per stage issued back to back).
+// The activation tile (16*kMT tokens x 256 B) and its scales are shared: every wave fetches a
+// quarter at the same prefetch depth as the weights (vmcnt retires in order - a shallower
+// activation pipeline would drain the weight stream), drops it into a double-buffered LDS tile,
+// and after ONE barrier per stage all waves read their B operands from LDS.
+template <int kMT, int kR>
+__global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockwise_stream_kernel(const Args a) {
+  constexpr int kTok = 16 * kMT;
+  __shared__ __attribute__((aligned(16))) uint8_t s_x[2][kTok * kXRow];
+  __shared__ float s_xs[2][2][kTok];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g4 = lane >> 4;
   const int e = blockIdx.y;
   const int m_cnt = as_const(a.seqlens)[e];
   if (m_cnt <= 0) return;
-  const int n0 = (blockIdx.x * 4 + wave) * 32;
-  if (n0 >= a.N) return;
+  const int n0 = (blockIdx.x * 4 + wave) * 16 * kR;  // N % 128 == 0 is checked by the launcher
   const int m0 = as_const(a.cu_seqlens)[e];
   const int K = a.K, KB = a.KB;
+  const int nstage = (KB + 1) >> 1;
 
   const uint8_t* wbase = a.w + (static_cast<long>(e) * a.N + n0) * K;
   const unsigned w_bytes = 16u * static_cast<unsigned>(K);
   const int w_voff = r16 * K + g4 * 16;
   const cint_ptr ws_row = as_const(reinterpret_cast<const int*>(a.ws)) +
                           (static_cast<long>(e) * (a.N >> 7) + (n0 >> 7)) * a.ws_ld;
+  const int xs_kb_bytes = static_cast<int>(a.xs_kb_stride * 4);
+  const long col0 = a.col_base ? static_cast<long>(as_const(a.col_base)[e]) * a.tile_m : 0;
 
-  const int npass = (m_cnt + 15) >> 4;
+  const int npass = (m_cnt + kTok - 1) / kTok;
   for (int p = 0; p < npass; ++p) {
-    const int slot = p * 16 + r16;
-    const bool valid = slot < m_cnt;
-    const int sc = valid ? slot : 0;
-    const int xrow = a.row_index ? a.row_index[m0 + sc] : m0 + sc;
-    const unsigned x_voff = static_cast<unsigned>(xrow) * static_cast<unsigned>(K) + g4 * 16;
-    const long xs_term = a.col_base ? static_cast<long>(as_const(a.col_base)[e]) * a.tile_m + sc
-                                    : static_cast<long>(xrow);
-    const unsigned xs_voff = static_cast<unsigned>(xs_term * a.xs_row_stride * 4);
-    const int xs_kb_bytes = static_cast<int>(a.xs_kb_stride * 4);
-
-    u32x4 wb[kDepth][2][2];
-    u32x4 xb[kDepth][2];
-    float xsb[kDepth];
-    auto issue = [&](int d, int kn) {
-      const unsigned on = kn < KB ? 1u : 0u;
-      const int koff = kn * 128;
+    // ---- this lane's roles in staging the activation tile ------------------------------------------
+    // x rows: instruction i = wave*kMT + j loads tile rows 4i .. 4i+3, lane -> (row 4i + g4, chunk r16)
+    unsigned x_voff[kMT];
+    int x_lds[kMT];
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        const auto rw = make_rsrc(wbase + static_cast<long>(rb) * 16 * K, on ? w_bytes : 0u);
-        wb[d][rb][0] = buf_ld16<2>(rw, w_voff, koff);
-        wb[d][rb][1] = buf_ld16<2>(rw, w_voff + 64, koff);
+    for (int j = 0; j < kMT; ++j) {
+      const int trow = 4 * (wave * kMT + j) + g4;
+      const int slot = p * kTok + trow;
+      const int sc = slot < m_cnt ? slot : m_cnt - 1;
+      const int xrow = a.row_index ? a.row_index[m0 + sc] : m0 + sc;
+      x_voff[j] = static_cast<unsigned>(xrow) * static_cast<unsigned>(K) + r16 * 16;
+      x_lds[j] = trow * kXRow + r16 * 16;
+    }
+    // scales: waves 0/1 load k-block 0/1 of the stage, lane -> token `lane`
+    unsigned xs_voff = 0;
+    const bool xs_role = wave < 2 && lane < kTok;
+    if (xs_role) {
+      const int slot = p * kTok + lane;
+      const int sc = slot < m_cnt ? slot : m_cnt - 1;
+      const long term = a.col_base ? col0 + sc : static_cast<long>(a.row_index ? a.row_index[m0 + sc] : m0 + sc);
+      xs_voff = static_cast<unsigned>(term * a.xs_row_stride * 4);
+    }
+
+    u32x4 wb[kDepth][2][kR][2];  // [stage][k-block of the stage][row block][64-byte half]
+    u32x4 xb[kDepth][kMT];
+    float xsb[kDepth];
+    auto issue = [&](int d, int st) {
+      const int kb0 = 2 * st;
+      const unsigned on0 = kb0 < KB ? 1u : 0u, on1 = kb0 + 1 < KB ? 1u : 0u;
+      const int koff = kb0 * 128;
+#pragma unroll
+      for (int rb = 0; rb < kR; ++rb) {
+        const uint8_t* base = wbase + static_cast<long>(rb) * 16 * K;
+        const auto rw0 = make_rsrc(base, on0 ? w_bytes : 0u);
+        const auto rw1 = make_rsrc(base, on1 ? w_bytes : 0u);
+        wb[d][0][rb][0] = buf_ld16<2>(rw0, w_voff, koff);
+        wb[d][0][rb][1] = buf_ld16<2>(rw0, w_voff + 64, koff);
+        wb[d][1][rb][0] = buf_ld16<2>(rw1, w_voff + 128, koff);
+        wb[d][1][rb][1] = buf_ld16<2>(rw1, w_voff + 192, koff);
       }
-      const auto rx = make_rsrc(a.x, on ? 0xffffffffu : 0u);
-      xb[d][0] = buf_ld16<0>(rx, x_voff, koff);
-      xb[d][1] = buf_ld16<0>(rx, x_voff + 64, koff);
-      const auto rs = make_rsrc(a.xs, on ? 0xffffffffu : 0u);
-      xsb[d] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, xs_voff, kn * xs_kb_bytes, 0));
+      // activation quarter: a 16-byte chunk of the 256-byte stage slab per lane; chunks 8..15 belong
+      // to the second k-block of the stage
+      const auto rx = make_rsrc(a.x, (r16 < 8 ? on0 : on1) ? 0xffffffffu : 0u);
+#pragma unroll
+      for (int j = 0; j < kMT; ++j) xb[d][j] = buf_ld16<0>(rx, x_voff[j], koff);
+      const auto rs = make_rsrc(a.xs, (xs_role && (wave == 0 ? on0 : on1)) ? 0xffffffffu : 0u);
+      xsb[d] = __uint_as_float(
+          __builtin_amdgcn_raw_buffer_load_b32(rs, xs_voff, (kb0 + wave) * xs_kb_bytes, 0));
     };
 
     __builtin_amdgcn_sched_barrier(0);
@@ -96,42 +138,70 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_blockwise_stream_kernel(cons
       __builtin_amdgcn_sched_barrier(0);  // keep issue order = consumption order (in-order vmcnt)
     }
 
-    f32x4 tot[2];
-    tot[0] = tot[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kb0 = 0; kb0 < KB; kb0 += kDepth) {
+    f32x4 tot[kR][kMT];
+#pragma unroll
+    for (int rb = 0; rb < kR; ++rb)
+#pragma unroll
+      for (int mt = 0; mt < kMT; ++mt) tot[rb][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int st0 = 0; st0 < nstage; st0 += kDepth) {
 #pragma unroll
       for (int d = 0; d < kDepth; ++d) {
-        const int kb = kb0 + d;
-        const int kbc = kb < KB ? kb : KB - 1;
-        const float wsk = __int_as_float(ws_row[kbc]);
-        const float f = xsb[d] * wsk;  // loads past K return 0 -> contribute nothing
+        const int st = st0 + d;
+        const int buf = d & 1;  // kDepth is even, so stage parity == d parity
+        // stage my quarter of the activation tile, then one barrier for the whole workgroup
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-          f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < kMT; ++j)
+          *reinterpret_cast<u32x4*>(&s_x[buf][x_lds[j]]) = xb[d][j];
+        if (xs_role) s_xs[buf][wave][lane] = xsb[d];
+        __syncthreads();
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            part = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                pack64(wb[d][rb][h][0], wb[d][rb][h][1]), pack64(xb[d][h][0], xb[d][h][1]), part, 0, 0, 0);
-            part = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                pack64(wb[d][rb][h][2], wb[d][rb][h][3]), pack64(xb[d][h][2], xb[d][h][3]), part, 0, 0, 0);
+        for (int kbl = 0; kbl < 2; ++kbl) {
+          const int kb = 2 * st + kbl;
+          const int kbc = kb < KB ? kb : KB - 1;
+          const float wsk = kb < KB ? __int_as_float(ws_row[kbc]) : 0.f;
+#pragma unroll
+          for (int mt = 0; mt < kMT; ++mt) {
+            const uint8_t* xp = &s_x[buf][(mt * 16 + r16) * kXRow + kbl * 128 + g4 * 16];
+            const u32x4 b0 = *reinterpret_cast<const u32x4*>(xp);
+            const u32x4 b1 = *reinterpret_cast<const u32x4*>(xp + 64);
+            const float f = s_xs[buf][kbl][mt * 16 + r16] * wsk;
+#pragma unroll
+            for (int rb = 0; rb < kR; ++rb) {
+              f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
+              part = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                  pack64(wb[d][kbl][rb][0][0], wb[d][kbl][rb][0][1]), pack64(b0[0], b0[1]), part, 0, 0, 0);
+              part = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                  pack64(wb[d][kbl][rb][0][2], wb[d][kbl][rb][0][3]), pack64(b0[2], b0[3]), part, 0, 0, 0);
+              part = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                  pack64(wb[d][kbl][rb][1][0], wb[d][kbl][rb][1][1]), pack64(b1[0], b1[1]), part, 0, 0, 0);
+              part = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                  pack64(wb[d][kbl][rb][1][2], wb[d][kbl][rb][1][3]), pack64(b1[2], b1[3]), part, 0, 0, 0);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) tot[rb][mt][i] = fmaf(part[i], f, tot[rb][mt][i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // stop hipcc hoisting every LDS read of the stage (VGPRs)
           }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) tot[rb][i] = fmaf(part[i], f, tot[rb][i]);
         }
-        issue(d, kb + kDepth);
+        issue(d, st + kDepth);
       }
     }
 
-    if (valid) {
 #pragma unroll
-      for (int rb = 0; rb < 2; ++rb) {
-        u32x2 pk;
-        pk[0] = pack_bf16x2(tot[rb][0], tot[rb][1]);
-        pk[1] = pack_bf16x2(tot[rb][2], tot[rb][3]);
-        *reinterpret_cast<u32x2*>(a.y + static_cast<long>(m0 + slot) * a.N + n0 + rb * 16 + g4 * 4) = pk;
+    for (int mt = 0; mt < kMT; ++mt) {
+      const int slot = p * kTok + mt * 16 + r16;
+      if (slot < m_cnt) {
+#pragma unroll
+        for (int rb = 0; rb < kR; ++rb) {
+          u32x2 pk;
+          pk[0] = pack_bf16x2(tot[rb][mt][0], tot[rb][mt][1]);
+          pk[1] = pack_bf16x2(tot[rb][mt][2], tot[rb][mt][3]);
+          *reinterpret_cast<u32x2*>(a.y + static_cast<long>(m0 + slot) * a.N + n0 + rb * 16 + g4 * 4) = pk;
+        }
       }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // retire stores before the next pass (see attention_decode.hip)
+    __syncthreads();
   }
 }
 
@@ -169,8 +239,23 @@ extern "C" int hpc_group_gemm_blockwise_fp8_async(
   a.tile_m = tile_m;
   a.xs_row_stride = xscale_row_stride;
   a.xs_kb_stride = xscale_kb_stride;
-  dim3 grid((n + 127) / 128, num_group);
-  gemm_blockwise_stream_kernel<<<grid, kThreads, 0, stream>>>(a);
+  const int forced_r = hpc_tuning_get(2);
+  // tokens served per pass over the weights, from the average group size (the reference picks its
+  // tileM the same way, fuse_moe/entry.cc:525-543); larger groups take several passes
+  const int avg = m / num_group;
+  const int forced = hpc_tuning_get(1);
+  const int mt = forced ? forced : (avg <= 10 ? 1 : 2);  // 64 tokens/pass (mt 4) is experimental: register-bound
+  // 64 tokens per pass needs the whole register file of a SIMD (1 workgroup per CU, 32 rows per
+  // wave); 16 / 32 tokens run 2 workgroups per CU with 16 rows per wave
+  (void)forced_r;
+  const int r = mt == 4 ? 2 : 1;
+  dim3 grid(n / (64 * r), num_group);
+  if (mt == 1)
+    gemm_blockwise_stream_kernel<1, 1><<<grid, kThreads, 0, stream>>>(a);
+  else if (mt == 2)
+    gemm_blockwise_stream_kernel<2, 1><<<grid, kThreads, 0, stream>>>(a);
+  else
+    gemm_blockwise_stream_kernel<4, 2><<<grid, kThreads, 0, stream>>>(a);
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }
