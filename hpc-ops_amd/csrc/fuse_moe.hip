@@ -24,6 +24,12 @@ extern "C" int hpc_group_gemm_blockwise_fp8_async(
     int num_block_k_pad4, int tile_m, int64_t xscale_row_stride, int64_t xscale_kb_stride,
     hipStream_t stream);
 
+extern "C" int hpc_group_gemm_pertensor_fp8_async(void* y_ptr, const void* x_ptr, const void* w_ptr,
+                                                  const void* seqlens_ptr, const void* cu_seqlens_ptr,
+                                                  const void* yscale_ptr, const void* row_index_ptr,
+                                                  int num_group, int m, int x_rows, int n, int k,
+                                                  hipStream_t stream);
+
 namespace hpc {
 namespace moe {
 
@@ -188,6 +194,74 @@ __global__ __launch_bounds__(kThreads) void act_mul_blockwise_quant_kernel(
   }
 }
 
+// Per-tensor variant: q = e4m3( silu(gate) * up * scale[0] ); with use_bf16_mul the product is formed
+// in bf16 like the reference kernel (src/activation/activation.cu:19-75, :54-65).
+__global__ __launch_bounds__(kThreads) void act_mul_quant_kernel(
+    const uint16_t* __restrict__ gate_up, const float* __restrict__ scale,
+    const int* __restrict__ num_rows_ptr, int max_rows, int inter, int use_bf16_mul,
+    uint8_t* __restrict__ out) {
+  const int row = blockIdx.y;
+  const int rows = num_rows_ptr ? min(*num_rows_ptr, max_rows) : max_rows;
+  if (row >= rows) return;
+  const int c8 = blockIdx.x * kThreads + threadIdx.x;
+  if (c8 * 8 >= inter) return;
+  const float sc = scale[0];
+  const uint16_t* gp = gate_up + static_cast<long>(row) * 2 * inter;
+  const u32x4 gv = ld16(gp + c8 * 8), uv = ld16(gp + inter + c8 * 8);
+  float a[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float g0 = bf16lo_to_f32(gv[j]), g1 = bf16hi_to_f32(gv[j]);
+    const float u0 = bf16lo_to_f32(uv[j]), u1 = bf16hi_to_f32(uv[j]);
+    float s0 = g0 / (1.0f + __expf(-g0)), s1 = g1 / (1.0f + __expf(-g1));
+    if (use_bf16_mul) {
+      s0 = bf16_to_f32(f32_to_bf16(bf16_to_f32(f32_to_bf16(s0)) * u0));
+      s1 = bf16_to_f32(f32_to_bf16(bf16_to_f32(f32_to_bf16(s1)) * u1));
+    } else {
+      s0 *= u0;
+      s1 *= u1;
+    }
+    a[2 * j] = s0 * sc;
+    a[2 * j + 1] = s1 * sc;
+  }
+  u32x2 q;
+  q[0] = cvt_4xe4m3(a[0], a[1], a[2], a[3]);
+  q[1] = cvt_4xe4m3(a[4], a[5], a[6], a[7]);
+  *reinterpret_cast<u32x2*>(out + static_cast<long>(row) * inter + c8 * 8) = q;
+}
+
+// out = e4m3(float(in) * scale[0])  (reference scaled_fp8_quant, src/activation/activation.cu)
+__global__ __launch_bounds__(kThreads) void scaled_fp8_quant_kernel(const uint16_t* __restrict__ in,
+                                                                    const float* __restrict__ scale,
+                                                                    long n8, uint8_t* __restrict__ out) {
+  const float sc = scale[0];
+  for (long i = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x; i < n8;
+       i += static_cast<long>(gridDim.x) * kThreads) {
+    const u32x4 v = ld16(in + i * 8);
+    u32x2 q;
+    q[0] = cvt_4xe4m3(bf16lo_to_f32(v[0]) * sc, bf16hi_to_f32(v[0]) * sc, bf16lo_to_f32(v[1]) * sc,
+                      bf16hi_to_f32(v[1]) * sc);
+    q[1] = cvt_4xe4m3(bf16lo_to_f32(v[2]) * sc, bf16hi_to_f32(v[2]) * sc, bf16lo_to_f32(v[3]) * sc,
+                      bf16hi_to_f32(v[3]) * sc);
+    *reinterpret_cast<u32x2*>(out + i * 8) = q;
+  }
+}
+
+// rows only (per-tensor count_and_gather): xg[pos] = x[token]
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(const uint8_t* __restrict__ x,
+                                                               const int* __restrict__ topk_pos, int n,
+                                                               int num_topk, int hidden,
+                                                               uint8_t* __restrict__ xg) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  const int pos = topk_pos[i];
+  if (pos < 0) return;
+  const int lane = threadIdx.x & 63;
+  const uint8_t* src = x + static_cast<long>(i / num_topk) * hidden;
+  uint8_t* dst = xg + static_cast<long>(pos) * hidden;
+  for (int c = lane * 16; c < hidden; c += 64 * 16) st16(dst + c, ld16(src + c));
+}
+
 // y[t] = bf16( sum_j topk_scale[t,j] * float(x[topk_pos[t,j]]) + float(shared[t]) ), pos < 0 skipped
 // (reference reduce_kernel, src/fuse_moe/reduce.cu:17-81).
 __global__ __launch_bounds__(kThreads) void reduce_kernel(
@@ -308,6 +382,48 @@ extern "C" int hpc_act_mul_and_blockwise_quant_async(void* out_ptr, void* out_sc
   return HPC_OK;
 }
 
+extern "C" int hpc_act_mul_and_quant_async(void* out_ptr, const void* gate_up_ptr, const void* scale_ptr,
+                                           const void* num_rows_ptr, int max_rows,
+                                           int intermediate_size, int use_bf16_mul, hipStream_t stream) {
+  if (!out_ptr || !gate_up_ptr || !scale_ptr) return HPC_ERR_INVALID;
+  if (intermediate_size <= 0 || (intermediate_size & 7)) return HPC_ERR_UNSUPPORTED;
+  if (max_rows <= 0) return HPC_OK;
+  dim3 grid((intermediate_size / 8 + kThreads - 1) / kThreads, max_rows);
+  act_mul_quant_kernel<<<grid, kThreads, 0, stream>>>(
+      static_cast<const uint16_t*>(gate_up_ptr), static_cast<const float*>(scale_ptr),
+      static_cast<const int*>(num_rows_ptr), max_rows, intermediate_size, use_bf16_mul ? 1 : 0,
+      static_cast<uint8_t*>(out_ptr));
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}
+
+extern "C" int hpc_scaled_fp8_quant_async(void* out_ptr, const void* in_ptr, const void* scale_ptr,
+                                          int64_t numel, hipStream_t stream) {
+  if (!out_ptr || !in_ptr || !scale_ptr) return HPC_ERR_INVALID;
+  if (numel & 7) return HPC_ERR_UNSUPPORTED;
+  if (numel <= 0) return HPC_OK;
+  const long n8 = numel / 8;
+  const int grid = static_cast<int>(n8 / kThreads + 1 < 4096 ? n8 / kThreads + 1 : 4096);
+  scaled_fp8_quant_kernel<<<grid, kThreads, 0, stream>>>(static_cast<const uint16_t*>(in_ptr),
+                                                         static_cast<const float*>(scale_ptr), n8,
+                                                         static_cast<uint8_t*>(out_ptr));
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}
+
+extern "C" int hpc_moe_gather_rows_async(const void* x, const void* topk_pos, int num_tokens,
+                                         int num_topk, int hidden, void* x_gathered, hipStream_t stream) {
+  if (!x || !topk_pos || !x_gathered) return HPC_ERR_INVALID;
+  if (hidden & 15) return HPC_ERR_UNSUPPORTED;
+  const int n = num_tokens * num_topk;
+  if (n <= 0) return HPC_OK;
+  gather_rows_kernel<<<(n + 3) / 4, kThreads, 0, stream>>>(
+      static_cast<const uint8_t*>(x), static_cast<const int*>(topk_pos), n, num_topk, hidden,
+      static_cast<uint8_t*>(x_gathered));
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}
+
 // ---- top-k reduce ------------------------------------------------------------------------------------
 extern "C" int hpc_moe_reduce_async(void* y_ptr, const void* x_ptr, const void* topk_pos_ptr,
                                     const void* topk_scale_ptr, const void* shared_output_ptr,
@@ -403,6 +519,45 @@ extern "C" int hpc_fuse_moe_blockwise_async(
                                           ws + w.seqlens, ws + w.cu_seqlens, ws + w.down_in_scale,
                                           down_weight_scale_ptr, nullptr, nullptr, num_expert, m,
                                           hidden_size, inter, down_ws_pad4, 16, inter / 128, 1, stream);
+  if (rc) return rc;
+  return hpc_moe_reduce_async(y_ptr, ws + w.down_out, ws + w.topk_pos, topk_scale_ptr,
+                              shared_output_ptr, num_tokens, num_topk, hidden_size, stream);
+}
+
+// Per-tensor pipeline (reference fuse_moe_async, src/fuse_moe/fuse_moe.cu:14-60, and the gather-free
+// cp.async pipeline cp_async/fuse_moe.cu:16-63): one fp32 scale per expert on each GEMM, one
+// activation scale.  Same workspace layout as the blockwise pipeline (the scale buffer is unused).
+extern "C" int hpc_fuse_moe_pertensor_async(
+    void* y_ptr, void* workspace, const void* x_ptr, const void* gate_up_weight_ptr,
+    const void* down_weight_ptr, const void* gate_up_scale_ptr, const void* down_scale_ptr,
+    const void* act_and_mul_scale_ptr, const void* topk_ids_ptr, const void* topk_scale_ptr,
+    const void* shared_output_ptr, int num_tokens, int hidden_size, int intermediate_size2,
+    int num_topk, int num_expert, int rank_ep, int use_bf16_mul, hipStream_t stream) {
+  if (!y_ptr || !workspace || !x_ptr || !gate_up_weight_ptr || !down_weight_ptr || !gate_up_scale_ptr ||
+      !down_scale_ptr || !act_and_mul_scale_ptr || !topk_ids_ptr || !topk_scale_ptr)
+    return HPC_ERR_INVALID;
+  if ((hidden_size & 63) || (intermediate_size2 & 127) || num_topk > 128) return HPC_ERR_UNSUPPORTED;
+  if (num_tokens <= 0) return HPC_OK;
+  const int inter = intermediate_size2 / 2;
+  const int m = num_tokens * num_topk;
+  const MoeWs w = moe_ws_layout(num_tokens, num_topk, hidden_size, (intermediate_size2 + 255) / 256 * 256,
+                                num_expert);
+  char* ws = static_cast<char*>(workspace);
+  int rc = hpc_moe_count_and_slot_async(topk_ids_ptr, num_tokens, num_topk, num_expert, rank_ep, 16,
+                                        ws + w.seqlens, ws + w.cu_seqlens, ws + w.tiles,
+                                        ws + w.cu_tiles, ws + w.topk_pos, ws + w.row_index, stream);
+  if (rc) return rc;
+  rc = hpc_group_gemm_pertensor_fp8_async(ws + w.gate_up_out, x_ptr, gate_up_weight_ptr, ws + w.seqlens,
+                                          ws + w.cu_seqlens, gate_up_scale_ptr, ws + w.row_index,
+                                          num_expert, m, num_tokens, intermediate_size2, hidden_size, stream);
+  if (rc) return rc;
+  rc = hpc_act_mul_and_quant_async(ws + w.down_in, ws + w.gate_up_out, act_and_mul_scale_ptr,
+                                   reinterpret_cast<const int*>(ws + w.cu_seqlens) + num_expert, m, inter,
+                                   use_bf16_mul, stream);
+  if (rc) return rc;
+  rc = hpc_group_gemm_pertensor_fp8_async(ws + w.down_out, ws + w.down_in, down_weight_ptr, ws + w.seqlens,
+                                          ws + w.cu_seqlens, down_scale_ptr, nullptr, num_expert, m, m,
+                                          hidden_size, inter, stream);
   if (rc) return rc;
   return hpc_moe_reduce_async(y_ptr, ws + w.down_out, ws + w.topk_pos, topk_scale_ptr,
                               shared_output_ptr, num_tokens, num_topk, hidden_size, stream);

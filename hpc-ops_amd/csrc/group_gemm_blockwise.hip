@@ -31,8 +31,11 @@ struct Args {
   const int* cu_seqlens;  // [G]   first row of group g in y (and in x when row_index == null)
   const int* row_index;   // null, or [M] -> row of x / xs for output row m (gather-free MoE)
   const int* col_base;    // null, or [G] (cu_tiles): transposed xs, column = col_base[g]*tile_m + slot
-  int N, K, KB, ws_ld, tile_m;
-  long xs_row_stride, xs_kb_stride;  // in floats
+  int N, K, KB, tile_m;
+  int ws_group_stride, ws_ntile_stride, ws_kb_stride;  // floats; per-tensor scales: (1, 0, 0)
+  int has_xs;                                           // 0: no activation scales (factor 1)
+  unsigned x_bytes;                                     // bytes of x (bounds the activation loads)
+  long xs_row_stride, xs_kb_stride;                     // in floats
 };
 
 constexpr int kThreads = 256;
@@ -68,14 +71,14 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
   if (m_cnt <= 0) return;
   const int n0 = (blockIdx.x * 4 + wave) * 16 * kR;  // N % 128 == 0 is checked by the launcher
   const int m0 = as_const(a.cu_seqlens)[e];
-  const int K = a.K, KB = a.KB;
+  const int K = a.K, KB = a.KB;  // KB = ceil(K / 128)
   const int nstage = (KB + 1) >> 1;
 
   const uint8_t* wbase = a.w + (static_cast<long>(e) * a.N + n0) * K;
   const unsigned w_bytes = 16u * static_cast<unsigned>(K);
   const int w_voff = r16 * K + g4 * 16;
   const cint_ptr ws_row = as_const(reinterpret_cast<const int*>(a.ws)) +
-                          (static_cast<long>(e) * (a.N >> 7) + (n0 >> 7)) * a.ws_ld;
+                          static_cast<long>(e) * a.ws_group_stride + (n0 >> 7) * a.ws_ntile_stride;
   const int xs_kb_bytes = static_cast<int>(a.xs_kb_stride * 4);
   const long col0 = a.col_base ? static_cast<long>(as_const(a.col_base)[e]) * a.tile_m : 0;
 
@@ -109,24 +112,24 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
     float xsb[kDepth];
     auto issue = [&](int d, int st) {
       const int kb0 = 2 * st;
-      const unsigned on0 = kb0 < KB ? 1u : 0u, on1 = kb0 + 1 < KB ? 1u : 0u;
       const int koff = kb0 * 128;
+      // Weights: whole stage on/off (a descriptor with num_records = 0 fetches nothing).  When K is
+      // not a multiple of 256 the tail of the last stage reads into the next weight row - finite
+      // e4m3 data that meets ZERO activations: the activation loads below are bounded per lane.
+      const unsigned w_on = st < nstage ? w_bytes : 0u;
 #pragma unroll
       for (int rb = 0; rb < kR; ++rb) {
-        const uint8_t* base = wbase + static_cast<long>(rb) * 16 * K;
-        const auto rw0 = make_rsrc(base, on0 ? w_bytes : 0u);
-        const auto rw1 = make_rsrc(base, on1 ? w_bytes : 0u);
-        wb[d][0][rb][0] = buf_ld16<2>(rw0, w_voff, koff);
-        wb[d][0][rb][1] = buf_ld16<2>(rw0, w_voff + 64, koff);
-        wb[d][1][rb][0] = buf_ld16<2>(rw1, w_voff + 128, koff);
-        wb[d][1][rb][1] = buf_ld16<2>(rw1, w_voff + 192, koff);
-      }
-      // activation quarter: a 16-byte chunk of the 256-byte stage slab per lane; chunks 8..15 belong
-      // to the second k-block of the stage
-      const auto rx = make_rsrc(a.x, (r16 < 8 ? on0 : on1) ? 0xffffffffu : 0u);
+        const auto rw = make_rsrc(wbase + static_cast<long>(rb) * 16 * K, w_on);
 #pragma unroll
-      for (int j = 0; j < kMT; ++j) xb[d][j] = buf_ld16<0>(rx, x_voff[j], koff);
-      const auto rs = make_rsrc(a.xs, (xs_role && (wave == 0 ? on0 : on1)) ? 0xffffffffu : 0u);
+        for (int qd = 0; qd < 4; ++qd) wb[d][qd >> 1][rb][qd & 1] = buf_ld16<2>(rw, w_voff + 64 * qd, koff);
+      }
+      // activation quarter: one 16-byte chunk of the 256-byte slab per lane; chunks at k >= K get an
+      // out-of-range offset and read as zero
+      const auto rx = make_rsrc(a.x, a.x_bytes);
+      const bool x_ok = koff + r16 * 16 < K;
+#pragma unroll
+      for (int j = 0; j < kMT; ++j) xb[d][j] = buf_ld16<0>(rx, x_ok ? x_voff[j] : 0xffffff00u, koff);
+      const auto rs = make_rsrc(a.xs, (a.has_xs && xs_role && kb0 + wave < KB) ? 0xffffffffu : 0u);
       xsb[d] = __uint_as_float(
           __builtin_amdgcn_raw_buffer_load_b32(rs, xs_voff, (kb0 + wave) * xs_kb_bytes, 0));
     };
@@ -159,13 +162,13 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
         for (int kbl = 0; kbl < 2; ++kbl) {
           const int kb = 2 * st + kbl;
           const int kbc = kb < KB ? kb : KB - 1;
-          const float wsk = kb < KB ? __int_as_float(ws_row[kbc]) : 0.f;
+          const float wsk = kb < KB ? __int_as_float(ws_row[kbc * a.ws_kb_stride]) : 0.f;
 #pragma unroll
           for (int mt = 0; mt < kMT; ++mt) {
             const uint8_t* xp = &s_x[buf][(mt * 16 + r16) * kXRow + kbl * 128 + g4 * 16];
             const u32x4 b0 = *reinterpret_cast<const u32x4*>(xp);
             const u32x4 b1 = *reinterpret_cast<const u32x4*>(xp + 64);
-            const float f = s_xs[buf][kbl][mt * 16 + r16] * wsk;
+            const float f = a.has_xs ? s_xs[buf][kbl][mt * 16 + r16] * wsk : wsk;
 #pragma unroll
             for (int rb = 0; rb < kR; ++rb) {
               f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -208,6 +211,29 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
 }  // namespace ggemm
 }  // namespace hpc
 
+namespace {
+int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, hipStream_t stream) {
+  using namespace hpc::ggemm;
+  // tokens served per pass over the weights, from the average group size (the reference picks its
+  // tileM the same way, fuse_moe/entry.cc:525-543); larger groups take several passes
+  const int avg = m / num_group;
+  const int forced = hpc_tuning_get(1);
+  const int mt = forced ? forced : (avg <= 10 ? 1 : 2);  // 64 tokens/pass (mt 4) is experimental: register-bound
+  // 64 tokens per pass needs the whole register file of a SIMD (1 workgroup per CU, 32 rows per
+  // wave); 16 / 32 tokens run 2 workgroups per CU with 16 rows per wave
+  const int r = (mt == 4 && n % 128 == 0) ? 2 : 1;
+  dim3 grid(n / (64 * r), num_group);
+  if (mt == 1)
+    gemm_blockwise_stream_kernel<1, 1><<<grid, kThreads, 0, stream>>>(a);
+  else if (mt == 2 || r == 1)
+    gemm_blockwise_stream_kernel<2, 1><<<grid, kThreads, 0, stream>>>(a);
+  else
+    gemm_blockwise_stream_kernel<4, 2><<<grid, kThreads, 0, stream>>>(a);
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}
+}  // namespace
+
 extern "C" int hpc_group_gemm_blockwise_fp8_async(
     void* y_ptr, const void* x_ptr, const void* w_ptr, const void* seqlens_ptr,
     const void* cu_seqlens_ptr, const void* xscale_ptr, const void* wscale_ptr,
@@ -221,7 +247,7 @@ extern "C" int hpc_group_gemm_blockwise_fp8_async(
   if (m <= 0) return HPC_OK;
   if ((n & 127) || (k & 127)) return HPC_ERR_UNSUPPORTED;  // 128x128 weight scale blocks
   if (num_block_k_pad4 < k / 128) return HPC_ERR_INVALID;
-  if (static_cast<int64_t>(m) * k > 0xffffffffll) return HPC_ERR_UNSUPPORTED;  // 32-bit x offsets
+  if (static_cast<int64_t>(m) * k > 0xfffffe00ll) return HPC_ERR_UNSUPPORTED;  // 32-bit x offsets
   Args a;
   a.x = static_cast<const uint8_t*>(x_ptr);
   a.w = static_cast<const uint8_t*>(w_ptr);
@@ -235,27 +261,52 @@ extern "C" int hpc_group_gemm_blockwise_fp8_async(
   a.N = n;
   a.K = k;
   a.KB = k / 128;
-  a.ws_ld = num_block_k_pad4;
   a.tile_m = tile_m;
+  a.ws_group_stride = (n / 128) * num_block_k_pad4;
+  a.ws_ntile_stride = num_block_k_pad4;
+  a.ws_kb_stride = 1;
+  a.has_xs = 1;
+  a.x_bytes = 0xfffffe00u;  // x may be indexed through row_index: rows beyond m exist (< 4 GB checked)
   a.xs_row_stride = xscale_row_stride;
   a.xs_kb_stride = xscale_kb_stride;
-  const int forced_r = hpc_tuning_get(2);
-  // tokens served per pass over the weights, from the average group size (the reference picks its
-  // tileM the same way, fuse_moe/entry.cc:525-543); larger groups take several passes
-  const int avg = m / num_group;
-  const int forced = hpc_tuning_get(1);
-  const int mt = forced ? forced : (avg <= 10 ? 1 : 2);  // 64 tokens/pass (mt 4) is experimental: register-bound
-  // 64 tokens per pass needs the whole register file of a SIMD (1 workgroup per CU, 32 rows per
-  // wave); 16 / 32 tokens run 2 workgroups per CU with 16 rows per wave
-  (void)forced_r;
-  const int r = mt == 4 ? 2 : 1;
-  dim3 grid(n / (64 * r), num_group);
-  if (mt == 1)
-    gemm_blockwise_stream_kernel<1, 1><<<grid, kThreads, 0, stream>>>(a);
-  else if (mt == 2)
-    gemm_blockwise_stream_kernel<2, 1><<<grid, kThreads, 0, stream>>>(a);
-  else
-    gemm_blockwise_stream_kernel<4, 2><<<grid, kThreads, 0, stream>>>(a);
-  HPC_CHECK_LAUNCH();
-  return HPC_OK;
+  return launch_stream_gemm(a, num_group, m, n, stream);
+}
+
+// Per-tensor variant: Y = bf16( (X W^T) * y_scale[g] ), no activation scales.
+// reference: group_gemm_fp8_async / group_gemm_pertensor_fp8 (src/group_gemm/group_gemm.h,
+// kernels.cuh:215-530) and the gather-free cp.async path (cp_async/group_gemm_fp8_scatter.cu).
+// n % 64 == 0, k % 64 == 0.
+extern "C" int hpc_group_gemm_pertensor_fp8_async(void* y_ptr, const void* x_ptr, const void* w_ptr,
+                                                  const void* seqlens_ptr, const void* cu_seqlens_ptr,
+                                                  const void* yscale_ptr, const void* row_index_ptr,
+                                                  int num_group, int m, int x_rows, int n, int k,
+                                                  hipStream_t stream) {
+  using namespace hpc::ggemm;
+  if (!y_ptr || !x_ptr || !w_ptr || !seqlens_ptr || !cu_seqlens_ptr || !yscale_ptr) return HPC_ERR_INVALID;
+  if (num_group <= 0 || n <= 0 || k <= 0 || x_rows <= 0) return HPC_ERR_INVALID;
+  if (m <= 0) return HPC_OK;
+  if ((n & 63) || (k & 63)) return HPC_ERR_UNSUPPORTED;
+  if (static_cast<int64_t>(x_rows) * k > 0xfffffe00ll) return HPC_ERR_UNSUPPORTED;
+  Args a;
+  a.x = static_cast<const uint8_t*>(x_ptr);
+  a.w = static_cast<const uint8_t*>(w_ptr);
+  a.xs = static_cast<const float*>(yscale_ptr);  // unused (has_xs = 0), any valid pointer
+  a.ws = static_cast<const float*>(yscale_ptr);
+  a.y = static_cast<uint16_t*>(y_ptr);
+  a.seqlens = static_cast<const int*>(seqlens_ptr);
+  a.cu_seqlens = static_cast<const int*>(cu_seqlens_ptr);
+  a.row_index = static_cast<const int*>(row_index_ptr);
+  a.col_base = nullptr;
+  a.N = n;
+  a.K = k;
+  a.KB = (k + 127) / 128;
+  a.tile_m = 16;
+  a.ws_group_stride = 1;
+  a.ws_ntile_stride = 0;
+  a.ws_kb_stride = 0;
+  a.has_xs = 0;
+  a.x_bytes = static_cast<unsigned>(static_cast<int64_t>(x_rows) * k);
+  a.xs_row_stride = 0;
+  a.xs_kb_stride = 0;
+  return launch_stream_gemm(a, num_group, m, n, stream);
 }

@@ -160,3 +160,172 @@ def _group_gemm_blockwise_fp8_entry(x, weight, seqlens, cu_seqlens, x_scale, w_s
 
 
 _T.impl("group_gemm_blockwise_fp8", _group_gemm_blockwise_fp8_entry, "CUDA")
+
+
+# ---- per-tensor FP8 path (reference src/fuse_moe/entry.cc:18-443, src/group_gemm/entry.cc:14-89,
+#      src/activation/entry.cc) ---------------------------------------------------------------------------
+_T.define(
+    "fuse_moe(Tensor x, Tensor gate_up_weight, Tensor down_weight, Tensor gate_up_scale, "
+    "Tensor down_scale, Tensor act_and_mul_scale, Tensor topk_ids, Tensor topk_scale, Tensor ? "
+    "shared_output, int rank_ep, int num_expert_total, bool use_bf16_mul, Tensor ? output) -> (Tensor)"
+)
+_T.define(
+    "fuse_moe_pertensor_fp8(Tensor x, Tensor gate_up_weight, Tensor down_weight, Tensor "
+    "gate_up_scale, Tensor down_scale, Tensor act_and_mul_scale, Tensor topk_ids, Tensor "
+    "topk_scale, Tensor ? shared_output, int rank_ep, int num_expert_total, bool use_bf16_mul, "
+    "Tensor ? output) -> (Tensor)"
+)
+_T.define(
+    "count_and_gather(Tensor x, Tensor topk_ids, int num_expert, int rank_ep, int "
+    "intermediate_size, int num_seq_per_group_avg) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, "
+    "Tensor, Tensor, Tensor)"
+)
+_T.define(
+    "group_gemm_fp8(Tensor x, Tensor weight, Tensor seqlens, Tensor cu_seqlens, Tensor y_scale, "
+    "int num_seq_per_group_avg, Tensor? output, Tensor? tma_desc, Tensor? task_map_workspace) -> (Tensor)"
+)
+_T.define(
+    "group_gemm_pertensor_fp8(Tensor x, Tensor weight, Tensor seqlens, Tensor cu_seqlens, Tensor y_scale, "
+    "int num_seq_per_group_avg, Tensor? output, Tensor? tma_desc, Tensor? task_map_workspace) -> (Tensor)"
+)
+_T.define("act_mul_and_quant(Tensor gate_up, Tensor scale, bool use_bf16_mul, Tensor? output) -> (Tensor)")
+_T.define("scaled_fp8_quant(Tensor input, Tensor? scale, Tensor? output) -> (Tensor)")
+
+
+def _fuse_moe_entry(x, gate_up_weight, down_weight, gate_up_scale, down_scale, act_and_mul_scale,
+                    topk_ids, topk_scale, shared_output, rank_ep, num_expert_total, use_bf16_mul, output):
+    _C.require(x.dtype == _F8 and gate_up_weight.dtype == _F8 and down_weight.dtype == _F8,
+               "x, gate_up_weight and down_weight dtype must be fp8_e4m3")
+    _C.require(topk_ids.dtype == torch.int32, "topk_ids dtype must be int32")
+    _C.require(gate_up_scale.dtype == torch.float32 and down_scale.dtype == torch.float32
+               and act_and_mul_scale.dtype == torch.float32 and topk_scale.dtype == torch.float32,
+               "gate_up_scale, down_scale, act_and_mul_scale and topk_scale dtype must be float32")
+    for t, n in ((x, "x"), (gate_up_weight, "gate_up_weight"), (gate_up_scale, "gate_up_scale"),
+                 (down_weight, "down_weight"), (down_scale, "down_scale"), (topk_ids, "topk_ids"),
+                 (topk_scale, "topk_scale"), (act_and_mul_scale, "act_and_mul_scale")):
+        _cuda_contig(t, n)
+    _C.require(x.size(0) == topk_ids.size(0), "x and topk_ids must share the same num_seq")
+    _C.require(topk_ids.shape == topk_scale.shape, "topk_ids and topk_scale must share the same shape")
+    _C.require(x.size(1) == gate_up_weight.size(2), "x and weight must share the same k")
+    _C.require(gate_up_weight.size(0) == down_weight.size(0),
+               "gate_up_weight and down_weight must share the same num_expert")
+    num_tokens, hidden = x.shape
+    num_experts, inter2 = gate_up_weight.size(0), gate_up_weight.size(1)
+    num_topk = topk_ids.size(1)
+    _C.require(num_topk <= 128, "num_topk must less than or equal to 128")
+    _C.require(gate_up_scale.numel() >= num_experts and down_scale.numel() >= num_experts,
+               "one scale per local expert is required")
+    if shared_output is not None:
+        _cuda_contig(shared_output, "shared_output")
+        _C.require(shared_output.dtype == torch.bfloat16, "shared_output tensor dtype must be bfloat16")
+        _C.require(tuple(shared_output.shape) == (num_tokens, hidden),
+                   "shared_output tensor shape must be same as x tensor")
+    if output is not None:
+        _C.require(tuple(output.shape) == (num_tokens, hidden) and output.dtype == torch.bfloat16
+                   and output.is_cuda, "output must be a cuda bfloat16 [num_tokens, hidden_size] tensor")
+        y = output
+    else:
+        y = torch.empty((num_tokens, hidden), dtype=torch.bfloat16, device=x.device)
+    nbytes = _C.lib.hpc_fuse_moe_blockwise_workspace_bytes(num_tokens, num_topk, hidden,
+                                                           (inter2 + 255) // 256 * 256, num_experts)
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=x.device)
+    rc = _C.lib.hpc_fuse_moe_pertensor_async(
+        _C.ptr(y), _C.ptr(ws), _C.ptr(x), _C.ptr(gate_up_weight), _C.ptr(down_weight),
+        _C.ptr(gate_up_scale), _C.ptr(down_scale), _C.ptr(act_and_mul_scale), _C.ptr(topk_ids),
+        _C.ptr(topk_scale), _C.ptr(shared_output), num_tokens, hidden, inter2, num_topk, num_experts,
+        int(rank_ep), int(bool(use_bf16_mul)), _C.stream_of(x))
+    _C.check(rc, "fuse_moe_async")
+    return y
+
+
+_T.impl("fuse_moe", _fuse_moe_entry, "CUDA")
+_T.impl("fuse_moe_pertensor_fp8", _fuse_moe_entry, "CUDA")
+
+
+def _count_and_gather_entry(x, topk_ids, num_expert, rank_ep, intermediate_size, num_seq_per_group_avg):
+    _cuda_contig(x, "x")
+    _cuda_contig(topk_ids, "topk_ids")
+    _C.require(x.size(0) == topk_ids.size(0), "x and topk_ids must share the same k")
+    _C.require(topk_ids.dtype == torch.int32 and x.element_size() == 1, "x must be fp8, topk_ids int32")
+    num_seq, hidden = x.shape
+    num_topk = topk_ids.size(1)
+    dev = x.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    gate_up_input = torch.empty((num_seq * num_topk, hidden), dtype=x.dtype, device=dev)
+    gate_up_output = torch.empty((num_seq * num_topk, intermediate_size), dtype=torch.bfloat16, device=dev)
+    topk_pos = torch.empty((num_seq, num_topk), **i32)
+    seqlens = torch.zeros(num_expert, **i32)
+    cu_seqlens = torch.empty(num_expert + 1, **i32)
+    tiles = torch.empty(num_expert, **i32)
+    cu_tiles = torch.empty(num_expert + 1, **i32)
+    row_index = torch.empty(num_seq * num_topk, **i32)
+    tmas = torch.empty((num_expert * 2, 128), dtype=torch.int8, device=dev)  # unused: no TMA on gfx950
+    tile_m = aligned_size(int(num_seq_per_group_avg))
+    s = _C.stream_of(x)
+    _C.check(_C.lib.hpc_moe_count_and_slot_async(
+        _C.ptr(topk_ids), num_seq, num_topk, int(num_expert), int(rank_ep), tile_m, _C.ptr(seqlens),
+        _C.ptr(cu_seqlens), _C.ptr(tiles), _C.ptr(cu_tiles), _C.ptr(topk_pos), _C.ptr(row_index), s),
+        "count_and_gather_async")
+    _C.check(_C.lib.hpc_moe_gather_rows_async(_C.ptr(x), _C.ptr(topk_pos), num_seq, num_topk, hidden,
+                                              _C.ptr(gate_up_input), s), "count_and_gather_async")
+    return (gate_up_input, gate_up_output, topk_pos, seqlens, cu_seqlens, tiles, cu_tiles, tmas, tmas.clone())
+
+
+_T.impl("count_and_gather", _count_and_gather_entry, "CUDA")
+
+
+def _group_gemm_fp8_entry(x, weight, seqlens, cu_seqlens, y_scale, num_seq_per_group_avg, output,
+                          tma_desc, task_map_workspace):
+    for t, n in ((x, "x"), (weight, "weight"), (seqlens, "seqlens"), (cu_seqlens, "cu_seqlens"),
+                 (y_scale, "y_scale")):
+        _C.require(t.is_cuda, f"{n} tensor must be cuda")
+    _C.require(x.is_contiguous() and weight.is_contiguous(), "x / weight tensor must be contiguous")
+    _C.require(x.dtype == _F8 and weight.dtype == _F8, "x and weight dtype must be fp8_e4m3")
+    _C.require(seqlens.dtype == torch.int32 and cu_seqlens.dtype == torch.int32,
+               "seqlens and cu_seqlens dtype must be int32")
+    _C.require(y_scale.dtype == torch.float32 and y_scale.numel() >= weight.size(0),
+               "y_scale must be float32 [num_group]")
+    _C.require(seqlens.size(0) == weight.size(0), "seqlens and weight must share the same num_group")
+    _C.require(x.size(1) == weight.size(2), "x and weight must share the same k")
+    m, k = x.shape
+    n, num_group = weight.size(1), seqlens.size(0)
+    y = output if output is not None else torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
+    rc = _C.lib.hpc_group_gemm_pertensor_fp8_async(
+        _C.ptr(y), _C.ptr(x), _C.ptr(weight), _C.ptr(seqlens), _C.ptr(cu_seqlens), _C.ptr(y_scale), None,
+        num_group, m, m, n, k, _C.stream_of(x))
+    _C.check(rc, "group_gemm_fp8_async")
+    return y
+
+
+_T.impl("group_gemm_fp8", _group_gemm_fp8_entry, "CUDA")
+_T.impl("group_gemm_pertensor_fp8", _group_gemm_fp8_entry, "CUDA")
+
+
+def _act_mul_and_quant_entry(gate_up, scale, use_bf16_mul, output):
+    _cuda_contig(gate_up, "gate_up")
+    _C.require(gate_up.dtype == torch.bfloat16 and gate_up.dim() == 2, "gate_up must be bfloat16 [N, 2*C]")
+    _C.require(scale.is_cuda and scale.dtype == torch.float32, "scale must be a cuda float32 tensor")
+    rows, inter = gate_up.size(0), gate_up.size(1) // 2
+    out = output if output is not None else torch.empty((rows, inter), dtype=_F8, device=gate_up.device)
+    rc = _C.lib.hpc_act_mul_and_quant_async(_C.ptr(out), _C.ptr(gate_up), _C.ptr(scale), None, rows, inter,
+                                            int(bool(use_bf16_mul)), _C.stream_of(gate_up))
+    _C.check(rc, "act_mul_and_quant_async")
+    return out
+
+
+_T.impl("act_mul_and_quant", _act_mul_and_quant_entry, "CUDA")
+
+
+def _scaled_fp8_quant_entry(input, scale, output):
+    _cuda_contig(input, "input")
+    _C.require(input.dtype == torch.bfloat16, "input must be bfloat16")
+    if scale is None:
+        scale = torch.ones(1, dtype=torch.float32, device=input.device)
+    out = output if output is not None else torch.empty(input.shape, dtype=_F8, device=input.device)
+    rc = _C.lib.hpc_scaled_fp8_quant_async(_C.ptr(out), _C.ptr(input), _C.ptr(scale), input.numel(),
+                                           _C.stream_of(input))
+    _C.check(rc, "scaled_fp8_quant_async")
+    return out
+
+
+_T.impl("scaled_fp8_quant", _scaled_fp8_quant_entry, "CUDA")

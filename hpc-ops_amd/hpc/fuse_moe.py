@@ -78,3 +78,47 @@ def fuse_moe_blockwise_fake(x, x_scale, gate_up_weight, gate_up_weight_scale, do
                             down_weight_scale, topk_ids, topk_scale, shared_output, rank_ep,
                             num_expert_total, output):
     return torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+
+
+def count_and_gather(x: Tensor, topk_ids: Tensor, num_expert: int, rank_ep: int, intermediate_size: int,
+                     num_seq_per_group_avg: int):
+    """Sort tokens by expert (reference hpc/fuse_moe.py:8-85).  Returns (gathered x [T*k, H],
+    group-GEMM output buffer [T*k, intermediate_size] bf16, topk_pos [T, k], seqlens [E], cu_seqlens
+    [E+1], tiles [E], cu_tiles [E+1], and two unused TMA-descriptor placeholders).  Slotting is the
+    deterministic arrival order of the reference tests' oracle."""
+    return torch.ops.hpc.count_and_gather(x, topk_ids, num_expert, rank_ep, intermediate_size,
+                                          num_seq_per_group_avg)
+
+
+def fuse_moe(x: Tensor, gate_up_weight: Tensor, down_weight: Tensor, gate_up_scale: Tensor,
+             down_scale: Tensor, act_and_mul_scale: Tensor, topk_ids: Tensor, topk_scale: Tensor,
+             rank_ep: int, num_expert_total: int, use_bf16_mul: bool = True, shared_output: Tensor = None,
+             output: Tensor = None) -> Tensor:
+    """Run per-tensor FP8 FusedMoE (reference hpc/fuse_moe.py:136-166): one fp32 scale per local
+    expert for each GEMM and one activation scale; hidden % 64 == 0, intermediate % 64 == 0."""
+    return torch.ops.hpc.fuse_moe(x, gate_up_weight, down_weight, gate_up_scale, down_scale,
+                                  act_and_mul_scale, topk_ids, topk_scale, shared_output, rank_ep,
+                                  num_expert_total, use_bf16_mul, output)
+
+
+def fuse_moe_pertensor_fp8(x: Tensor, gate_up_weight: Tensor, down_weight: Tensor, gate_up_scale: Tensor,
+                           down_scale: Tensor, act_and_mul_scale: Tensor, topk_ids: Tensor,
+                           topk_scale: Tensor, rank_ep: int, num_expert_total: int,
+                           use_bf16_mul: bool = True, shared_output: Tensor = None) -> Tensor:
+    """Run per-tensor FP8 FusedMoE (reference hpc/fuse_moe.py:169-199)."""
+    return torch.ops.hpc.fuse_moe_pertensor_fp8(x, gate_up_weight, down_weight, gate_up_scale, down_scale,
+                                                act_and_mul_scale, topk_ids, topk_scale, shared_output,
+                                                rank_ep, num_expert_total, use_bf16_mul, None)
+
+
+@torch.library.register_fake("hpc::fuse_moe")
+def fuse_moe_fake(x, gate_up_weight, down_weight, gate_up_scale, down_scale, act_and_mul_scale, topk_ids,
+                  topk_scale, shared_output, rank_ep, num_expert_total, use_bf16_mul, output):
+    return torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+
+
+@torch.library.register_fake("hpc::fuse_moe_pertensor_fp8")
+def fuse_moe_pertensor_fp8_fake(x, gate_up_weight, down_weight, gate_up_scale, down_scale,
+                                act_and_mul_scale, topk_ids, topk_scale, shared_output, rank_ep,
+                                num_expert_total, use_bf16_mul, output):
+    return torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)

@@ -35,3 +35,20 @@ def group_gemm_blockwise_fp8(
 def group_gemm_blockwise_fp8_fake(x, weight, seqlens, cu_seqlens, x_scale, w_scale,
                                   num_seq_per_group_avg, output, tma_desc, task_map_workspace):
     return torch.empty((x.shape[0], weight.shape[1]), dtype=torch.bfloat16, device=x.device)
+
+
+def group_gemm_pertensor_fp8(x: Tensor, weight: Tensor, seqlens: Tensor, cu_seqlens: Tensor,
+                             y_scale: Tensor, num_seq_per_group_avg: int = 32, output: Tensor = None,
+                             tma_desc: Tensor = None, task_map_workspace: Tensor = None) -> Tensor:
+    """Grouped GEMM, FP8 operands, one fp32 output scale per group (reference hpc/group_gemm.py:51-107):
+    y[rows of g] = bf16((x @ weight[g].T) * y_scale[g]).  N % 64 == 0, K % 64 == 0."""
+    return torch.ops.hpc.group_gemm_pertensor_fp8(x, weight, seqlens, cu_seqlens, y_scale,
+                                                  num_seq_per_group_avg, output, tma_desc, task_map_workspace)
+
+
+def group_gemm_fp8(x: Tensor, weight: Tensor, seqlens: Tensor, cu_seqlens: Tensor, y_scale: Tensor,
+                   num_seq_per_group_avg: int = 32, output: Tensor = None, tma_desc: Tensor = None,
+                   task_map_workspace: Tensor = None) -> Tensor:
+    """Alias kept by the reference (hpc/group_gemm.py:110-131)."""
+    return torch.ops.hpc.group_gemm_fp8(x, weight, seqlens, cu_seqlens, y_scale, num_seq_per_group_avg,
+                                        output, tma_desc, task_map_workspace)

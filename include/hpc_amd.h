@@ -187,6 +187,32 @@ int hpc_fuse_moe_blockwise_async(void* y_ptr, void* workspace, const void* x_ptr
                                  int gate_up_ws_pad4, int down_ws_pad4, int rank_ep,
                                  hpc_stream_t stream);
 
+/* Per-tensor FP8 MoE pieces (reference src/fuse_moe/fuse_moe.h:15-40 fuse_moe_async, src/group_gemm/
+ * group_gemm.h group_gemm_fp8_async, src/activation/activation.h act_mul_and_quant_async /
+ * scaled_fp8_quant_async, cp.async pipeline src/fuse_moe/cp_async/fuse_moe.cu:16-63):
+ * Y = bf16((X W^T) * y_scale[g]); n % 64 == 0, k % 64 == 0; x_rows = rows of x (bounds the loads when
+ * row_index is used).  act: out = e4m3(silu(gate) * up * scale[0]) with the bf16-rounded multiply of
+ * the reference when use_bf16_mul.  The fused per-tensor pipeline uses the same workspace size as the
+ * blockwise one (hpc_fuse_moe_blockwise_workspace_bytes with intermediate_size2 rounded up to 256). */
+int hpc_group_gemm_pertensor_fp8_async(void* y_ptr, const void* x_ptr, const void* w_ptr,
+                                       const void* seqlens_ptr, const void* cu_seqlens_ptr,
+                                       const void* yscale_ptr, const void* row_index_ptr, int num_group,
+                                       int m, int x_rows, int n, int k, hpc_stream_t stream);
+int hpc_act_mul_and_quant_async(void* out_ptr, const void* gate_up_ptr, const void* scale_ptr,
+                                const void* num_rows_ptr, int max_rows, int intermediate_size,
+                                int use_bf16_mul, hpc_stream_t stream);
+int hpc_scaled_fp8_quant_async(void* out_ptr, const void* in_ptr, const void* scale_ptr, int64_t numel,
+                               hpc_stream_t stream);
+int hpc_moe_gather_rows_async(const void* x, const void* topk_pos, int num_tokens, int num_topk,
+                              int hidden, void* x_gathered, hpc_stream_t stream);
+int hpc_fuse_moe_pertensor_async(void* y_ptr, void* workspace, const void* x_ptr,
+                                 const void* gate_up_weight_ptr, const void* down_weight_ptr,
+                                 const void* gate_up_scale_ptr, const void* down_scale_ptr,
+                                 const void* act_and_mul_scale_ptr, const void* topk_ids_ptr,
+                                 const void* topk_scale_ptr, const void* shared_output_ptr,
+                                 int num_tokens, int hidden_size, int intermediate_size2, int num_topk,
+                                 int num_expert, int rank_ep, int use_bf16_mul, hpc_stream_t stream);
+
 /* ---- communicator: socket rendezvous + symmetric device buffers (HIP IPC over xGMI) ---------------
  * reference: src/communicator/{communicator,channel,listener,connector,protocol}.cc (rank-0 star over
  *            an abstract unix socket "unix://name" / bare name, or "tcp://ip:port"),

@@ -98,3 +98,38 @@ def fuse_moe_blockwise_fp8(x, x_scale, gate_up_weight, gate_up_weight_scale, dow
         return y, dict(topk_pos=topk_pos, seqlens=seqlens, cu_seqlens=cu, gate_up=g, down_in=di,
                        down_in_scale=dis, down_out=d)
     return y
+
+
+# ---- per-tensor path: reference tests/test_fuse_moe_pertensor.py:73-160, test_fuse_moe_cp_async.py:65-143,
+#      test_act.py:20-29, test_group_gemm_pertensor.py:20-48 ------------------------------------------------
+def group_gemm_pertensor(x, w, seqlens, cu_seqlens, scale):
+    m, _ = x.shape
+    num_group, n, _ = w.shape
+    y = torch.zeros((m, n), dtype=torch.bfloat16)
+    for i in range(num_group):
+        s, cnt = int(cu_seqlens[i]), int(seqlens[i])
+        if cnt == 0:
+            continue
+        y[s : s + cnt] = ((x[s : s + cnt].float() @ w[i].float().t()) * scale[i].float()).to(torch.bfloat16)
+    return y
+
+
+def act_mul_and_quant(gate_up, scale, use_bf16_mul=True):
+    gate, up = torch.chunk(gate_up.float(), 2, dim=1)
+    silu = gate / (1 + (-gate).exp())
+    if use_bf16_mul:
+        out = (silu.to(torch.bfloat16) * up.to(torch.bfloat16)).float() * scale
+    else:
+        out = silu * up * scale
+    return out.to(torch.float8_e4m3fn)
+
+
+def fuse_moe_pertensor_fp8(x, gate_up_weight, down_weight, gate_up_scale, down_scale, act_and_mul_scale,
+                           topk_ids, topk_scale, rank_ep, shared_output=None, use_bf16_mul=True):
+    num_expert = gate_up_weight.size(0)
+    dummy = torch.zeros(x.shape[0], 1)
+    gi, _, topk_pos, seqlens, cu = gather_expert_inputs(x, dummy, topk_ids, num_expert, rank_ep)
+    g = group_gemm_pertensor(gi, gate_up_weight, seqlens, cu, gate_up_scale)
+    di = act_mul_and_quant(g, act_and_mul_scale, use_bf16_mul)
+    d = group_gemm_pertensor(di, down_weight, seqlens, cu, down_scale)
+    return reduce(d, topk_pos, topk_scale, shared_output)

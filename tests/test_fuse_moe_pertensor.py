@@ -1,0 +1,104 @@
+"""Parity of the per-tensor FP8 MoE surface (fuse_moe, fuse_moe_pertensor_fp8, count_and_gather,
+group_gemm_pertensor_fp8, act_mul_and_quant, scaled_fp8_quant) with the CPU oracle; generators and
+tolerances follow reference tests/test_fuse_moe_pertensor.py:162-223 (rtol 0.08, atol 0.1),
+tests/test_fuse_moe_cp_async.py:145-242 (I = 192, H = 4096), tests/test_group_gemm_pertensor.py:52-77
+and tests/test_act.py:45-59."""
+import pytest
+import torch
+
+from utils import allclose
+
+F8 = torch.float8_e4m3fn
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_seq,hidden,inter,num_expert", [(128, 512, 512, 128), (64, 4096, 192, 192),
+                                                             (5, 512, 256, 16)])
+@pytest.mark.parametrize("rank_ep,size_ep", [(0, 1), (1, 4)])
+@pytest.mark.parametrize("shared", [False, True])
+@pytest.mark.parametrize("use_bf16_mul", [False, True])
+def test_fuse_moe_pertensor(num_seq, hidden, inter, num_expert, rank_ep, size_ep, shared, use_bf16_mul):
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(41)
+    k = 8
+    ids = torch.sort(torch.randint(0, num_expert, (num_seq, k), dtype=torch.int32), dim=1)[0]
+    x = (torch.randn((num_seq, hidden)) / 100).to(F8)
+    el = num_expert // size_ep
+    guw = torch.randn((el, inter * 2, hidden)).to(F8)
+    dw = torch.randn((el, hidden, inter)).to(F8)
+    gus, ds, ams = torch.randn(el), torch.randn(el), torch.randn(1)
+    sc = torch.randn((num_seq, k)) / k
+    so = torch.randn((num_seq, hidden), dtype=torch.bfloat16) if shared else None
+    gt = omoe.fuse_moe_pertensor_fp8(x, guw, dw, gus, ds, ams, ids, sc, rank_ep, so, use_bf16_mul)
+    c = lambda t: None if t is None else t.cuda()  # noqa: E731
+    my = hpc.fuse_moe_pertensor_fp8(c(x), c(guw), c(dw), c(gus), c(ds), c(ams), c(ids), c(sc), rank_ep, el,
+                                    use_bf16_mul=use_bf16_mul, shared_output=c(so))
+    out = torch.empty_like(my)
+    my2 = hpc.fuse_moe(c(x), c(guw), c(dw), c(gus), c(ds), c(ams), c(ids), c(sc), rank_ep, el,
+                       use_bf16_mul=use_bf16_mul, shared_output=c(so), output=out)
+    torch.cuda.synchronize()
+    assert allclose(gt.float(), my.cpu().float(), rtol=0.08, atol=0.1)
+    assert my2.data_ptr() == out.data_ptr() and torch.equal(my2, my)
+
+
+@pytest.mark.gpu
+def test_count_and_gather_bit_exact():
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(2)
+    T, k, E, rank, el, H = 77, 8, 64, 1, 16, 256
+    ids = torch.sort(torch.randint(0, E, (T, k), dtype=torch.int32), dim=1)[0]
+    x = torch.randn(T, H).to(F8)
+    xg_ref, _, pos_ref, cnt_ref, cu_ref = omoe.gather_expert_inputs(x, torch.zeros(T, 1), ids, el, rank)
+    xg, g_out, pos, seqlens, cu, tiles, cu_tiles, _, _ = hpc.count_and_gather(x.cuda(), ids.cuda(), el, rank, 512, 8)
+    torch.cuda.synchronize()
+    assert g_out.shape == (T * k, 512) and g_out.dtype == torch.bfloat16
+    assert torch.equal(pos.cpu(), pos_ref) and torch.equal(seqlens.cpu(), cnt_ref) and torch.equal(cu.cpu(), cu_ref)
+    total = int(cu_ref[-1])
+    assert torch.equal(xg.cpu().view(torch.uint8)[:total], xg_ref.view(torch.uint8)[:total])
+    assert torch.equal(tiles.cpu(), (cnt_ref + 7) // 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("actual_m", [8, 30, 70])
+def test_group_gemm_pertensor(actual_m):
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(0)
+    G, n, k = 8, 1024, 1792
+    seqlens = torch.full((G,), actual_m, dtype=torch.int32)
+    seqlens[2] = 0
+    total = int(seqlens.sum())
+    x = torch.randn((total, k)).to(F8)
+    w = torch.randn((G, n, k)).to(F8)
+    scale = torch.rand(G) + 0.5
+    cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
+    gt = omoe.group_gemm_pertensor(x, w, seqlens, cu, scale)
+    my = hpc.group_gemm_pertensor_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), scale.cuda(),
+                                      num_seq_per_group_avg=actual_m)
+    torch.cuda.synchronize()
+    assert allclose(gt.float(), my.cpu().float(), rtol=0.08, atol=0.5)  # |y| ~ 40: bf16 rounding
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_bf16_mul", [True, False])
+def test_act_mul_and_quant(use_bf16_mul):
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(0)
+    gate_up = torch.randn((513, 4608 * 2), dtype=torch.bfloat16)
+    scale = torch.rand(1) + 1.0
+    gt = omoe.act_mul_and_quant(gate_up, scale, use_bf16_mul)
+    out = hpc.act_mul_and_quant(gate_up.cuda(), scale.cuda(), use_bf16_mul=use_bf16_mul)
+    torch.cuda.synchronize()
+    # fp8 results: allow one e4m3 rounding step (exp / reciprocal differ by an ulp from torch's)
+    assert allclose(gt.float(), out.cpu().float(), rtol=0.13, atol=2e-3)
+    agree = (gt.view(torch.uint8) == out.cpu().view(torch.uint8)).float().mean().item()
+    assert agree > 0.995, agree
+    q = hpc.scaled_fp8_quant(gate_up.cuda(), scale.cuda())
+    assert torch.equal(q.cpu().view(torch.uint8), (gate_up.float() * scale).to(F8).view(torch.uint8))
