@@ -80,11 +80,22 @@ def cpu_baseline(q, k_cache, v_cache, block_ids, kv_lens, w, sample_requests=4):
     }
 
 
-def timed(fn, iters=30, warm=5):
-    """median microseconds per call from events on the current stream"""
+def timed(fn, iters=30, warm=5, graph=False):
+    """median microseconds per call from events on the current stream (optionally replaying a
+    hipGraph of one call, the reference benchmarks' method)"""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
+    if graph:
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            fn = g.replay
+            fn()
+            torch.cuda.synchronize()
+        except Exception:  # noqa: BLE001
+            pass
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
     ev[0].record()
     for i in range(iters):
@@ -176,6 +187,79 @@ def extra_moe(dev, hpc, tokens=(16, 64, 256)):
                         "weight_GBps": round(wbytes / us / 1e3, 1),
                         "hbm_frac_of_8TBps": round(wbytes / us / 1e3 / HBM_PEAK_GBPS, 4), "experts_hit": hit}
     return {"fuse_moe_blockwise_fp8_E64_top8_H4096_I11008": res}
+
+
+def _ar_child(rank, world, local_rank, name, q):
+    """Fused AllReduce+residual+RMSNorm (BASELINE configs[4], H=8192) in a child process per rank so
+    that a failure on an untested fabric cannot take the headline measurement down with it."""
+    try:
+        import hpc
+
+        dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(dev)
+        comm = hpc.MulticastCommunicator(rank, world, local_rank, name)
+        H, res = 8192, {}
+        w = torch.randn(H, dtype=torch.bfloat16, device=dev)
+        for mode, T in (("ll", 32), ("ll", 512), ("ht", 512), ("ht", 4096)):
+            Tp = (T + world - 1) // world * world
+            residual = torch.randn(Tp, H, dtype=torch.bfloat16, device=dev)
+            x = torch.randn(Tp, H, dtype=torch.bfloat16, device=dev)
+            if mode == "ll":
+                M = 2 * math.ceil(T / world) * world * 3
+                ws_buf, hdl = hpc.empty_multimem(comm, [M, H], dtype=torch.bfloat16, device=dev)
+                ws_buf.view(torch.int32).fill_(-(2 ** 31))
+                mc = hdl.get_multimem_buff([M, H], dtype=torch.bfloat16)
+                flags = torch.tensor([0, 2, (M * H * 2 // 3) // 16 * 16, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=dev)
+                out, out_res = torch.empty_like(x[:T]), torch.empty_like(x[:T])
+                xin, rin = x[:T].contiguous(), residual[:T].contiguous()
+
+                def call():
+                    hpc.fuse_allreduce_rmsnorm_low_latency(xin, mc, hdl.data_buffer_ptrs_dev, ws_buf, flags, world,
+                                                           rank, rin, w, 1e-6, 16, out, out_res, True)
+            else:
+                in_x, in_hdl = hpc.empty_multimem(comm, [Tp, H], dtype=torch.bfloat16, device=dev)
+                out_x, out_hdl = hpc.empty_multimem(comm, [Tp, H], dtype=torch.bfloat16, device=dev)
+                in_x.copy_(x)
+                out_res = torch.empty_like(residual)
+                a, b = Tp // world * rank, Tp // world * (rank + 1)
+                off = a * H * 2
+                mi = in_hdl.get_multimem_buff(in_x[a:b].shape, dtype=in_x.dtype, storage_offset=off)
+                mo = out_hdl.get_multimem_buff(out_x[a:b].shape, dtype=out_x.dtype, storage_offset=off)
+
+                def call():
+                    hpc.fuse_allreduce_rmsnorm_high_throughput(in_x[a:b], mi, residual[a:b], w, 1e-6,
+                                                               in_hdl.signal_buffer_ptrs_dev, rank, world, 64,
+                                                               out_x[a:b], mo, out_res[a:b])
+            torch.cuda.synchronize()
+            comm.Barrier()
+            us = timed(call, iters=20, warm=3, graph=True)
+            comm.Barrier()
+            msg = T * H * 2
+            bw = (2 * (world - 1) / world * msg if world > 1 else 4 * msg) / us / 1e3
+            res[f"{mode}_T{T}"] = {"us": round(us, 1), ("busbw_GBps" if world > 1 else "hbm_GBps"): round(bw, 1)}
+        from hpc import _C
+        res["spin_timeouts"] = _C.lib.hpc_allreduce_timeouts()
+        q.put((rank, res))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, {"error": repr(e)[:300]}))
+
+
+def extra_allreduce(rank, world, local_rank):
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = f"bench_ar_{os.environ.get('MASTER_PORT', '0')}_{world}"
+    p = ctx.Process(target=_ar_child, args=(rank, world, local_rank, name, q))
+    p.start()
+    try:
+        _, res = q.get(timeout=240)
+    except Exception:  # noqa: BLE001
+        res = {"error": "timeout"}
+    p.join(timeout=20)
+    if p.is_alive():
+        p.kill()
+    return {f"fuse_allreduce_rmsnorm_bf16_H8192_ws{world}": res}
 
 
 def main():
@@ -273,6 +357,13 @@ def main():
                 extras[fn.__name__] = {"error": repr(e)[:200]}
             torch.cuda.empty_cache()
         graph = None if args.no_graph else True
+
+    if not args.no_extras:
+        try:  # every rank takes part (one child process per rank); rank 0 reports
+            ar = extra_allreduce(rank, world, local_rank)
+        except Exception as e:  # noqa: BLE001
+            ar = {"fuse_allreduce_rmsnorm": {"error": repr(e)[:200]}}
+        extras.update(ar)
 
     if rank == 0:
         nbytes = algorithmic_bytes(w)

@@ -363,8 +363,14 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_high_throughput_async(
   a.hidden = hidden_size;
   a.rank = rank;
   a.ws = world_size;
-  // every rank must launch the same grid: the barriers pair block b with block b of each peer
-  ht_kernel<<<num_max_blocks, kThreads, 0, stream>>>(a);
+  // Every rank must launch the same grid: the barriers pair block b with block b of each peer, so
+  // the grid is a pure function of (rows, num_max_blocks).  One row is only 2*hidden bytes per
+  // peer, so a 78-block grid (the reference's SM-count-sized default) is latency-bound on MI355X:
+  // use at least 2 workgroups per CU worth of rows; the signal pad (72 * CUs words) bounds it.
+  int grid = num_max_blocks > 512 ? num_max_blocks : 512;
+  if (grid > num_rows) grid = num_rows > 0 ? num_rows : 1;
+  if (grid * world_size > 72 * 256) grid = 72 * 256 / world_size;
+  ht_kernel<<<grid, kThreads, 0, stream>>>(a);
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }
