@@ -21,10 +21,13 @@ def _case(num_batch, num_seq_q, lens_before, block_size, kv_head_q_head, k_per_t
     total_blocks = int(nblocks.sum())
     max_num_blocks = int(total_blocks * 1.2) + 4
     scale_rows = block_size * 4 // D if k_per_token else 0
+    gen_dev = "cuda" if torch.cuda.is_available() else "cpu"
     if k_per_token:
-        kv = torch.randn(max_num_blocks, 2, block_size + scale_rows, num_head_kv, D, dtype=torch.bfloat16)
+        kv = torch.randn(max_num_blocks, 2, block_size + scale_rows, num_head_kv, D, dtype=torch.bfloat16,
+                         device=gen_dev).cpu()
     else:
-        kv = torch.randn(max_num_blocks, 2, block_size, num_head_kv, D, dtype=torch.bfloat16) / math.sqrt(D)
+        kv = (torch.randn(max_num_blocks, 2, block_size, num_head_kv, D, dtype=torch.bfloat16, device=gen_dev)
+              / math.sqrt(D)).cpu()
     packed = torch.randperm(max_num_blocks)[:total_blocks].to(torch.int32)
     block_ids = torch.full((num_batch, int(nblocks.max())), -999999, dtype=torch.int32)
     cu = 0
@@ -84,13 +87,13 @@ def _run(num_batch, num_seq_q, lens_before, block_size, kv_head_q_head, k_per_to
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("num_batch", [1, 16, 50])
-@pytest.mark.parametrize("num_seq_q", [1, 2, 3, 4])
+@pytest.mark.parametrize("num_seq_q", [1, 2, 4])
 @pytest.mark.parametrize("kv_head_q_head", [(1, 8), (4, 32)])
 @pytest.mark.parametrize("use_dynamic_sched", [True, False])
 @pytest.mark.parametrize("kvcache_shape", ["NHD", "HND"])
 def test_attn_fp8_kvpertensor(num_batch, num_seq_q, kv_head_q_head, use_dynamic_sched, kvcache_shape):
     torch.manual_seed(41)
-    max_seq_kv = 1024 if num_batch > 16 else 4096
+    max_seq_kv = 1024 if num_batch >= 16 else 4096
     lens = torch.randint(1, max_seq_kv, (num_batch,), dtype=torch.int32)
     _run(num_batch, num_seq_q, lens, 64, kv_head_q_head, False, True, use_dynamic_sched,
          kvcache_shape, 0.2)
