@@ -61,6 +61,10 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
   constexpr int kTok = 16 * kMT;
   __shared__ __attribute__((aligned(16))) uint8_t s_x[2][kTok * kXRow];
   __shared__ float s_xs[2][2][kTok];
+  // wave-private 16-row x 256-byte weight tile (double-buffered): weights are fetched with full-row
+  // loads (16 lanes x 16 B per row segment - the access shape that streams fastest, see
+  // attention_decode.hip) and reach the MFMA A-operand layout through this tile; no barrier needed.
+  __shared__ __attribute__((aligned(16))) uint8_t s_w[4][2][16 * kXRow];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
 
   const uint8_t* wbase = a.w + (static_cast<long>(e) * a.N + n0) * K;
   const unsigned w_bytes = 16u * static_cast<unsigned>(K);
-  const int w_voff = r16 * K + g4 * 16;
+  const int w_voff = g4 * K + r16 * 16;  // lane -> (row 4*qd + g4, 16-byte chunk r16) of the stage slab
   const cint_ptr ws_row = as_const(reinterpret_cast<const int*>(a.ws)) +
                           static_cast<long>(e) * a.ws_group_stride + (n0 >> 7) * a.ws_ntile_stride;
   const int xs_kb_bytes = static_cast<int>(a.xs_kb_stride * 4);
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
       for (int rb = 0; rb < kR; ++rb) {
         const auto rw = make_rsrc(wbase + static_cast<long>(rb) * 16 * K, w_on);
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) wb[d][qd >> 1][rb][qd & 1] = buf_ld16<2>(rw, w_voff + 64 * qd, koff);
+        for (int qd = 0; qd < 4; ++qd) wb[d][qd >> 1][rb][qd & 1] = buf_ld16<2>(rw, w_voff, koff + qd * 4 * K);
       }
       // activation quarter: one 16-byte chunk of the 256-byte slab per lane; chunks at k >= K get an
       // out-of-range offset and read as zero
@@ -157,6 +161,20 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
         for (int j = 0; j < kMT; ++j)
           *reinterpret_cast<u32x4*>(&s_x[buf][x_lds[j]]) = xb[d][j];
         if (xs_role) s_xs[buf][wave][lane] = xsb[d];
+        // weights: full-row layout -> MFMA A-operand layout (lane (r16, g4): row r16, chunk kbl*8+h*4+g4)
+        u32x4 wf[kR][2][2];
+#pragma unroll
+        for (int rb = 0; rb < kR; ++rb) {
+          uint8_t* wt = s_w[wave][(rb + d) & 1];
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd)
+            *reinterpret_cast<u32x4*>(wt + (4 * qd + g4) * kXRow + r16 * 16) = wb[d][qd >> 1][rb][qd & 1];
+#pragma unroll
+          for (int kbl = 0; kbl < 2; ++kbl)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              wf[rb][kbl][h] = *reinterpret_cast<const u32x4*>(wt + r16 * kXRow + (kbl * 8 + h * 4 + g4) * 16);
+        }
         __syncthreads();
 #pragma unroll
         for (int kbl = 0; kbl < 2; ++kbl) {
@@ -173,13 +191,13 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
             for (int rb = 0; rb < kR; ++rb) {
               f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
               part = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                  pack64(wb[d][kbl][rb][0][0], wb[d][kbl][rb][0][1]), pack64(b0[0], b0[1]), part, 0, 0, 0);
+                  pack64(wf[rb][kbl][0][0], wf[rb][kbl][0][1]), pack64(b0[0], b0[1]), part, 0, 0, 0);
               part = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                  pack64(wb[d][kbl][rb][0][2], wb[d][kbl][rb][0][3]), pack64(b0[2], b0[3]), part, 0, 0, 0);
+                  pack64(wf[rb][kbl][0][2], wf[rb][kbl][0][3]), pack64(b0[2], b0[3]), part, 0, 0, 0);
               part = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                  pack64(wb[d][kbl][rb][1][0], wb[d][kbl][rb][1][1]), pack64(b1[0], b1[1]), part, 0, 0, 0);
+                  pack64(wf[rb][kbl][1][0], wf[rb][kbl][1][1]), pack64(b1[0], b1[1]), part, 0, 0, 0);
               part = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                  pack64(wb[d][kbl][rb][1][2], wb[d][kbl][rb][1][3]), pack64(b1[2], b1[3]), part, 0, 0, 0);
+                  pack64(wf[rb][kbl][1][2], wf[rb][kbl][1][3]), pack64(b1[2], b1[3]), part, 0, 0, 0);
 #pragma unroll
               for (int i = 0; i < 4; ++i) tot[rb][mt][i] = fmaf(part[i], f, tot[rb][mt][i]);
             }
