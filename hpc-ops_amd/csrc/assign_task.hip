@@ -69,8 +69,9 @@ __host__ __device__ inline int next_task_overflow(const Plan& p, int h, int b, i
   return imin(seqkv - p.num_seq_q, 0);
 }
 
-// Plans bin `ibin`: writes its (per + 1) records and returns the number of tasks.
-__host__ __device__ inline int plan_bin(const Plan& p, int ibin, int* bin_ptr) {
+// Plans bin `ibin`: writes its task records and returns the number of tasks.  The terminators of
+// the unused slots are written by the caller (host: plan_bin; device: 8 lanes per bin).
+__host__ __device__ inline int plan_bin_tasks(const Plan& p, int ibin, int* bin_ptr) {
   const long grand = static_cast<long>(p.total) * p.num_head_kv;
   long g = static_cast<long>(ibin) * p.per;
   const long end = g + p.per < grand ? g + p.per : grand;
@@ -118,6 +119,11 @@ __host__ __device__ inline int plan_bin(const Plan& p, int ibin, int* bin_ptr) {
       }
     }
   }
+  return itask;
+}
+
+__host__ __device__ inline int plan_bin(const Plan& p, int ibin, int* bin_ptr) {
+  const int itask = plan_bin_tasks(p, ibin, bin_ptr);
   for (int slot = itask; slot <= p.per; ++slot) {  // terminators in every unused slot
     bin_ptr[slot * kTaskStride] = -1;
     bin_ptr[slot * kTaskStride + 1] = -1;
@@ -135,7 +141,9 @@ __host__ __device__ inline int chunks_of(const Plan& p, int h, int b) {
 namespace {
 
 constexpr int kMaxBatch = 4096;
-constexpr int kThreads = 64;  // one wave per workgroup, one lane per bin
+constexpr int kThreads = 64;      // one wave per workgroup
+constexpr int kLanesPerBin = 8;   // lane 0 of each group plans the bin, all 8 write its terminators
+constexpr int kBinsPerWg = kThreads / kLanesPerBin;
 
 __global__ __launch_bounds__(kThreads) void assign_task_kernel(
     int* __restrict__ task_map, const int* __restrict__ num_seq_kvcache, int num_batch,
@@ -187,10 +195,23 @@ __global__ __launch_bounds__(kThreads) void assign_task_kernel(
   int* chunk_tab = task_map + chunk_table_off(p.per, num_bins);
   int* tasks_per_bin = chunk_tab + pad12(max_batch * num_head_kv) + pad12(num_bins);
 
-  const int ibin = blockIdx.x * kThreads + lane;
+  // The layout demands a terminator in every unused slot (tiles_per_bin + 1 records per bin, 48 B
+  // apart): spread that over 8 lanes per bin and 8 bins per workgroup so the scattered stores of
+  // all bins proceed in parallel across the chip.
+  const int ibin = blockIdx.x * kBinsPerWg + lane / kLanesPerBin;
+  const int sub = lane % kLanesPerBin;
+  int* bin_ptr = task_map + static_cast<long>(kTaskStride) * (1 + static_cast<long>(ibin) * (p.per + 1));
+  int itask = 0;
+  if (ibin < num_bins && sub == 0) {
+    itask = plan_bin_tasks(p, ibin, bin_ptr);
+    tasks_per_bin[ibin] = itask;
+  }
+  itask = __shfl(itask, lane - sub, 64);
   if (ibin < num_bins) {
-    int* bin_ptr = task_map + static_cast<long>(kTaskStride) * (1 + static_cast<long>(ibin) * (p.per + 1));
-    tasks_per_bin[ibin] = plan_bin(p, ibin, bin_ptr);
+    for (int slot = itask + sub; slot <= p.per; slot += kLanesPerBin) {
+      bin_ptr[slot * kTaskStride] = -1;
+      bin_ptr[slot * kTaskStride + 1] = -1;
+    }
   }
 
   if (blockIdx.x == 0) {  // header + chunk table (closed form, no atomics)
@@ -300,7 +321,7 @@ extern "C" int hpc_assign_attention_decode_task_async(int* task_map, const int* 
   if (num_batch <= 0 || num_batch > kMaxBatch) return HPC_ERR_UNSUPPORTED;
   if (num_seq_q < 1 || num_seq_q > kMaxSeqQ || num_head_kv <= 0 || num_total_ctas <= 0)
     return HPC_ERR_INVALID;
-  const int grid = (num_total_ctas + kThreads - 1) / kThreads;
+  const int grid = (num_total_ctas + kBinsPerWg - 1) / kBinsPerWg;
   assign_task_kernel<<<grid, kThreads, 0, stream>>>(task_map, num_seq_kvcache, num_batch,
                                                     num_head_kv, num_seq_q, new_kv_included ? 1 : 0,
                                                     min_process_len, num_total_ctas);
