@@ -159,7 +159,7 @@ def extra_decode(dev, hpc):
     return out
 
 
-def extra_moe(dev, hpc, tokens=(16, 64, 256)):
+def extra_moe(dev, hpc, tokens=(16, 64, 256, 4096)):
     """fused MoE FP8 blockwise, BASELINE configs[3]: 64 experts top-8, hidden 4096, ffn 11008."""
     E, k, H, I = 64, 8, 4096, 11008
     torch.manual_seed(41)
@@ -184,6 +184,7 @@ def extra_moe(dev, hpc, tokens=(16, 64, 256)):
         wbytes = hit * (2 * I * H + H * I)
         flops = 2.0 * T * k * (2 * I * H + H * I)
         res[f"T{T}"] = {"us": round(us, 1), "TFLOPS": round(flops / us / 1e6, 2),
+                        "mfma_frac_of_2.5PF": round(flops / us / 1e6 / 2500.0, 4),
                         "weight_GBps": round(wbytes / us / 1e3, 1),
                         "hbm_frac_of_8TBps": round(wbytes / us / 1e3 / HBM_PEAK_GBPS, 4), "experts_hit": hit}
     return {"fuse_moe_blockwise_fp8_E64_top8_H4096_I11008": res}

@@ -22,13 +22,13 @@ extern "C" int hpc_group_gemm_blockwise_fp8_async(
     const void* cu_seqlens_ptr, const void* xscale_ptr, const void* wscale_ptr,
     const void* row_index_ptr, const void* col_base_ptr, int num_group, int m, int n, int k,
     int num_block_k_pad4, int tile_m, int64_t xscale_row_stride, int64_t xscale_kb_stride,
-    hipStream_t stream);
+    const void* cu_tiles128_ptr, hipStream_t stream);
 
 extern "C" int hpc_group_gemm_pertensor_fp8_async(void* y_ptr, const void* x_ptr, const void* w_ptr,
                                                   const void* seqlens_ptr, const void* cu_seqlens_ptr,
                                                   const void* yscale_ptr, const void* row_index_ptr,
                                                   int num_group, int m, int x_rows, int n, int k,
-                                                  hipStream_t stream);
+                                                  const void* cu_tiles128_ptr, hipStream_t stream);
 
 namespace hpc {
 namespace moe {
@@ -499,7 +499,7 @@ extern "C" int hpc_fuse_moe_blockwise_async(
   const int m = num_tokens * num_topk;
   const MoeWs w = moe_ws_layout(num_tokens, num_topk, hidden_size, intermediate_size2, num_expert);
   char* ws = static_cast<char*>(workspace);
-  int rc = hpc_moe_count_and_slot_async(topk_ids_ptr, num_tokens, num_topk, num_expert, rank_ep, 16,
+  int rc = hpc_moe_count_and_slot_async(topk_ids_ptr, num_tokens, num_topk, num_expert, rank_ep, 128,
                                         ws + w.seqlens, ws + w.cu_seqlens, ws + w.tiles,
                                         ws + w.cu_tiles, ws + w.topk_pos, ws + w.row_index, stream);
   if (rc) return rc;
@@ -508,7 +508,7 @@ extern "C" int hpc_fuse_moe_blockwise_async(
                                           ws + w.seqlens, ws + w.cu_seqlens, x_scale_ptr,
                                           gate_up_weight_scale_ptr, ws + w.row_index, nullptr,
                                           num_expert, m, intermediate_size2, hidden_size,
-                                          gate_up_ws_pad4, 16, hidden_size / 128, 1, stream);
+                                          gate_up_ws_pad4, 16, hidden_size / 128, 1, ws + w.cu_tiles, stream);
   if (rc) return rc;
   rc = hpc_act_mul_and_blockwise_quant_async(
       ws + w.down_in, ws + w.down_in_scale, ws + w.gate_up_out,
@@ -518,7 +518,8 @@ extern "C" int hpc_fuse_moe_blockwise_async(
   rc = hpc_group_gemm_blockwise_fp8_async(ws + w.down_out, ws + w.down_in, down_weight_ptr,
                                           ws + w.seqlens, ws + w.cu_seqlens, ws + w.down_in_scale,
                                           down_weight_scale_ptr, nullptr, nullptr, num_expert, m,
-                                          hidden_size, inter, down_ws_pad4, 16, inter / 128, 1, stream);
+                                          hidden_size, inter, down_ws_pad4, 16, inter / 128, 1,
+                                          ws + w.cu_tiles, stream);
   if (rc) return rc;
   return hpc_moe_reduce_async(y_ptr, ws + w.down_out, ws + w.topk_pos, topk_scale_ptr,
                               shared_output_ptr, num_tokens, num_topk, hidden_size, stream);
@@ -543,13 +544,14 @@ extern "C" int hpc_fuse_moe_pertensor_async(
   const MoeWs w = moe_ws_layout(num_tokens, num_topk, hidden_size, (intermediate_size2 + 255) / 256 * 256,
                                 num_expert);
   char* ws = static_cast<char*>(workspace);
-  int rc = hpc_moe_count_and_slot_async(topk_ids_ptr, num_tokens, num_topk, num_expert, rank_ep, 16,
+  int rc = hpc_moe_count_and_slot_async(topk_ids_ptr, num_tokens, num_topk, num_expert, rank_ep, 128,
                                         ws + w.seqlens, ws + w.cu_seqlens, ws + w.tiles,
                                         ws + w.cu_tiles, ws + w.topk_pos, ws + w.row_index, stream);
   if (rc) return rc;
   rc = hpc_group_gemm_pertensor_fp8_async(ws + w.gate_up_out, x_ptr, gate_up_weight_ptr, ws + w.seqlens,
                                           ws + w.cu_seqlens, gate_up_scale_ptr, ws + w.row_index,
-                                          num_expert, m, num_tokens, intermediate_size2, hidden_size, stream);
+                                          num_expert, m, num_tokens, intermediate_size2, hidden_size,
+                                          ws + w.cu_tiles, stream);
   if (rc) return rc;
   rc = hpc_act_mul_and_quant_async(ws + w.down_in, ws + w.gate_up_out, act_and_mul_scale_ptr,
                                    reinterpret_cast<const int*>(ws + w.cu_seqlens) + num_expert, m, inter,
@@ -557,7 +559,7 @@ extern "C" int hpc_fuse_moe_pertensor_async(
   if (rc) return rc;
   rc = hpc_group_gemm_pertensor_fp8_async(ws + w.down_out, ws + w.down_in, down_weight_ptr, ws + w.seqlens,
                                           ws + w.cu_seqlens, down_scale_ptr, nullptr, num_expert, m, m,
-                                          hidden_size, inter, stream);
+                                          hidden_size, inter, ws + w.cu_tiles, stream);
   if (rc) return rc;
   return hpc_moe_reduce_async(y_ptr, ws + w.down_out, ws + w.topk_pos, topk_scale_ptr,
                               shared_output_ptr, num_tokens, num_topk, hidden_size, stream);

@@ -1,0 +1,31 @@
+// Shared argument block of the grouped FP8 GEMM kernels (streaming form: group_gemm_blockwise.hip,
+// tiled form: group_gemm_tiled.hip).
+#pragma once
+#include <stdint.h>
+
+namespace hpc {
+namespace ggemm {
+
+struct Args {
+  const uint8_t* x;       // [rows, K] e4m3
+  const uint8_t* w;       // [G, N, K] e4m3
+  const float* xs;        // activation scales, see xs_row_stride / xs_kb_stride
+  const float* ws;        // [G, N/128, ws_ld]
+  uint16_t* y;            // [M, N] bf16
+  const int* seqlens;     // [G]
+  const int* cu_seqlens;  // [G]   first row of group g in y (and in x when row_index == null)
+  const int* row_index;   // null, or [M] -> row of x / xs for output row m (gather-free MoE)
+  const int* col_base;    // null, or [G] (cu_tiles): transposed xs, column = col_base[g]*tile_m + slot
+  int N, K, KB, tile_m;
+  int ws_group_stride, ws_ntile_stride, ws_kb_stride;  // floats; per-tensor scales: (1, 0, 0)
+  int has_xs;                                           // 0: no activation scales (factor 1)
+  unsigned x_bytes;                                     // bytes of x (bounds the activation loads)
+  long xs_row_stride, xs_kb_stride;                     // in floats
+};
+
+}  // namespace ggemm
+}  // namespace hpc
+
+// tiled (MFMA-bound) form for large groups; `cu_tiles` = exclusive scan of ceil(seqlens / 128).
+int hpc_ggemm_launch_tiled(const hpc::ggemm::Args& a, const int* cu_tiles, int num_group, int m, int n,
+                           hipStream_t stream);

@@ -17,26 +17,12 @@
 // kernels.cuh:806-836).
 #include "hpc_common.h"
 #include "../../include/hpc_amd.h"
+#include "group_gemm.h"
 
 namespace hpc {
 namespace ggemm {
 
-struct Args {
-  const uint8_t* x;       // [rows, K] e4m3
-  const uint8_t* w;       // [G, N, K] e4m3
-  const float* xs;        // activation scales, see xs_row_stride / xs_kb_stride
-  const float* ws;        // [G, N/128, ws_ld]
-  uint16_t* y;            // [M, N] bf16
-  const int* seqlens;     // [G]
-  const int* cu_seqlens;  // [G]   first row of group g in y (and in x when row_index == null)
-  const int* row_index;   // null, or [M] -> row of x / xs for output row m (gather-free MoE)
-  const int* col_base;    // null, or [G] (cu_tiles): transposed xs, column = col_base[g]*tile_m + slot
-  int N, K, KB, tile_m;
-  int ws_group_stride, ws_ntile_stride, ws_kb_stride;  // floats; per-tensor scales: (1, 0, 0)
-  int has_xs;                                           // 0: no activation scales (factor 1)
-  unsigned x_bytes;                                     // bytes of x (bounds the activation loads)
-  long xs_row_stride, xs_kb_stride;                     // in floats
-};
+
 
 constexpr int kThreads = 256;
 constexpr int kDepth = 4;     // stages in flight per wave; one stage = 2 k-blocks = 256 B per weight row
@@ -230,8 +216,13 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
 }  // namespace hpc
 
 namespace {
-int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, hipStream_t stream) {
+int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const void* cu_tiles128,
+                       hipStream_t stream) {
   using namespace hpc::ggemm;
+  // large groups: MFMA-bound 128x128-tile kernel (needs the scan of ceil(seqlens/128))
+  const int tiled_mode = hpc_tuning_get(3);  // 0 auto, 1 never, 2 always (when possible)
+  if (cu_tiles128 && n % 128 == 0 && tiled_mode != 1 && (tiled_mode == 2 || m / num_group > 32))
+    return hpc_ggemm_launch_tiled(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);
   // tokens served per pass over the weights, from the average group size (the reference picks its
   // tileM the same way, fuse_moe/entry.cc:525-543); larger groups take several passes
   const int avg = m / num_group;
@@ -257,7 +248,7 @@ extern "C" int hpc_group_gemm_blockwise_fp8_async(
     const void* cu_seqlens_ptr, const void* xscale_ptr, const void* wscale_ptr,
     const void* row_index_ptr, const void* col_base_ptr, int num_group, int m, int n, int k,
     int num_block_k_pad4, int tile_m, int64_t xscale_row_stride, int64_t xscale_kb_stride,
-    hipStream_t stream) {
+    const void* cu_tiles128_ptr, hipStream_t stream) {
   using namespace hpc::ggemm;
   if (!y_ptr || !x_ptr || !w_ptr || !seqlens_ptr || !cu_seqlens_ptr || !xscale_ptr || !wscale_ptr)
     return HPC_ERR_INVALID;
@@ -287,7 +278,7 @@ extern "C" int hpc_group_gemm_blockwise_fp8_async(
   a.x_bytes = 0xfffffe00u;  // x may be indexed through row_index: rows beyond m exist (< 4 GB checked)
   a.xs_row_stride = xscale_row_stride;
   a.xs_kb_stride = xscale_kb_stride;
-  return launch_stream_gemm(a, num_group, m, n, stream);
+  return launch_stream_gemm(a, num_group, m, n, cu_tiles128_ptr, stream);
 }
 
 // Per-tensor variant: Y = bf16( (X W^T) * y_scale[g] ), no activation scales.
@@ -298,7 +289,7 @@ extern "C" int hpc_group_gemm_pertensor_fp8_async(void* y_ptr, const void* x_ptr
                                                   const void* seqlens_ptr, const void* cu_seqlens_ptr,
                                                   const void* yscale_ptr, const void* row_index_ptr,
                                                   int num_group, int m, int x_rows, int n, int k,
-                                                  hipStream_t stream) {
+                                                  const void* cu_tiles128_ptr, hipStream_t stream) {
   using namespace hpc::ggemm;
   if (!y_ptr || !x_ptr || !w_ptr || !seqlens_ptr || !cu_seqlens_ptr || !yscale_ptr) return HPC_ERR_INVALID;
   if (num_group <= 0 || n <= 0 || k <= 0 || x_rows <= 0) return HPC_ERR_INVALID;
@@ -326,5 +317,5 @@ extern "C" int hpc_group_gemm_pertensor_fp8_async(void* y_ptr, const void* x_ptr
   a.x_bytes = static_cast<unsigned>(static_cast<int64_t>(x_rows) * k);
   a.xs_row_stride = 0;
   a.xs_kb_stride = 0;
-  return launch_stream_gemm(a, num_group, m, n, stream);
+  return launch_stream_gemm(a, num_group, m, n, cu_tiles128_ptr, stream);
 }

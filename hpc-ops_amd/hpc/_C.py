@@ -55,7 +55,7 @@ _sig("hpc_attention_decode_bf16_async", I, P, P, IP, P, P, P, IP, I, I, I, I, I,
 _sig("hpc_attention_decode_fp8_async", I, P, P, IP, P, P, P, IP, P, P, P, I, I, I, I, I, I, I, I, I, I,
      I, I, I, L, L, L, L, L, L, L, L, L, P)
 
-_sig("hpc_group_gemm_blockwise_fp8_async", I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, P)
+_sig("hpc_group_gemm_blockwise_fp8_async", I, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, L, L, P, P)
 _sig("hpc_moe_count_and_slot_async", I, P, I, I, I, I, I, P, P, P, P, P, P, P)
 _sig("hpc_moe_tiles_async", I, P, I, I, P, P, P)
 _sig("hpc_moe_gather_blockwise_async", I, P, P, P, P, P, P, I, I, I, I, I, I, I, P, P, P)
@@ -64,7 +64,7 @@ _sig("hpc_moe_reduce_async", I, P, P, P, P, P, I, I, I, P)
 _sig("hpc_fuse_moe_blockwise_workspace_bytes", L, I, I, I, I, I)
 _sig("hpc_fuse_moe_blockwise_async", I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, P)
 
-_sig("hpc_group_gemm_pertensor_fp8_async", I, P, P, P, P, P, P, P, I, I, I, I, I, P)
+_sig("hpc_group_gemm_pertensor_fp8_async", I, P, P, P, P, P, P, P, I, I, I, I, I, P, P)
 _sig("hpc_act_mul_and_quant_async", I, P, P, P, P, I, I, I, P)
 _sig("hpc_scaled_fp8_quant_async", I, P, P, P, L, P)
 _sig("hpc_moe_gather_rows_async", I, P, P, I, I, I, P, P)

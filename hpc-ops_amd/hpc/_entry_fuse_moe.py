@@ -39,6 +39,17 @@ def aligned_size(avg: int) -> int:
     return 64
 
 
+def _cu_tiles128(seqlens, m, num_group, stream):
+    """Scan of ceil(seqlens/128) for the tiled (large-group) GEMM kernel; None keeps the streaming one."""
+    if m // max(num_group, 1) <= 32:
+        return None
+    tiles = torch.empty(num_group, dtype=torch.int32, device=seqlens.device)
+    cu = torch.empty(num_group + 1, dtype=torch.int32, device=seqlens.device)
+    _C.check(_C.lib.hpc_moe_tiles_async(_C.ptr(seqlens), num_group, 128, _C.ptr(tiles), _C.ptr(cu), stream),
+             "group_gemm tiles")
+    return _C.ptr(cu)
+
+
 def _cuda_contig(t, name):
     _C.require(t.is_cuda, f"{name} tensor must be cuda")
     _C.require(t.is_contiguous(), f"{name} tensor must be contiguous")
@@ -154,7 +165,7 @@ def _group_gemm_blockwise_fp8_entry(x, weight, seqlens, cu_seqlens, x_scale, w_s
     rc = _C.lib.hpc_group_gemm_blockwise_fp8_async(
         _C.ptr(y), _C.ptr(x), _C.ptr(weight), _C.ptr(seqlens), _C.ptr(cu_seqlens), _C.ptr(x_scale),
         _C.ptr(w_scale), None, _C.ptr(cu_tiles), num_group, m, n, k, w_scale.size(2), tile_m, 1,
-        m_pad, s)
+        m_pad, _cu_tiles128(seqlens, m, num_group, s), s)
     _C.check(rc, "group_gemm_blockwise_fp8_async")
     return y
 
@@ -290,9 +301,10 @@ def _group_gemm_fp8_entry(x, weight, seqlens, cu_seqlens, y_scale, num_seq_per_g
     m, k = x.shape
     n, num_group = weight.size(1), seqlens.size(0)
     y = output if output is not None else torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
+    s = _C.stream_of(x)
     rc = _C.lib.hpc_group_gemm_pertensor_fp8_async(
         _C.ptr(y), _C.ptr(x), _C.ptr(weight), _C.ptr(seqlens), _C.ptr(cu_seqlens), _C.ptr(y_scale), None,
-        num_group, m, m, n, k, _C.stream_of(x))
+        num_group, m, m, n, k, _cu_tiles128(seqlens, m, num_group, s), s)
     _C.check(rc, "group_gemm_fp8_async")
     return y
 

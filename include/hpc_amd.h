@@ -132,14 +132,18 @@ int hpc_attention_decode_fp8_async(void* y_ptr, void* workspace, const int* task
  * xs addressing in floats: xs[term * xscale_row_stride + kb * xscale_kb_stride] with
  *   term = row(m)                       when col_base == NULL  (row-major [rows, k/128]: strides k/128, 1)
  *   term = col_base[g]*tile_m + slot    when col_base != NULL  (reference layout [k/128, m_pad],
- *                                        col_base = cu_tiles: strides 1, m_pad). */
+ *                                        col_base = cu_tiles: strides 1, m_pad).
+ * cu_tiles128_ptr (nullable): exclusive scan of ceil(seqlens/128), [G+1] (hpc_moe_tiles_async with
+ * tile_m = 128); when given and groups are large (> 32 rows on average) the MFMA-bound 128x128-tile
+ * kernel is used instead of the weight-streaming one. */
 int hpc_group_gemm_blockwise_fp8_async(void* y_ptr, const void* x_ptr, const void* w_ptr,
                                        const void* seqlens_ptr, const void* cu_seqlens_ptr,
                                        const void* xscale_ptr, const void* wscale_ptr,
                                        const void* row_index_ptr, const void* col_base_ptr,
                                        int num_group, int m, int n, int k, int num_block_k_pad4,
                                        int tile_m, int64_t xscale_row_stride,
-                                       int64_t xscale_kb_stride, hpc_stream_t stream);
+                                       int64_t xscale_kb_stride, const void* cu_tiles128_ptr,
+                                       hpc_stream_t stream);
 
 /* ---- fused MoE pieces ---------------------------------------------------------------------------
  * reference: src/fuse_moe/fuse_moe.h:15-62 (count_and_gather_async / blockwise_count_and_gather_async,
@@ -197,7 +201,8 @@ int hpc_fuse_moe_blockwise_async(void* y_ptr, void* workspace, const void* x_ptr
 int hpc_group_gemm_pertensor_fp8_async(void* y_ptr, const void* x_ptr, const void* w_ptr,
                                        const void* seqlens_ptr, const void* cu_seqlens_ptr,
                                        const void* yscale_ptr, const void* row_index_ptr, int num_group,
-                                       int m, int x_rows, int n, int k, hpc_stream_t stream);
+                                       int m, int x_rows, int n, int k, const void* cu_tiles128_ptr,
+                                       hpc_stream_t stream);
 int hpc_act_mul_and_quant_async(void* out_ptr, const void* gate_up_ptr, const void* scale_ptr,
                                 const void* num_rows_ptr, int max_rows, int intermediate_size,
                                 int use_bf16_mul, hpc_stream_t stream);
