@@ -263,6 +263,20 @@ def extra_allreduce(rank, world, local_rank):
     return {f"fuse_allreduce_rmsnorm_bf16_H8192_ws{world}": res}
 
 
+def max_over_ranks(wall, device):
+    """the timed region of the job is the slowest rank's (contract: MAX over ranks)"""
+    import torch.distributed as dist
+
+    t = torch.tensor([wall], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def whole_job_value(bytes_per_rank, world, wall, steps):
+    """whole-job throughput in GB/s: every rank (replica) processed `steps` batches"""
+    return bytes_per_rank * world / (wall / steps) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -344,11 +358,16 @@ def main():
     kern_ms_avg = sum(per_step_ms) / len(per_step_ms)
 
     if dist_on:
-        t = torch.tensor([wall], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+        wall = max_over_ranks(wall, dev)
 
     extras = {}
+    if not args.no_extras:
+        try:  # every rank takes part (one child process per rank); rank 0 reports
+            ar = extra_allreduce(rank, world, local_rank)
+        except Exception as e:  # noqa: BLE001
+            ar = {"fuse_allreduce_rmsnorm": {"error": repr(e)[:200]}}
+        extras.update(ar)
+
     if rank == 0 and not args.no_extras:
         del graph
         for fn in (extra_decode, extra_moe):
@@ -359,17 +378,10 @@ def main():
             torch.cuda.empty_cache()
         graph = None if args.no_graph else True
 
-    if not args.no_extras:
-        try:  # every rank takes part (one child process per rank); rank 0 reports
-            ar = extra_allreduce(rank, world, local_rank)
-        except Exception as e:  # noqa: BLE001
-            ar = {"fuse_allreduce_rmsnorm": {"error": repr(e)[:200]}}
-        extras.update(ar)
-
     if rank == 0:
         nbytes = algorithmic_bytes(w)
         ms_per_step = wall / args.steps * 1e3
-        value = nbytes * world / (wall / args.steps) / 1e9
+        value = whole_job_value(nbytes, world, wall, args.steps)
         achieved = nbytes / (kern_ms_avg * 1e-3) / 1e9
         traffic = None
         pmc = ROOT / "profiles" / "decode_bf16_pmc.json"
