@@ -1,0 +1,136 @@
+"""Golden fixtures made by running the REFERENCE's own in-file oracle functions on the CPU
+(tests/golden/make_golden.py + ref_extract.py, build container only):
+ * CPU: our oracle restatements reproduce the stored reference outputs (this is what pins them);
+ * GPU: the HIP path, through the C-ABI, matches the stored reference outputs at the reference's tolerances.
+"""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+from utils import allclose
+
+G = np.load(Path(__file__).resolve().parent / "golden" / "fp_golden.npz")
+F8 = torch.float8_e4m3fn
+
+
+def bf(name):
+    return torch.from_numpy(G[name].copy()).view(torch.bfloat16)
+
+
+def f8(name):
+    return torch.from_numpy(G[name].copy()).view(F8)
+
+
+def t(name):
+    return torch.from_numpy(G[name].copy())
+
+
+def _nblocks(lens, sq, P=64):
+    return (lens + sq + P - 1) // P
+
+
+# ---------------------------------------------------------------------------- CPU: pin the oracles
+def test_oracle_rmsnorm_matches_reference_output():
+    from oracle import normalization as onorm
+
+    x, w = bf("norm_x"), bf("norm_w")
+    assert torch.equal(onorm.rmsnorm_fp32(x, w, 1e-6), t("norm_y32"))
+    assert torch.equal(onorm.rmsnorm_with_scale_fp8(x, w, torch.tensor(2.5), 1e-6), bf("norm_y8"))
+
+
+def test_oracle_allreduce_matches_reference_output():
+    from oracle import allreduce as oar
+
+    xs = list(bf("ar_x"))
+    rr, ro = oar.ref_allreduce_rmsnorm(xs, bf("ar_res"), bf("ar_w"), 1e-6)
+    assert torch.equal(rr, bf("ar_out_res")) and torch.equal(ro, bf("ar_out"))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_oracle_attention_bf16_matches_reference_output(tag):
+    from oracle import attention as oattn
+
+    sq, lens = int(G[f"attn_bf16_{tag}_sq"]), t(f"attn_bf16_{tag}_lens")
+    out = oattn.ref_attn_with_paged_kvcache(bf(f"attn_bf16_{tag}_q"), bf(f"attn_bf16_{tag}_kv"),
+                                            t(f"attn_bf16_{tag}_bid"), _nblocks(lens, sq), sq, lens)
+    assert torch.equal(out, bf(f"attn_bf16_{tag}_out"))
+
+
+def test_oracle_attention_fp8_matches_reference_output():
+    from oracle import attention as oattn
+
+    lens = t("attn_fp8t_lens")
+    out = oattn.ref_attn_fp8(f8("attn_fp8t_q"), f8("attn_fp8t_kv"), t("attn_fp8t_bid"), _nblocks(lens, 1), 1, lens,
+                             t("attn_fp8t_qs"), torch.tensor([0.7]), torch.tensor([-1.3]), False)
+    assert torch.equal(out, bf("attn_fp8t_out"))
+    lens = t("attn_fp8k_lens")
+    kv = f8("attn_fp8k_kv")
+    out = oattn.ref_attn_fp8(f8("attn_fp8k_q"), kv[:, :, :64], t("attn_fp8k_bid"), _nblocks(lens, 2), 2, lens,
+                             t("attn_fp8k_qs"), kv[:, 0, 64:], t("attn_fp8k_vs"), True, literal_qscale_row=True)
+    assert torch.equal(out, bf("attn_fp8k_out"))
+
+
+def _moe_inputs():
+    rank, E, el = (int(v) for v in G["moe_meta"])
+    return (f8("moe_x"), t("moe_xs"), f8("moe_guw"), t("moe_guws"), f8("moe_dw"), t("moe_dws"), t("moe_ids"),
+            t("moe_sc"), bf("moe_so")), rank, E
+
+
+def test_oracle_moe_matches_reference_output():
+    from oracle import fuse_moe as omoe
+
+    (x, xs, guw, guws, dw, dws, ids, sc, so), rank, E = _moe_inputs()
+    y, inter = omoe.fuse_moe_blockwise_fp8(x, xs, guw, guws, dw, dws, ids, sc, rank, E, so, return_intermediates=True)
+    assert torch.equal(inter["topk_pos"], t("moe_topk_pos"))  # routing: bit-exact
+    assert allclose(bf("moe_out").float(), y.float(), rtol=2e-3, atol=2e-3)
+
+
+# ---------------------------------------------------------------------------- GPU: HIP path vs golden
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_hip_attention_bf16_vs_reference_golden(tag):
+    import hpc
+
+    sq, lens = int(G[f"attn_bf16_{tag}_sq"]), t(f"attn_bf16_{tag}_lens")
+    kv = bf(f"attn_bf16_{tag}_kv").cuda()
+    y = hpc.attention_decode_bf16(bf(f"attn_bf16_{tag}_q").cuda(), kv[:, 0], kv[:, 1], t(f"attn_bf16_{tag}_bid").cuda(),
+                                  lens.cuda(), mtp=sq - 1, new_kv_included=False)
+    assert allclose(bf(f"attn_bf16_{tag}_out"), y.cpu(), atol=0.016)
+
+
+@pytest.mark.gpu
+def test_hip_attention_fp8_vs_reference_golden():
+    import hpc
+
+    lens, kv = t("attn_fp8t_lens"), f8("attn_fp8t_kv").cuda()
+    y = hpc.attention_decode_fp8(f8("attn_fp8t_q").cuda(), kv[:, 0], kv[:, 1], t("attn_fp8t_bid").cuda(), lens.cuda(),
+                                 t("attn_fp8t_qs").cuda(), torch.tensor([0.7]).cuda(), torch.tensor([-1.3]).cuda(),
+                                 mtp=0, new_kv_included=False)
+    assert allclose(bf("attn_fp8t_out"), y.cpu(), atol=0.2)
+    lens, kv = t("attn_fp8k_lens"), f8("attn_fp8k_kv").cuda()
+    y = hpc.attention_decode_fp8(f8("attn_fp8k_q").cuda(), kv[:, 0, :64], kv[:, 1, :64], t("attn_fp8k_bid").cuda(),
+                                 lens.cuda(), t("attn_fp8k_qs").cuda(), kv[:, 0, 64:], t("attn_fp8k_vs").cuda(), mtp=1,
+                                 new_kv_included=False,
+                                 quant_type=hpc.QuantType.QPERTOKEN_PERHEAD_KPERTOKEN_PERHEAD_VPERHEAD)
+    assert allclose(bf("attn_fp8k_out"), y.cpu(), atol=0.1)
+
+
+@pytest.mark.gpu
+def test_hip_moe_vs_reference_golden():
+    import hpc
+
+    args, rank, E = _moe_inputs()
+    d = [a.cuda() for a in args]
+    y = hpc.fuse_moe_blockwise_fp8(d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7], rank, E, d[8])
+    assert allclose(bf("moe_out").float(), y.cpu().float(), rtol=0.01, atol=0.01)
+
+
+@pytest.mark.gpu
+def test_hip_rmsnorm_vs_reference_golden():
+    import hpc
+
+    y = hpc.fused_rmsnorm_with_scale(bf("norm_x").cuda(), bf("norm_w").cuda(), eps=1e-6,
+                                     scale=torch.tensor([2.5]).cuda())
+    assert allclose(bf("norm_y8"), y.cpu().to(torch.bfloat16), atol=0.15, rtol=0.0125)
