@@ -159,6 +159,38 @@ def extra_decode(dev, hpc):
     return out
 
 
+def extra_rope(dev, hpc):
+    """rope_norm_store_kv (bf16 + fp8, QK-norm policy 1), Hq 64 / Hkv 8 / D 128: decode step of 64
+    requests at 8k context and a 8192-token prefill chunk.  Bytes = qkv read + q out + K/V cache write."""
+    out = {}
+    Hq, Hkv, D, P = 64, 8, 128, 64
+    torch.manual_seed(41)
+    cs = torch.cat([torch.rand(16384, 64).cos(), torch.rand(16384, 64).sin()], -1).to(dev)
+    qw, kw = torch.rand(D, device=dev) + 0.5, torch.rand(D, device=dev) + 0.5
+    for name, nreq, qlen, ctx in (("decode_b64", 64, 1, 8192), ("prefill_8x1024", 8, 1024, 1024)):
+        rows = nreq * qlen
+        nb = (ctx + P - 1) // P
+        qkv = torch.randn(rows, (Hq + 2 * Hkv) * D, dtype=torch.bfloat16, device=dev)
+        kc = torch.zeros(nreq * nb + 8, P, Hkv, D, dtype=torch.bfloat16, device=dev)
+        vc = torch.zeros_like(kc)
+        ns = torch.full((nreq,), ctx, dtype=torch.int32, device=dev)
+        qi = torch.arange(0, (nreq + 1) * qlen, qlen, dtype=torch.int32, device=dev)
+        ki = torch.randperm(nreq * nb + 8, device=dev)[: nreq * nb].to(torch.int32).reshape(nreq, nb).contiguous()
+        oq = torch.empty(rows, Hq, D, dtype=torch.bfloat16, device=dev)
+        us = timed(lambda: hpc.rope_norm_store_kv(kc, vc, qkv, cs, ns, qi, ki, qlen > 1, qw, kw, oq, None, None, 1),
+                   graph=True)
+        byt = rows * (Hq + 2 * Hkv) * D * 2 * 2
+        out[f"rope_bf16_{name}"] = {"us": round(us, 1), "GBps": round(byt / us / 1e3, 1)}
+        kc8, vc8 = kc.to(torch.float8_e4m3fn), vc.to(torch.float8_e4m3fn)
+        one = torch.ones(1, device=dev)
+        oq8 = torch.empty(rows, Hq, D, dtype=torch.float8_e4m3fn, device=dev)
+        us = timed(lambda: hpc.rope_norm_store_kv_fp8(kc8, vc8, qkv, cs, ns, qi, ki, qlen > 1, one, one, 1, qlen,
+                                                      None, None, qw, kw, oq8, None, None, 1), graph=True)
+        byt = rows * (Hq + 2 * Hkv) * D * 3
+        out[f"rope_fp8_{name}"] = {"us": round(us, 1), "GBps": round(byt / us / 1e3, 1)}
+    return out
+
+
 def extra_moe(dev, hpc, tokens=(16, 64, 256, 4096)):
     """fused MoE FP8 blockwise, BASELINE configs[3]: 64 experts top-8, hidden 4096, ffn 11008."""
     E, k, H, I = 64, 8, 4096, 11008
@@ -370,7 +402,7 @@ def main():
 
     if rank == 0 and not args.no_extras:
         del graph
-        for fn in (extra_decode, extra_moe):
+        for fn in (extra_decode, extra_moe, extra_rope):
             try:
                 extras.update(fn(dev, hpc))
             except Exception as e:  # noqa: BLE001

@@ -69,6 +69,9 @@ _sig("hpc_act_mul_and_quant_async", I, P, P, P, P, I, I, I, P)
 _sig("hpc_scaled_fp8_quant_async", I, P, P, P, L, P)
 _sig("hpc_moe_gather_rows_async", I, P, P, I, I, I, P, P)
 _sig("hpc_fuse_moe_pertensor_async", I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P)
+_sig("hpc_rope_norm_store_kv_async", I, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, I, I, I, I, I, I, P)
+_sig("hpc_rope_norm_store_kv_fp8_async", I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, F, I, L, L,
+     I, I, I, I, I, I, I, I, I, I, I, P)
 PP = ctypes.POINTER(c_void_p)
 _sig("hpc_comm_create", I, I, I, I, c_char_p)
 _sig("hpc_comm_destroy", I, I)

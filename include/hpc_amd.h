@@ -218,6 +218,38 @@ int hpc_fuse_moe_pertensor_async(void* y_ptr, void* workspace, const void* x_ptr
                                  int num_tokens, int hidden_size, int intermediate_size2, int num_topk,
                                  int num_expert, int rank_ep, int use_bf16_mul, hpc_stream_t stream);
 
+/* ---- RoPE + optional QK RMSNorm + paged KV-cache write (producer of the decode-attention inputs) ----
+ * reference: rope_norm_store_kv_async / rope_norm_store_kv_fp8_async, src/rope/rope.cu:790-950
+ *            (kernels :99, :420), entry src/rope/entry.cc:14-240.
+ * qkv bf16 [rows, (Hq + 2*Hkv) * 128]; cos_sin f32 [max_pos, 128] (cos | sin halves, neox pairing);
+ * num_seqlen_per_req int32 [num_req] (total length incl. the new tokens), q_index int32 [num_req+1],
+ * kvcache_indices int32 [num_req, max_blocks_per_req]; caches [blocks, block_size, Hkv, 128]
+ * contiguous inside a block, block stride in elements; out_k / out_v (nullable) bypass the cache
+ * ([rows, Hkv, 128]).  qk_norm_policy 0 none / 1 rope then RMSNorm / 2 RMSNorm then rope (eps 1e-6,
+ * f32 weights [128]).  The tail of each request's last page and (fp8) its split_k_flag row are zeroed.
+ * fp8: q/k/v e4m3; quant_policy 1 = dynamic per-token per-head q scale amax/upper_max written to
+ * q_scale (decode [rows, Hq]; prefill [num_req, Hq, max_seqlens_pad]), 2 = static q_scale_inv[0];
+ * k, v divided by k_scale[0], v_scale[0].  head dims must be 128. */
+int hpc_rope_norm_store_kv_async(void* out_q, void* kcache, void* vcache, void* out_k, void* out_v,
+                                 const void* qkv, const void* cos_sin, const void* num_seqlen_per_req,
+                                 const void* q_index, const void* kvcache_indices,
+                                 const void* q_norm_weight, const void* k_norm_weight,
+                                 int64_t kcache_block_stride, int64_t vcache_block_stride, int num_req,
+                                 int max_blocks_per_req, int kv_block_size, int num_rows,
+                                 int num_q_heads, int num_kv_heads, int qk_head_dim, int v_head_dim,
+                                 int is_prefill, int qk_norm_policy, hpc_stream_t stream);
+int hpc_rope_norm_store_kv_fp8_async(void* out_q, void* kcache, void* vcache, void* out_k, void* out_v,
+                                     void* split_k_flag, void* q_scale, const void* qkv,
+                                     const void* cos_sin, const void* num_seqlen_per_req,
+                                     const void* q_index, const void* kvcache_indices,
+                                     const void* q_norm_weight, const void* k_norm_weight,
+                                     const void* k_scale, const void* v_scale, const void* q_scale_inv,
+                                     float upper_max, int max_seqlens_pad, int64_t kcache_block_stride,
+                                     int64_t vcache_block_stride, int num_req, int max_blocks_per_req,
+                                     int kv_block_size, int num_rows, int num_q_heads, int num_kv_heads,
+                                     int qk_head_dim, int v_head_dim, int is_prefill, int qk_norm_policy,
+                                     int quant_policy, hpc_stream_t stream);
+
 /* ---- communicator: socket rendezvous + symmetric device buffers (HIP IPC over xGMI) ---------------
  * reference: src/communicator/{communicator,channel,listener,connector,protocol}.cc (rank-0 star over
  *            an abstract unix socket "unix://name" / bare name, or "tcp://ip:port"),

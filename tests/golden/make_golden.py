@@ -156,6 +156,38 @@ def golden_fp():
               moe_guws=guws.numpy(), moe_dw=dw.view(torch.uint8).numpy(), moe_dws=dws.numpy(), moe_ids=ids.numpy(),
               moe_sc=sc.numpy(), moe_so=so.view(torch.int16).numpy(), moe_topk_pos=rg[2].numpy(),
               moe_out=ref.view(torch.int16).numpy(), moe_meta=np.array([rank, E, el]))
+    # ---- rope + qk-norm + paged KV store (tests/test_rope.py:14-117) ---------------------------------
+    from oracle import rope as orope
+    r = load("tests/test_rope.py", ["generate_cos_sin_cache", "apply_rms_norm_reference",
+                                    "apply_rotary_pos_emb_neox_reference", "rope_norm_ref"])
+    torch.manual_seed(41)
+    hq, hkv, d, blk, nblocks = 4, 2, 128, 16, 24
+    cs = r["generate_cos_sin_cache"](256, d).float()
+    assert torch.equal(cs, orope.generate_cos_sin_cache(256, d))
+    req_len = torch.tensor([21, 37, 16, 5])
+    q_len = torch.tensor([3, 37, 1, 5])
+    qkv = torch.randn(int(q_len.sum()), (hq + 2 * hkv) * d).bfloat16()
+    qi = torch.cat([torch.zeros(1, dtype=torch.long), q_len.cumsum(0)]).int()
+    per = ((req_len + blk - 1) // blk).tolist()
+    perm = torch.randperm(nblocks)[: sum(per)].int()
+    ki = torch.zeros(4, max(per), dtype=torch.int32)
+    o = 0
+    for i, n in enumerate(per):
+        ki[i, :n] = perm[o : o + n]
+        o += n
+    kc0, vc0 = torch.randn(nblocks, blk, hkv, d).bfloat16(), torch.randn(nblocks, blk, hkv, d).bfloat16()
+    qw, kw = torch.randn(d), torch.randn(d)
+    st.update(rope_qkv=qkv.view(torch.int16).numpy(), rope_cs=cs.numpy(), rope_ns=req_len.int().numpy(),
+              rope_qi=qi.numpy(), rope_ki=ki.numpy(), rope_kc0=kc0.view(torch.int16).numpy(),
+              rope_vc0=vc0.view(torch.int16).numpy(), rope_qw=qw.numpy(), rope_kw=kw.numpy())
+    for pol in (0, 1, 2):
+        kr, vr = kc0.clone(), vc0.clone()
+        q = r["rope_norm_ref"](kr, vr, qkv, cs, req_len.int(), qi, ki, qw, kw, pol)
+        km, vm = kc0.clone(), vc0.clone()
+        qm = orope.rope_norm_ref(km, vm, qkv, cs, req_len.int(), qi, ki, qw, kw, pol)
+        assert torch.equal(q, qm) and torch.equal(kr, km) and torch.equal(vr, vm), pol
+        st.update({f"rope_q_p{pol}": q.view(torch.int16).numpy(), f"rope_k_p{pol}": kr.view(torch.int16).numpy(),
+                   f"rope_v_p{pol}": vr.view(torch.int16).numpy()})
     np.savez_compressed(ROOT / "tests" / "golden" / "fp_golden.npz", **st)
     print("wrote fp_golden.npz:", len(st), "arrays")
 

@@ -134,3 +134,32 @@ def test_hip_rmsnorm_vs_reference_golden():
     y = hpc.fused_rmsnorm_with_scale(bf("norm_x").cuda(), bf("norm_w").cuda(), eps=1e-6,
                                      scale=torch.tensor([2.5]).cuda())
     assert allclose(bf("norm_y8"), y.cpu().to(torch.bfloat16), atol=0.15, rtol=0.0125)
+
+
+# ---------------------------------------------------------------------------- rope + KV store
+def _rope_inputs():
+    return (bf("rope_kc0"), bf("rope_vc0"), bf("rope_qkv"), t("rope_cs"), t("rope_ns"), t("rope_qi"),
+            t("rope_ki"), t("rope_qw"), t("rope_kw"))
+
+
+@pytest.mark.parametrize("policy", [0, 1, 2])
+def test_oracle_rope_matches_reference_output(policy):
+    from oracle import rope as orope
+
+    kc, vc, qkv, cs, ns, qi, ki, qw, kw = _rope_inputs()
+    q = orope.rope_norm_ref(kc, vc, qkv, cs, ns, qi, ki, qw, kw, policy)
+    assert torch.equal(q, bf(f"rope_q_p{policy}"))
+    assert torch.equal(kc, bf(f"rope_k_p{policy}")) and torch.equal(vc, bf(f"rope_v_p{policy}"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", [0, 1, 2])
+def test_hip_rope_vs_reference_golden(policy):
+    import hpc
+
+    kc, vc, qkv, cs, ns, qi, ki, qw, kw = [a.cuda() for a in _rope_inputs()]
+    q = hpc.rope_norm_store_kv(kc, vc, qkv, cs, ns, qi, ki, True, qw if policy else None, kw if policy else None,
+                               qk_norm_policy=policy)
+    assert allclose(bf(f"rope_q_p{policy}"), q.cpu(), atol=8e-2)
+    assert allclose(bf(f"rope_k_p{policy}"), kc.cpu(), atol=8e-2)
+    assert torch.equal(bf(f"rope_v_p{policy}"), vc.cpu())
