@@ -80,9 +80,10 @@ def cpu_baseline(q, k_cache, v_cache, block_ids, kv_lens, w, sample_requests=4):
     }
 
 
-def timed(fn, iters=30, warm=5, graph=False):
+def timed(fn, iters=30, warm=5, graph=False, reps=1):
     """median microseconds per call from events on the current stream (optionally replaying a
-    hipGraph of one call, the reference benchmarks' method)"""
+    hipGraph of `reps` back-to-back calls, the reference benchmarks' method; reps > 1 amortises the
+    ~10 us per-replay overhead for kernels that are themselves only a few microseconds)"""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -90,12 +91,15 @@ def timed(fn, iters=30, warm=5, graph=False):
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                fn()
+                for _ in range(reps):
+                    fn()
             fn = g.replay
             fn()
             torch.cuda.synchronize()
         except Exception:  # noqa: BLE001
-            pass
+            reps = 1
+    else:
+        reps = 1
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(iters + 1)]
     ev[0].record()
     for i in range(iters):
@@ -103,7 +107,7 @@ def timed(fn, iters=30, warm=5, graph=False):
         ev[i + 1].record()
     torch.cuda.synchronize()
     ts = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(iters))
-    return ts[len(ts) // 2] * 1e3
+    return ts[len(ts) // 2] * 1e3 / reps
 
 
 def extra_decode(dev, hpc):
@@ -178,17 +182,35 @@ def extra_rope(dev, hpc):
         ki = torch.randperm(nreq * nb + 8, device=dev)[: nreq * nb].to(torch.int32).reshape(nreq, nb).contiguous()
         oq = torch.empty(rows, Hq, D, dtype=torch.bfloat16, device=dev)
         us = timed(lambda: hpc.rope_norm_store_kv(kc, vc, qkv, cs, ns, qi, ki, qlen > 1, qw, kw, oq, None, None, 1),
-                   graph=True)
+                   graph=True, reps=10)
         byt = rows * (Hq + 2 * Hkv) * D * 2 * 2
         out[f"rope_bf16_{name}"] = {"us": round(us, 1), "GBps": round(byt / us / 1e3, 1)}
         kc8, vc8 = kc.to(torch.float8_e4m3fn), vc.to(torch.float8_e4m3fn)
         one = torch.ones(1, device=dev)
         oq8 = torch.empty(rows, Hq, D, dtype=torch.float8_e4m3fn, device=dev)
         us = timed(lambda: hpc.rope_norm_store_kv_fp8(kc8, vc8, qkv, cs, ns, qi, ki, qlen > 1, one, one, 1, qlen,
-                                                      None, None, qw, kw, oq8, None, None, 1), graph=True)
+                                                      None, None, qw, kw, oq8, None, None, 1), graph=True, reps=10)
         byt = rows * (Hq + 2 * Hkv) * D * 3
         out[f"rope_fp8_{name}"] = {"us": round(us, 1), "GBps": round(byt / us / 1e3, 1)}
     return out
+
+
+def extra_router_gemm(dev, hpc):
+    """gemm_bf16xfp32 (router): n = 256 experts, k = 4096; bytes = both weight planes + x + y(fp32)."""
+    out = {}
+    n, k = 256, 4096
+    torch.manual_seed(41)
+    w = torch.randn(n, k, device=dev)
+    wh = w.bfloat16()
+    wl = ((w - wh.float()) * 256).bfloat16()
+    flag = hpc.get_gemm_bf16xfp32_workspace(n, 8192)
+    for m in (16, 64, 256, 4096):
+        x = torch.randn(m, k, device=dev).bfloat16()
+        us = timed(lambda: hpc.gemm_bf16xfp32(x, wh, wl, 1 / 256, True, True, flag), graph=True, reps=20)
+        byt = 2 * n * k * 2 + m * k * 2 + m * n * 4
+        out[f"m{m}"] = {"us": round(us, 1), "GBps": round(byt / us / 1e3, 1),
+                        "TFLOPS": round(4 * m * n * k / us / 1e6, 2)}
+    return {"gemm_bf16xfp32_n256_k4096": out}
 
 
 def extra_moe(dev, hpc, tokens=(16, 64, 256, 4096)):
@@ -402,7 +424,7 @@ def main():
 
     if rank == 0 and not args.no_extras:
         del graph
-        for fn in (extra_decode, extra_moe, extra_rope):
+        for fn in (extra_decode, extra_moe, extra_rope, extra_router_gemm):
             try:
                 extras.update(fn(dev, hpc))
             except Exception as e:  # noqa: BLE001

@@ -1,0 +1,363 @@
+// Router ("route") GEMM: bf16 activations x fp32 weights carried as two bf16 planes - gfx950.
+//
+//   y[m, n] = sum_k x[m,k] * (w_high[n,k] + scale * w_low[n,k])        (fp32 accumulate)
+// with w_high = bf16(w), w_low = bf16((w - w_high) / scale), scale = 1/256: the fp32 router weight at
+// ~16 mantissa bits from two bf16 MFMA GEMMs.  Replaces reference src/gemm/sm90/gemm_bf16xfp32.cu
+// (kernel :88-410, launcher :413-557; config table src/gemm/sm90/entry.cc:23-84).
+//
+// MI355X design: weights sit on the MFMA M axis, tokens on N.  Two kernels: the decode-step shape
+// (m <= 256 tokens against n = #experts rows of k = 4096: 3 - 33 MB of weights, a streaming / latency
+// problem) runs on skinny 16-row tiles with K split over waves and workgroups (below); larger m runs
+// on 64 x 64 tiles (16 rows per wave) with K optionally split across blockIdx.z.  Both weight planes and the
+// activations are fetched straight into MFMA operand layout (v_mfma_f32_16x16x32_bf16: lane
+// (r, g) holds 8 consecutive k of row r), 64 k per step, register double-buffered.  Split-K partials
+// go to an fp32 workspace; the last workgroup to arrive at a tile (device-scope counter) sums the
+// splits in fixed order - deterministic - writes y and leaves the counter at zero for the next call
+// (same contract as the reference's split_flag).
+#include "hpc_common.h"
+#include "../../include/hpc_amd.h"
+
+namespace hpc {
+namespace rgemm {
+
+struct Args {
+  const uint16_t* x;
+  const uint16_t* wh;
+  const uint16_t* wl;
+  void* y;
+  float* split_y;  // [S, m, n] fp32 (S > 1)
+  int* flag;       // per-tile arrival counters, row stride flag_ld (S > 1)
+  int m, n, k, splits, flag_ld, fp32_out;
+  float scale;
+};
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ f32x4 mfma_bf16(const u32x4 a, const u32x4 b, const f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                 c, 0, 0, 0);
+}
+
+template <int kMT>
+__global__ __launch_bounds__(kThreads) void gemm_bf16xfp32_kernel(const Args a) {
+  constexpr int kTM = 16 * kMT;
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int n0 = blockIdx.x * 64, m0 = blockIdx.y * kTM, split = blockIdx.z;
+  const int K = a.k;
+  const int chunks = K >> 6;  // 64 k per step
+  const int c_begin = static_cast<int>(static_cast<long>(chunks) * split / a.splits);
+  const int c_end = static_cast<int>(static_cast<long>(chunks) * (split + 1) / a.splits);
+
+  const unsigned w_bytes = static_cast<unsigned>(a.n) * static_cast<unsigned>(K) * 2u;
+  const unsigned x_bytes = static_cast<unsigned>(a.m) * static_cast<unsigned>(K) * 2u;
+  const unsigned w_off = static_cast<unsigned>(n0 + wave * 16 + r16) * static_cast<unsigned>(K) * 2u + g4 * 16;
+  unsigned x_off[kMT];
+#pragma unroll
+  for (int j = 0; j < kMT; ++j) {
+    const int t = m0 + j * 16 + r16;
+    x_off[j] = static_cast<unsigned>(t < a.m ? t : a.m - 1) * static_cast<unsigned>(K) * 2u + g4 * 16;
+  }
+
+  f32x4 acc_h[kMT], acc_l[kMT];
+#pragma unroll
+  for (int j = 0; j < kMT; ++j) acc_h[j] = acc_l[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // Two 64-k steps in flight.  Loads are UNCONDITIONAL (steps past the end use empty descriptors and
+  // read zeros): a branch around a prefetch makes hipcc fall back to vmcnt(0) at the join.
+  u32x4 bh[2][2], bl[2][2], bx[2][kMT][2];  // [buffer][..][32-k half of the step]
+  auto issue = [&](int buf, int c) {
+    const int koff = c * 128;  // bytes
+    const bool on = c < c_end;
+    const auto rh_ = make_rsrc(a.wh, on ? w_bytes : 0u), rl_ = make_rsrc(a.wl, on ? w_bytes : 0u);
+    const auto rx_ = make_rsrc(a.x, on ? x_bytes : 0u);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bh[buf][h] = buf_ld16<0>(rh_, w_off, koff + h * 64);
+      bl[buf][h] = buf_ld16<0>(rl_, w_off, koff + h * 64);
+#pragma unroll
+      for (int j = 0; j < kMT; ++j) bx[buf][j][h] = buf_ld16<0>(rx_, x_off[j], koff + h * 64);
+    }
+  };
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < kMT; ++j) {
+        acc_h[j] = mfma_bf16(bh[buf][h], bx[buf][j][h], acc_h[j]);
+        acc_l[j] = mfma_bf16(bl[buf][h], bx[buf][j][h], acc_l[j]);
+      }
+  };
+  issue(0, c_begin);
+  issue(1, c_begin + 1);
+  for (int c = c_begin; c < c_end; c += 2) {
+    compute(0);
+    issue(0, c + 2);
+    compute(1);
+    issue(1, c + 3);
+  }
+
+  // lane holds rows n = n0 + wave*16 + g4*4 + i of token column m0 + j*16 + r16
+  const int nn = n0 + wave * 16 + g4 * 4;
+  auto emit = [&](int t, const f32x4 v) {
+    if (a.fp32_out) {
+      *reinterpret_cast<f32x4*>(static_cast<float*>(a.y) + static_cast<long>(t) * a.n + nn) = v;
+    } else {
+      u32x2 pk;
+      pk[0] = pack_bf16x2(v[0], v[1]);
+      pk[1] = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(static_cast<uint16_t*>(a.y) + static_cast<long>(t) * a.n + nn) = pk;
+    }
+  };
+  if (a.splits == 1) {
+#pragma unroll
+    for (int j = 0; j < kMT; ++j) {
+      const int t = m0 + j * 16 + r16;
+      if (t < a.m) emit(t, acc_l[j] * a.scale + acc_h[j]);
+    }
+    return;
+  }
+
+  // ---- split-K: park the partial, count arrivals, the last workgroup reduces ---------------------------
+  // Partials travel with system-scope (sc0 sc1) buffer stores / loads: written through to memory and
+  // read around the per-XCD L2s, so no L2 write-back / invalidate fence is needed (those cost tens
+  // of microseconds here - more than the GEMM).
+  const unsigned plane = static_cast<unsigned>(a.m) * static_cast<unsigned>(a.n) * 4u;  // bytes, < 2^28 (launcher)
+  const auto rp = make_rsrc(a.split_y, plane * static_cast<unsigned>(a.splits));
+#pragma unroll
+  for (int j = 0; j < kMT; ++j) {
+    const int t = m0 + j * 16 + r16;
+    const f32x4 v = acc_l[j] * a.scale + acc_h[j];
+    if (t < a.m)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp,
+                                             (static_cast<unsigned>(t) * a.n + nn) * 4u, split * plane, 17);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the write-through stores are acknowledged
+  __syncthreads();
+  int* flag = a.flag + static_cast<long>(blockIdx.y) * a.flag_ld + blockIdx.x;
+  if (tid == 0) {
+    const int old = atomicAdd(flag, 1);
+    s_last = (old == a.splits - 1);
+    if (s_last) atomicExch(flag, 0);  // every split has arrived: nobody touches the counter again in this call
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // all partial loads of (up to) two token blocks in flight at once: a serial load->add chain costs
+  // one ~2 us memory round trip per split.  Splits past a.splits use an empty descriptor (reads 0).
+  constexpr int kMaxSplits = 16;
+  const auto rnull = make_rsrc(a.split_y, 0u);
+#pragma unroll
+  for (int j0 = 0; j0 < kMT; j0 += 2) {
+    u32x4 part[2][kMaxSplits];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int t = m0 + (j0 + jj) * 16 + r16;
+      const unsigned off = (static_cast<unsigned>(t < a.m ? t : 0) * a.n + nn) * 4u;
+#pragma unroll
+      for (int sp = 0; sp < kMaxSplits; ++sp)
+        if (j0 + jj < kMT) part[jj][sp] = buf_ld16<17>(sp < a.splits ? rp : rnull, off, sp * plane);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      if (j0 + jj >= kMT) continue;
+      const int t = m0 + (j0 + jj) * 16 + r16;
+      f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sp = 0; sp < kMaxSplits; ++sp) sum += __builtin_bit_cast(f32x4, part[jj][sp]);
+      if (t < a.m) emit(t, sum);
+    }
+  }
+}
+
+// ---- decode-size m (<= 256): skinny tiles, K split across waves AND workgroups --------------------------
+// The problem is a stream of the two weight planes (4 - 33 MB) against a few tokens: it needs every
+// CU pulling bytes (one CU sustains only ~50 GB/s), so the tile is the MFMA minimum of 16 weight rows
+// x 16*kMT tokens, the 4 waves of a workgroup interleave the 64-k steps of the workgroup's K range
+// (partials meet in LDS, free), and K is further split over blockIdx.z just enough to reach ~256
+// workgroups.  Cross-workgroup partials are one f32x4 per thread (kept small on purpose: they travel
+// write-through / uncached), the last arriver sums them in split order.
+template <int kMT>
+__global__ __launch_bounds__(kThreads) void gemm_bf16xfp32_skinny_kernel(const Args a) {
+  constexpr int kTM = 16 * kMT;
+  __shared__ f32x4 s_part[4][kMT][64];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * kTM, split = blockIdx.z;
+  const int K = a.k;
+  const int chunks = K >> 6;
+  const int c_begin = static_cast<int>(static_cast<long>(chunks) * split / a.splits);
+  const int c_end = static_cast<int>(static_cast<long>(chunks) * (split + 1) / a.splits);
+
+  const unsigned w_bytes = static_cast<unsigned>(a.n) * static_cast<unsigned>(K) * 2u;
+  const unsigned x_bytes = static_cast<unsigned>(a.m) * static_cast<unsigned>(K) * 2u;
+  const unsigned w_off = static_cast<unsigned>(n0 + r16) * static_cast<unsigned>(K) * 2u + g4 * 16;
+  unsigned x_off[kMT];
+#pragma unroll
+  for (int j = 0; j < kMT; ++j) {
+    const int t = m0 + j * 16 + r16;
+    x_off[j] = static_cast<unsigned>(t < a.m ? t : a.m - 1) * static_cast<unsigned>(K) * 2u + g4 * 16;
+  }
+  f32x4 acc_h[kMT], acc_l[kMT];
+#pragma unroll
+  for (int j = 0; j < kMT; ++j) acc_h[j] = acc_l[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // two steps in flight per wave; unconditional loads, empty descriptors past the end
+  u32x4 bh[2][2], bl[2][2], bx[2][kMT][2];
+  auto issue = [&](int buf, int c) {
+    const int koff = c * 128;
+    const bool on = c < c_end;
+    const auto rh_ = make_rsrc(a.wh, on ? w_bytes : 0u), rl_ = make_rsrc(a.wl, on ? w_bytes : 0u);
+    const auto rx_ = make_rsrc(a.x, on ? x_bytes : 0u);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bh[buf][h] = buf_ld16<0>(rh_, w_off, koff + h * 64);
+      bl[buf][h] = buf_ld16<0>(rl_, w_off, koff + h * 64);
+#pragma unroll
+      for (int j = 0; j < kMT; ++j) bx[buf][j][h] = buf_ld16<0>(rx_, x_off[j], koff + h * 64);
+    }
+  };
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < kMT; ++j) {
+        acc_h[j] = mfma_bf16(bh[buf][h], bx[buf][j][h], acc_h[j]);
+        acc_l[j] = mfma_bf16(bl[buf][h], bx[buf][j][h], acc_l[j]);
+      }
+  };
+  issue(0, c_begin + wave);
+  issue(1, c_begin + wave + 4);
+  for (int c = c_begin + wave; c < c_end; c += 8) {
+    compute(0);
+    issue(0, c + 8);
+    compute(1);
+    issue(1, c + 12);
+  }
+#pragma unroll
+  for (int j = 0; j < kMT; ++j) s_part[wave][j][lane] = acc_l[j] * a.scale + acc_h[j];
+  __syncthreads();
+
+  // threads 0 .. 64*kMT-1 own one f32x4 of the tile each: (token block j = tid / 64, MFMA C lane)
+  const bool owner = tid < kMT * 64;
+  const int j = tid >> 6;  // wave-uniform
+  const int t = m0 + j * 16 + r16;
+  const int nn = n0 + g4 * 4;
+  f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (owner) sum = (s_part[0][j][lane] + s_part[1][j][lane]) + (s_part[2][j][lane] + s_part[3][j][lane]);
+  auto emit = [&](const f32x4 v) {
+    if (a.fp32_out) {
+      *reinterpret_cast<f32x4*>(static_cast<float*>(a.y) + static_cast<long>(t) * a.n + nn) = v;
+    } else {
+      u32x2 pk;
+      pk[0] = pack_bf16x2(v[0], v[1]);
+      pk[1] = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(static_cast<uint16_t*>(a.y) + static_cast<long>(t) * a.n + nn) = pk;
+    }
+  };
+  if (a.splits == 1) {
+    if (owner && t < a.m) emit(sum);
+    return;
+  }
+  const unsigned plane = static_cast<unsigned>(a.m) * static_cast<unsigned>(a.n) * 4u;
+  const auto rp = make_rsrc(a.split_y, plane * static_cast<unsigned>(a.splits));
+  const unsigned off = (static_cast<unsigned>(t < a.m ? t : 0) * a.n + nn) * 4u;
+  if (owner && t < a.m) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sum), rp, off, split * plane, 17);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // write-through stores acknowledged
+  __syncthreads();
+  int* flag = a.flag + static_cast<long>(blockIdx.y) * a.flag_ld + blockIdx.x;
+  if (tid == 0) {
+    const int old = atomicAdd(flag, 1);
+    s_last = (old == a.splits - 1);
+    if (s_last) atomicExch(flag, 0);
+  }
+  __syncthreads();
+  if (!s_last || !owner) return;
+  constexpr int kMaxSplits = 16;
+  const auto rnull = make_rsrc(a.split_y, 0u);
+  u32x4 part[kMaxSplits];
+#pragma unroll
+  for (int sp = 0; sp < kMaxSplits; ++sp) part[sp] = buf_ld16<17>(sp < a.splits ? rp : rnull, off, sp * plane);
+  f32x4 tot = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int sp = 0; sp < kMaxSplits; ++sp) tot += __builtin_bit_cast(f32x4, part[sp]);
+  if (t < a.m) emit(tot);
+}
+
+constexpr int kSkinnyMaxM = 256;
+inline int skinny_tm(int m) { return m <= 16 ? 16 : (m <= 32 ? 32 : 64); }
+
+}  // namespace rgemm
+}  // namespace hpc
+
+// Split count the launcher will use for (m, n, k): callers size split_y = splits * m * n floats and
+// (m <= 256) provide ceil(m / tm) * n / 16 zeroed counters, (m > 256) a [ceil(m/64)+, n/64+] counter grid.
+extern "C" int hpc_gemm_bf16xfp32_splits(int m, int n, int k, int use_splitk) {
+  using namespace hpc::rgemm;
+  if (m <= 0 || n <= 0 || k <= 0) return 1;
+  if (!use_splitk) return 1;
+  int s = 1;
+  if (m <= kSkinnyMaxM) {
+    const int tm = skinny_tm(m);
+    const long tiles = static_cast<long>((m + tm - 1) / tm) * (n / 16);
+    // ~one workgroup per CU; every wave keeps at least one 64-k step
+    while (s < 16 && tiles * s < 256 && (k >> 6) / (s * 2) >= 4) s *= 2;
+    return s;
+  }
+  const long tiles = static_cast<long>((m + 63) / 64) * (n / 64);
+  while (s < 16 && tiles * s < 512 && k / (s * 2) >= 256) s *= 2;
+  return s;
+}
+
+// reference: gemm_bf16xfp32_async (src/gemm/gemm.h:13-17, src/gemm/sm90/gemm_bf16xfp32.cu:488-557)
+extern "C" int hpc_gemm_bf16xfp32_async(void* y_ptr, void* splitk_y_ptr, void* split_flag_ptr,
+                                        const void* x_ptr, const void* w_high_ptr, const void* w_low_ptr,
+                                        int m, int n, int k, float scale, int use_fp32_output, int splits,
+                                        int flag_ld, hipStream_t stream) {
+  using namespace hpc::rgemm;
+  if (!y_ptr || !x_ptr || !w_high_ptr || !w_low_ptr) return HPC_ERR_INVALID;
+  if (m < 0 || n <= 0 || k <= 0 || splits < 1) return HPC_ERR_INVALID;
+  if (m == 0) return HPC_OK;
+  if ((n & 63) || (k & 63)) return HPC_ERR_UNSUPPORTED;
+  if (static_cast<int64_t>(m) * k * 2 > 0xfffffff0ll || static_cast<int64_t>(n) * k * 2 > 0xfffffff0ll)
+    return HPC_ERR_UNSUPPORTED;  // 32-bit buffer offsets
+  if (splits > 1 && (!splitk_y_ptr || !split_flag_ptr)) return HPC_ERR_INVALID;
+  if (splits > (k >> 6)) return HPC_ERR_INVALID;
+  if (splits > 1 && static_cast<int64_t>(splits) * m * n * 4 > 0xfffffff0ll) return HPC_ERR_UNSUPPORTED;
+  Args a;
+  a.x = static_cast<const uint16_t*>(x_ptr);
+  a.wh = static_cast<const uint16_t*>(w_high_ptr);
+  a.wl = static_cast<const uint16_t*>(w_low_ptr);
+  a.y = y_ptr;
+  a.split_y = static_cast<float*>(splitk_y_ptr);
+  a.flag = static_cast<int*>(split_flag_ptr);
+  a.m = m;
+  a.n = n;
+  a.k = k;
+  a.splits = splits;
+  a.flag_ld = flag_ld;
+  a.fp32_out = use_fp32_output;
+  a.scale = scale;
+  if (m <= kSkinnyMaxM) {
+    const int tm = skinny_tm(m);
+    dim3 grid(n / 16, (m + tm - 1) / tm, splits);
+    if (splits > 1 && flag_ld < n / 16) return HPC_ERR_INVALID;
+    if (tm == 16)
+      gemm_bf16xfp32_skinny_kernel<1><<<grid, kThreads, 0, stream>>>(a);
+    else if (tm == 32)
+      gemm_bf16xfp32_skinny_kernel<2><<<grid, kThreads, 0, stream>>>(a);
+    else
+      gemm_bf16xfp32_skinny_kernel<4><<<grid, kThreads, 0, stream>>>(a);
+    HPC_CHECK_LAUNCH();
+    return HPC_OK;
+  }
+  dim3 grid(n / 64, (m + 63) / 64, splits);
+  if (grid.y > 65535) return HPC_ERR_UNSUPPORTED;
+  if (splits > 1 && flag_ld < n / 64) return HPC_ERR_INVALID;
+  gemm_bf16xfp32_kernel<4><<<grid, kThreads, 0, stream>>>(a);
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}

@@ -72,6 +72,8 @@ _sig("hpc_fuse_moe_pertensor_async", I, P, P, P, P, P, P, P, P, P, P, P, I, I, I
 _sig("hpc_rope_norm_store_kv_async", I, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, I, I, I, I, I, I, P)
 _sig("hpc_rope_norm_store_kv_fp8_async", I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, F, I, L, L,
      I, I, I, I, I, I, I, I, I, I, I, P)
+_sig("hpc_gemm_bf16xfp32_splits", I, I, I, I, I)
+_sig("hpc_gemm_bf16xfp32_async", I, P, P, P, P, P, P, I, I, I, F, I, I, I, P)
 PP = ctypes.POINTER(c_void_p)
 _sig("hpc_comm_create", I, I, I, I, c_char_p)
 _sig("hpc_comm_destroy", I, I)

@@ -250,6 +250,18 @@ int hpc_rope_norm_store_kv_fp8_async(void* out_q, void* kcache, void* vcache, vo
                                      int qk_head_dim, int v_head_dim, int is_prefill, int qk_norm_policy,
                                      int quant_policy, hpc_stream_t stream);
 
+/* ---- router GEMM: y = x (w_high + scale * w_low)^T, bf16 operands, fp32 accumulate ----
+ * reference: gemm_bf16xfp32_async, src/gemm/gemm.h:13-17 (kernel src/gemm/sm90/gemm_bf16xfp32.cu:88-410,
+ * config src/gemm/sm90/entry.cc:23-84).  x [m,k] bf16, w_high / w_low [n,k] bf16, y [m,n] bf16 or fp32.
+ * n % 64 == 0, k % 64 == 0.  splits = hpc_gemm_bf16xfp32_splits(m, n, k, use_splitk); when > 1 the
+ * caller provides splitk_y (splits*m*n fp32) and zeroed int32 arrival counters split_flag: for
+ * m <= 256 a flat [ceil(m/tm), flag_ld = n/16] array (tm = 16 / 32 / 64 for m <= 16 / 32 / 256), for
+ * larger m a [ceil(m/64), flag_ld >= n/64] grid; the counters are zero again when the call retires. */
+int hpc_gemm_bf16xfp32_splits(int m, int n, int k, int use_splitk);
+int hpc_gemm_bf16xfp32_async(void* y, void* splitk_y, void* split_flag, const void* x, const void* w_high,
+                             const void* w_low, int m, int n, int k, float scale, int use_fp32_output,
+                             int splits, int flag_ld, hpc_stream_t stream);
+
 /* ---- communicator: socket rendezvous + symmetric device buffers (HIP IPC over xGMI) ---------------
  * reference: src/communicator/{communicator,channel,listener,connector,protocol}.cc (rank-0 star over
  *            an abstract unix socket "unix://name" / bare name, or "tcp://ip:port"),

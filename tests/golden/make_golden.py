@@ -188,6 +188,20 @@ def golden_fp():
         assert torch.equal(q, qm) and torch.equal(kr, km) and torch.equal(vr, vm), pol
         st.update({f"rope_q_p{pol}": q.view(torch.int16).numpy(), f"rope_k_p{pol}": kr.view(torch.int16).numpy(),
                    f"rope_v_p{pol}": vr.view(torch.int16).numpy()})
+    # ---- router GEMM (tests/test_gemm_bf16xfp32.py:24-45: the oracle is inline there, reproduced literally) ----
+    from oracle import gemm as ogemm
+    torch.manual_seed(10086)
+    dtype = torch.bfloat16
+    x = torch.randn((6, 512), dtype=torch.float).to(dtype)
+    w = torch.randn((192, 512), dtype=torch.float)
+    scale = 1 / 256
+    w_high = w.to(torch.bfloat16)
+    w_low = ((w - w_high.float()) / scale).to(torch.bfloat16)
+    gt = torch.matmul(x.float(), w.t())
+    mh, ml = ogemm.split_weight(w, scale)
+    assert torch.equal(mh, w_high) and torch.equal(ml, w_low) and torch.equal(gt, ogemm.ground_truth(x, w))
+    st.update(rgemm_x=x.view(torch.int16).numpy(), rgemm_w=w.numpy(), rgemm_wh=w_high.view(torch.int16).numpy(),
+              rgemm_wl=w_low.view(torch.int16).numpy(), rgemm_gt=gt.numpy())
     np.savez_compressed(ROOT / "tests" / "golden" / "fp_golden.npz", **st)
     print("wrote fp_golden.npz:", len(st), "arrays")
 

@@ -163,3 +163,22 @@ def test_hip_rope_vs_reference_golden(policy):
     assert allclose(bf(f"rope_q_p{policy}"), q.cpu(), atol=8e-2)
     assert allclose(bf(f"rope_k_p{policy}"), kc.cpu(), atol=8e-2)
     assert torch.equal(bf(f"rope_v_p{policy}"), vc.cpu())
+
+
+# ---------------------------------------------------------------------------- router GEMM
+def test_oracle_router_gemm_matches_reference_output():
+    from oracle import gemm as ogemm
+
+    wh, wl = ogemm.split_weight(t("rgemm_w"), 1 / 256)
+    assert torch.equal(wh, bf("rgemm_wh")) and torch.equal(wl, bf("rgemm_wl"))
+    assert torch.equal(ogemm.ground_truth(bf("rgemm_x"), t("rgemm_w")), t("rgemm_gt"))
+    assert allclose(t("rgemm_gt"), ogemm.two_plane(bf("rgemm_x"), wh, wl, 1 / 256), rtol=0.08, atol=0.01)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fp32_out", [True, False])
+def test_hip_router_gemm_vs_reference_golden(fp32_out):
+    import hpc
+
+    y = hpc.gemm_bf16xfp32(bf("rgemm_x").cuda(), bf("rgemm_wh").cuda(), bf("rgemm_wl").cuda(), 1 / 256, fp32_out)
+    assert allclose(t("rgemm_gt"), y.float().cpu(), rtol=0.08, atol=0.01)
