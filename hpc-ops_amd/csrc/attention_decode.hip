@@ -27,6 +27,8 @@
 //  * fp8 numerics follow the reference kernels: scores scaled by
 //    qscale[row]*kscale/sqrt(d) in the exp2 domain, P~ = e4m3(256 * 2^(s - running max)),
 //    O = sum(P~ V) / sum(p) * vscale / 256.
+#include <type_traits>
+
 #include "hpc_common.h"
 #include "../../include/hpc_amd.h"
 #include "sched_task_info.h"
@@ -51,6 +53,7 @@ struct Args {
   const float* vscale;  // fp8: [1] or [Hkv]
   int num_batch, num_seq_q, num_head_kv, g_shift, page_shift, max_blocks;
   int ldq, ldy, qscale_stride;
+  int solo_ok;  // bins full of short tasks may run one task per wave (tuning key 5 = 1 turns it off)
   long k_block_stride, k_token_stride, k_head_stride;  // elements
   long v_block_stride, v_token_stride, v_head_stride;
   long ks_block_stride, ks_row_stride, ks_head_stride;  // bytes, per-token K scales
@@ -107,10 +110,39 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
   const uint8_t* kbase = static_cast<const uint8_t*>(a.kcache);
   const uint8_t* vbase = static_cast<const uint8_t*>(a.vcache);
 
-  for (int itask = 0; itask < per1; ++itask, task_ptr += kTaskStride) {
+  // ---- how many tasks does this bin hold, and how long is the longest? ------------------------------
+  // (lane-parallel scan of the bin's records; the list ends at the first h < 0 / b < 0 record)
+  int ntasks = 0, max_ntile = 0;
+  for (int base = 0; base < per1; base += 64) {
+    const int idx = base + lane;
+    int hh = -1, bb = -1, nt = 0;
+    if (idx < per1) {
+      const int* rec = a.task_map + static_cast<long>(kTaskStride) * (1 + static_cast<long>(bin) * per1 + idx);
+      hh = rec[0];
+      bb = rec[1];
+      nt = rec[6];
+    }
+    const uint64_t bad = __ballot(hh < 0 || bb < 0);
+    const int first = bad ? __builtin_ctzll(bad) : 64;
+    int mx = lane < first ? nt : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+    max_ntile = max(max_ntile, mx);
+    ntasks += first;
+    if (first < 64) break;
+  }
+  ntasks = __builtin_amdgcn_readfirstlane(ntasks);
+  max_ntile = __builtin_amdgcn_readfirstlane(max_ntile);
+
+  // One task, two ways to run it.  TEAM: the 4 waves take tiles w, w+4, ... and merge through LDS
+  // (long tasks: KV streaming).  SOLO: one wave runs the whole task alone and finishes it without
+  // any workgroup barrier, so 4 short tasks of a bin run side by side - a bin packed with short
+  // requests (mixed-length batches) would otherwise serialise ~5 us of latency chain per task.
+  auto run_task = [&](cint_ptr task_ptr, auto solo_c) {
+    constexpr bool kSolo = decltype(solo_c)::value;
+    const int t_first = kSolo ? 0 : wave, t_step = kSolo ? 1 : kWaves;
     const int h = __builtin_amdgcn_readfirstlane(task_ptr[0]);
     const int b = __builtin_amdgcn_readfirstlane(task_ptr[1]);
-    if (h < 0 || b < 0) break;
     const int ichunk = __builtin_amdgcn_readfirstlane(task_ptr[2]);
     const int iseq_start = __builtin_amdgcn_readfirstlane(task_ptr[3]);
     const int num_seqkv = __builtin_amdgcn_readfirstlane(task_ptr[4]);
@@ -224,7 +256,7 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
       l_run[nb] = 0.f;
     }
 
-    int t = wave;
+    int t = t_first;
     int pid[4], inpage[4];
     {
       const unsigned nrec = t < ntile ? 0xffffffffu : 0u;
@@ -237,9 +269,9 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
       load_v(pid, inpage, nrec);
       __builtin_amdgcn_sched_barrier(0);
     }
-    for (; t < ntile; t += kWaves) {
-      const unsigned nrec = t + kWaves < ntile ? 0xffffffffu : 0u;
-      tile_pages(t + kWaves < ntile ? t + kWaves : ntile - 1, pid, inpage);
+    for (; t < ntile; t += t_step) {
+      const unsigned nrec = t + t_step < ntile ? 0xffffffffu : 0u;
+      tile_pages(t + t_step < ntile ? t + t_step : ntile - 1, pid, inpage);
 
       // ---- S^T = K Q^T ------------------------------------------------------------------
       f32x4 s[kNB][4];
@@ -384,8 +416,31 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
       load_v(pid, inpage, nrec);
     }
 
-    // ---- merge the 4 waves of the workgroup, one 16-row q block at a time ---------------------------
     const int nchunks = chunk_tab[h * a.num_batch + b];
+    // final scaling + store of 8 output dims of one q row: bf16 y when the request is whole, fp32
+    // partial + lse otherwise (slot 1 of the bin for a request's first chunk, slot 0 for a later one)
+    auto emit = [&](int nb, int row16, int c8, float M, float L, float (&acc)[8]) {
+      const int row = nb * 16 + row16;
+      const float inv = (L > 0.f ? 1.0f / L : 0.f) * out_scale;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] *= inv;
+      if (row >= rows_valid) return;
+      if (nchunks == 1) {
+        const int rs = row >> a.g_shift;
+        uint16_t* dst = a.y + static_cast<long>(b * a.num_seq_q + rs) * a.ldy +
+                        ((h << a.g_shift) + (row & (G - 1))) * 128 + c8 * 8;
+        u32x4 pk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pk[i] = pack_bf16x2(acc[2 * i], acc[2 * i + 1]);
+        st16(dst, pk);
+      } else {
+        const long slot = static_cast<long>(bin) * 2 + (ichunk == 0 ? 1 : 0);
+        float* po = a.part_o + ((slot * kNB * 16) + row) * 128 + c8 * 8;
+        *reinterpret_cast<f32x4*>(po) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+        *reinterpret_cast<f32x4*>(po + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+        if (c8 == 0) a.part_lse[slot * kNB * 16 + row] = L > 0.f ? M + __builtin_amdgcn_logf(L) : kNegInf;
+      }
+    };
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) {
       float l = l_run[nb];
@@ -399,65 +454,66 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
       for (int jj = 0; jj < 8; ++jj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s_o[wave][n][8 * (g * 4 + r) + jj] = o[nb][jj][r];
-      __syncthreads();
-      {
-        const int row16 = tid >> 4;          // q row inside the block
-        const int row = nb * 16 + row16;     // q row of the group
-        const int c8 = tid & 15;             // chunk of 8 dims
-        float mw[kWaves], M = kNegInf;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-          mw[w] = s_m[w][row16];
-          M = fmaxf(M, mw[w]);
+      if constexpr (kSolo) {
+        // ---- the wave finishes its own task: re-read its tile row-major (LDS ops of a wave are in order)
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+          const int row16 = it * 4 + (lane >> 4), c8 = lane & 15;
+          const f32x4 x0 = *reinterpret_cast<const f32x4*>(&s_o[wave][row16][c8 * 8]);
+          const f32x4 x1 = *reinterpret_cast<const f32x4*>(&s_o[wave][row16][c8 * 8 + 4]);
+          float acc[8] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+          emit(nb, row16, c8, s_m[wave][row16], s_l[wave][row16], acc);
         }
-        const float Mu = M == kNegInf ? 0.f : M;
-        float L = 0.f, acc[8];
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see below
+      } else {
+        // ---- merge the 4 waves of the workgroup, one 16-row q block at a time -----------------------
+        __syncthreads();
+        {
+          const int row16 = tid >> 4;  // q row inside the block
+          const int c8 = tid & 15;     // chunk of 8 dims
+          float mw[kWaves], M = kNegInf;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int w = 0; w < kWaves; ++w) {
-          const float wgt = __builtin_amdgcn_exp2f(mw[w] - Mu);
-          L += wgt * s_l[w][row16];
-          const f32x4 x0 = *reinterpret_cast<const f32x4*>(&s_o[w][row16][c8 * 8]);
-          const f32x4 x1 = *reinterpret_cast<const f32x4*>(&s_o[w][row16][c8 * 8 + 4]);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            acc[i] = fmaf(wgt, x0[i], acc[i]);
-            acc[4 + i] = fmaf(wgt, x1[i], acc[4 + i]);
+          for (int w = 0; w < kWaves; ++w) {
+            mw[w] = s_m[w][row16];
+            M = fmaxf(M, mw[w]);
           }
-        }
-        const float inv = (L > 0.f ? 1.0f / L : 0.f) * out_scale;
+          const float Mu = M == kNegInf ? 0.f : M;
+          float L = 0.f, acc[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] *= inv;
-        if (row < rows_valid) {
-          if (nchunks == 1) {
-            const int rs = row >> a.g_shift;
-            uint16_t* dst = a.y + static_cast<long>(b * a.num_seq_q + rs) * a.ldy +
-                            ((h << a.g_shift) + (row & (G - 1))) * 128 + c8 * 8;
-            u32x4 pk;
+          for (int i = 0; i < 8; ++i) acc[i] = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pk[i] = pack_bf16x2(acc[2 * i], acc[2 * i + 1]);
-            st16(dst, pk);
-          } else {
-            const long slot = static_cast<long>(bin) * 2 + (ichunk == 0 ? 1 : 0);
-            float* po = a.part_o + ((slot * kNB * 16) + row) * 128 + c8 * 8;
-            *reinterpret_cast<f32x4*>(po) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-            *reinterpret_cast<f32x4*>(po + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
-            if (c8 == 0)
-              a.part_lse[slot * kNB * 16 + row] = L > 0.f ? M + __builtin_amdgcn_logf(L) : kNegInf;
+          for (int w = 0; w < kWaves; ++w) {
+            const float wgt = __builtin_amdgcn_exp2f(mw[w] - Mu);
+            L += wgt * s_l[w][row16];
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(&s_o[w][row16][c8 * 8]);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(&s_o[w][row16][c8 * 8 + 4]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              acc[i] = fmaf(wgt, x0[i], acc[i]);
+              acc[4 + i] = fmaf(wgt, x1[i], acc[4 + i]);
+            }
           }
+          emit(nb, row16, c8, M, L, acc);
         }
+        // gfx950 counts stores in vmcnt too; a store still pending when the next task starts makes
+        // hipcc treat the counter as out-of-order and degrade every wait in the tile loop to
+        // vmcnt(0).  Retire the epilogue stores here, where nothing else is in flight.
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+        __syncthreads();
       }
-      // gfx950 counts stores in vmcnt too; a store still pending when the next task starts makes
-      // hipcc treat the counter as out-of-order and degrade every wait in the tile loop to
-      // vmcnt(0).  Retire the epilogue stores here, where nothing else is in flight.
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-      __syncthreads();
     }
-    if (tid == 0 && nchunks > 1 && ichunk == 0) {
+    if ((kSolo ? lane == 0 : tid == 0) && nchunks > 1 && ichunk == 0) {
       a.first_bin[h * a.num_batch + b] = bin;
       __builtin_amdgcn_s_waitcnt(0x0F70);
     }
+  };
+
+  constexpr int kSoloMaxTiles = 4;  // up to here a lone wave is no slower than the team (1 tile per wave)
+  const bool solo = ntasks >= 2 && max_ntile <= kSoloMaxTiles && a.solo_ok;
+  if (solo) {
+    for (int it = wave; it < ntasks; it += kWaves) run_task(task_ptr + it * kTaskStride, std::true_type{});
+  } else {
+    for (int it = 0; it < ntasks; ++it) run_task(task_ptr + it * kTaskStride, std::false_type{});
   }
 }
 
@@ -480,26 +536,45 @@ __global__ __launch_bounds__(kThreads) void decode_combine_kernel(const Args a, 
   const int G = 1 << a.g_shift;
   const long rows_per_slot = num_nb * 16;
 
+  // chunks in batches with all loads of a batch in flight (a serial load->use chain costs one L2 /
+  // HBM round trip per chunk - 19 us for a 32-chunk request)
+  auto slot_of = [&](int c) { return static_cast<long>(fb + c) * 2 + (c == 0 ? 1 : 0); };
   float M = kNegInf;
-  for (int c = 0; c < nchunks; ++c) {
-    const long slot = static_cast<long>(fb + c) * 2 + (c == 0 ? 1 : 0);
-    M = fmaxf(M, a.part_lse[slot * rows_per_slot + row]);
+  for (int c0 = 0; c0 < nchunks; c0 += 8) {
+    float l8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = c0 + u < nchunks ? c0 + u : nchunks - 1;
+      l8[u] = a.part_lse[slot_of(c) * rows_per_slot + row];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) M = fmaxf(M, l8[u]);
   }
   const float Mu = M == kNegInf ? 0.f : M;
   float W = 0.f, acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  for (int c = 0; c < nchunks; ++c) {
-    const long slot = static_cast<long>(fb + c) * 2 + (c == 0 ? 1 : 0);
-    const float wgt = __builtin_amdgcn_exp2f(a.part_lse[slot * rows_per_slot + row] - Mu);
-    const float* po = a.part_o + (slot * rows_per_slot + row) * 128 + c8 * 8;
-    const f32x4 x0 = *reinterpret_cast<const f32x4*>(po);
-    const f32x4 x1 = *reinterpret_cast<const f32x4*>(po + 4);
-    W += wgt;
+  for (int c0 = 0; c0 < nchunks; c0 += 4) {
+    float l4[4];
+    f32x4 x0[4], x1[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc[i] = fmaf(wgt, x0[i], acc[i]);
-      acc[4 + i] = fmaf(wgt, x1[i], acc[4 + i]);
+    for (int u = 0; u < 4; ++u) {
+      const int c = c0 + u < nchunks ? c0 + u : nchunks - 1;
+      const long slot = slot_of(c);
+      l4[u] = a.part_lse[slot * rows_per_slot + row];
+      const float* po = a.part_o + (slot * rows_per_slot + row) * 128 + c8 * 8;
+      x0[u] = *reinterpret_cast<const f32x4*>(po);
+      x1[u] = *reinterpret_cast<const f32x4*>(po + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float wgt = c0 + u < nchunks ? __builtin_amdgcn_exp2f(l4[u] - Mu) : 0.f;
+      W += wgt;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        acc[i] = fmaf(wgt, x0[u][i], acc[i]);
+        acc[4 + i] = fmaf(wgt, x1[u][i], acc[4 + i]);
+      }
     }
   }
   const float inv = W > 0.f ? 1.0f / W : 0.f;
@@ -595,6 +670,7 @@ inline Common fill_common(Args& a, void* y_ptr, void* workspace, const int* task
   a.g_shift = group == 8 ? 3 : 2;
   a.page_shift = block_size == 64 ? 6 : (block_size == 32 ? 5 : 4);
   a.max_blocks = num_seq_max_blocks;
+  a.solo_ok = hpc_tuning_get(5) != 1;
   a.ldq = ldQ;
   a.ldy = ldY;
   a.qscale_stride = 0;

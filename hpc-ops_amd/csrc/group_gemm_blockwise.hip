@@ -25,7 +25,7 @@ namespace ggemm {
 
 
 constexpr int kThreads = 256;
-constexpr int kDepth = 4;     // stages in flight per wave; one stage = 2 k-blocks = 256 B per weight row
+// stages in flight per wave (template kDepth, default 4); one stage = 2 k-blocks = 256 B per weight row
 constexpr int kXRow = 272;    // LDS bytes per staged activation row (256 + 16: conflict-free b128 reads)
 
 __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
@@ -42,15 +42,20 @@ __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
 // quarter at the same prefetch depth as the weights (vmcnt retires in order - a shallower
 // activation pipeline would drain the weight stream), drops it into a double-buffered LDS tile,
 // and after ONE barrier per stage all waves read their B operands from LDS.
-template <int kMT, int kR>
-__global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockwise_stream_kernel(const Args a) {
+// kWaves = 4 or 8 waves per workgroup; with 8 the activation staging is spread over twice the lanes
+// (half the staging registers per lane) - that is what makes 64 tokens per pass fit without spills.
+template <int kMT, int kR, int kWaves = 4, int kDepth = 4>
+__global__ __launch_bounds__(64 * kWaves, (kWaves == 8 || kMT * kR >= 8) ? 1 : 2) void gemm_blockwise_stream_kernel(
+    const Args a) {
   constexpr int kTok = 16 * kMT;
+  constexpr int kXI = 4 * kMT / kWaves;  // activation staging instructions (4 rows x 256 B each) per wave
+  static_assert(kXI >= 1, "need at least one staging instruction per wave");
   __shared__ __attribute__((aligned(16))) uint8_t s_x[2][kTok * kXRow];
   __shared__ float s_xs[2][2][kTok];
   // wave-private 16-row x 256-byte weight tile (double-buffered): weights are fetched with full-row
   // loads (16 lanes x 16 B per row segment - the access shape that streams fastest, see
   // attention_decode.hip) and reach the MFMA A-operand layout through this tile; no barrier needed.
-  __shared__ __attribute__((aligned(16))) uint8_t s_w[4][2][16 * kXRow];
+  __shared__ __attribute__((aligned(16))) uint8_t s_w[kWaves][2][16 * kXRow];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -59,7 +64,7 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
   const int e = blockIdx.y;
   const int m_cnt = as_const(a.seqlens)[e];
   if (m_cnt <= 0) return;
-  const int n0 = (blockIdx.x * 4 + wave) * 16 * kR;  // N % 128 == 0 is checked by the launcher
+  const int n0 = (blockIdx.x * kWaves + wave) * 16 * kR;  // N % 128 == 0 is checked by the launcher
   const int m0 = as_const(a.cu_seqlens)[e];
   const int K = a.K, KB = a.KB;  // KB = ceil(K / 128)
   const int nstage = (KB + 1) >> 1;
@@ -75,12 +80,12 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
   const int npass = (m_cnt + kTok - 1) / kTok;
   for (int p = 0; p < npass; ++p) {
     // ---- this lane's roles in staging the activation tile ------------------------------------------
-    // x rows: instruction i = wave*kMT + j loads tile rows 4i .. 4i+3, lane -> (row 4i + g4, chunk r16)
-    unsigned x_voff[kMT];
-    int x_lds[kMT];
+    // x rows: instruction i = wave*kXI + j loads tile rows 4i .. 4i+3, lane -> (row 4i + g4, chunk r16)
+    unsigned x_voff[kXI];
+    int x_lds[kXI];
 #pragma unroll
-    for (int j = 0; j < kMT; ++j) {
-      const int trow = 4 * (wave * kMT + j) + g4;
+    for (int j = 0; j < kXI; ++j) {
+      const int trow = 4 * (wave * kXI + j) + g4;
       const int slot = p * kTok + trow;
       const int sc = slot < m_cnt ? slot : m_cnt - 1;
       const int xrow = a.row_index ? a.row_index[m0 + sc] : m0 + sc;
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
     }
 
     u32x4 wb[kDepth][2][kR][2];  // [stage][k-block of the stage][row block][64-byte half]
-    u32x4 xb[kDepth][kMT];
+    u32x4 xb[kDepth][kXI];
     float xsb[kDepth];
     auto issue = [&](int d, int st) {
       const int kb0 = 2 * st;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
       const auto rx = make_rsrc(a.x, a.x_bytes);
       const bool x_ok = koff + r16 * 16 < K;
 #pragma unroll
-      for (int j = 0; j < kMT; ++j) xb[d][j] = buf_ld16<0>(rx, x_ok ? x_voff[j] : 0xffffff00u, koff);
+      for (int j = 0; j < kXI; ++j) xb[d][j] = buf_ld16<0>(rx, x_ok ? x_voff[j] : 0xffffff00u, koff);
       const auto rs = make_rsrc(a.xs, (a.has_xs && xs_role && kb0 + wave < KB) ? 0xffffffffu : 0u);
       xsb[d] = __uint_as_float(
           __builtin_amdgcn_raw_buffer_load_b32(rs, xs_voff, (kb0 + wave) * xs_kb_bytes, 0));
@@ -141,17 +146,17 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
 #pragma unroll
       for (int d = 0; d < kDepth; ++d) {
         const int st = st0 + d;
-        const int buf = d & 1;  // kDepth is even, so stage parity == d parity
+        const int buf = (kDepth & 1) ? (st & 1) : (d & 1);  // stage parity (== d parity when kDepth is even)
         // stage my quarter of the activation tile, then one barrier for the whole workgroup
 #pragma unroll
-        for (int j = 0; j < kMT; ++j)
+        for (int j = 0; j < kXI; ++j)
           *reinterpret_cast<u32x4*>(&s_x[buf][x_lds[j]]) = xb[d][j];
         if (xs_role) s_xs[buf][wave][lane] = xsb[d];
         // weights: full-row layout -> MFMA A-operand layout (lane (r16, g4): row r16, chunk kbl*8+h*4+g4)
         u32x4 wf[kR][2][2];
 #pragma unroll
         for (int rb = 0; rb < kR; ++rb) {
-          uint8_t* wt = s_w[wave][(rb + d) & 1];
+          uint8_t* wt = s_w[wave][(rb + buf) & 1];
 #pragma unroll
           for (int qd = 0; qd < 4; ++qd)
             *reinterpret_cast<u32x4*>(wt + (4 * qd + g4) * kXRow + r16 * 16) = wb[d][qd >> 1][rb][qd & 1];
@@ -167,25 +172,44 @@ __global__ __launch_bounds__(kThreads, (kMT * kR >= 8) ? 1 : 2) void gemm_blockw
           const int kb = 2 * st + kbl;
           const int kbc = kb < KB ? kb : KB - 1;
           const float wsk = kb < KB ? __int_as_float(ws_row[kbc * a.ws_kb_stride]) : 0.f;
+          // token blocks two at a time: their MFMA chains (4 dependent k-steps each) interleave
+          constexpr int kPair = kMT >= 2 ? 2 : 1;
 #pragma unroll
-          for (int mt = 0; mt < kMT; ++mt) {
-            const uint8_t* xp = &s_x[buf][(mt * 16 + r16) * kXRow + kbl * 128 + g4 * 16];
-            const u32x4 b0 = *reinterpret_cast<const u32x4*>(xp);
-            const u32x4 b1 = *reinterpret_cast<const u32x4*>(xp + 64);
-            const float f = a.has_xs ? s_xs[buf][kbl][mt * 16 + r16] * wsk : wsk;
+          for (int mt0 = 0; mt0 < kMT; mt0 += kPair) {
+            u32x4 b0[kPair], b1[kPair];
+            float f[kPair];
+#pragma unroll
+            for (int q = 0; q < kPair; ++q) {
+              const uint8_t* xp = &s_x[buf][((mt0 + q) * 16 + r16) * kXRow + kbl * 128 + g4 * 16];
+              b0[q] = *reinterpret_cast<const u32x4*>(xp);
+              b1[q] = *reinterpret_cast<const u32x4*>(xp + 64);
+              f[q] = a.has_xs ? s_xs[buf][kbl][(mt0 + q) * 16 + r16] * wsk : wsk;
+            }
 #pragma unroll
             for (int rb = 0; rb < kR; ++rb) {
-              f32x4 part = f32x4{0.f, 0.f, 0.f, 0.f};
-              part = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                  pack64(wf[rb][kbl][0][0], wf[rb][kbl][0][1]), pack64(b0[0], b0[1]), part, 0, 0, 0);
-              part = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                  pack64(wf[rb][kbl][0][2], wf[rb][kbl][0][3]), pack64(b0[2], b0[3]), part, 0, 0, 0);
-              part = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                  pack64(wf[rb][kbl][1][0], wf[rb][kbl][1][1]), pack64(b1[0], b1[1]), part, 0, 0, 0);
-              part = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-                  pack64(wf[rb][kbl][1][2], wf[rb][kbl][1][3]), pack64(b1[2], b1[3]), part, 0, 0, 0);
+              f32x4 part[kPair];
 #pragma unroll
-              for (int i = 0; i < 4; ++i) tot[rb][mt][i] = fmaf(part[i], f, tot[rb][mt][i]);
+              for (int q = 0; q < kPair; ++q) part[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+              for (int q = 0; q < kPair; ++q)
+                part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                    pack64(wf[rb][kbl][0][0], wf[rb][kbl][0][1]), pack64(b0[q][0], b0[q][1]), part[q], 0, 0, 0);
+#pragma unroll
+              for (int q = 0; q < kPair; ++q)
+                part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                    pack64(wf[rb][kbl][0][2], wf[rb][kbl][0][3]), pack64(b0[q][2], b0[q][3]), part[q], 0, 0, 0);
+#pragma unroll
+              for (int q = 0; q < kPair; ++q)
+                part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                    pack64(wf[rb][kbl][1][0], wf[rb][kbl][1][1]), pack64(b1[q][0], b1[q][1]), part[q], 0, 0, 0);
+#pragma unroll
+              for (int q = 0; q < kPair; ++q)
+                part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                    pack64(wf[rb][kbl][1][2], wf[rb][kbl][1][3]), pack64(b1[q][2], b1[q][3]), part[q], 0, 0, 0);
+#pragma unroll
+              for (int q = 0; q < kPair; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) tot[rb][mt0 + q][i] = fmaf(part[q][i], f[q], tot[rb][mt0 + q][i]);
             }
             __builtin_amdgcn_sched_barrier(0);  // stop hipcc hoisting every LDS read of the stage (VGPRs)
           }
@@ -227,17 +251,26 @@ int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const v
   // tileM the same way, fuse_moe/entry.cc:525-543); larger groups take several passes
   const int avg = m / num_group;
   const int forced = hpc_tuning_get(1);
-  const int mt = forced ? forced : (avg <= 10 ? 1 : 2);  // 64 tokens/pass (mt 4) is experimental: register-bound
-  // 64 tokens per pass needs the whole register file of a SIMD (1 workgroup per CU, 32 rows per
-  // wave); 16 / 32 tokens run 2 workgroups per CU with 16 rows per wave
-  const int r = (mt == 4 && n % 128 == 0) ? 2 : 1;
-  dim3 grid(n / (64 * r), num_group);
-  if (mt == 1)
-    gemm_blockwise_stream_kernel<1, 1><<<grid, kThreads, 0, stream>>>(a);
-  else if (mt == 2 || r == 1)
-    gemm_blockwise_stream_kernel<2, 1><<<grid, kThreads, 0, stream>>>(a);
-  else
+  // forced: 1 / 2 / 4 = tokens-per-pass 16 / 32 / 64 with 16 rows per wave; 8 = 64 tokens, 32 rows per wave
+  const int mt = forced ? forced : (avg <= 10 ? 1 : 2);
+  if (mt == 8 && n % 128 == 0) {
+    dim3 grid(n / 128, num_group);
     gemm_blockwise_stream_kernel<4, 2><<<grid, kThreads, 0, stream>>>(a);
+  } else if (mt == 16 && n % 128 == 0) {  // 64 tokens per pass, 8 waves x 16 rows
+    dim3 grid(n / 128, num_group);
+    gemm_blockwise_stream_kernel<4, 1, 8, 3><<<grid, 512, 0, stream>>>(a);
+  } else if (mt == 32 && n % 128 == 0) {  // 32 tokens per pass, 8 waves x 16 rows
+    dim3 grid(n / 128, num_group);
+    gemm_blockwise_stream_kernel<2, 1, 8><<<grid, 512, 0, stream>>>(a);
+  } else {
+    dim3 grid(n / 64, num_group);
+    if (mt == 1)
+      gemm_blockwise_stream_kernel<1, 1><<<grid, kThreads, 0, stream>>>(a);
+    else if (mt == 4)
+      gemm_blockwise_stream_kernel<4, 1, 4, 3><<<grid, kThreads, 0, stream>>>(a);
+    else
+      gemm_blockwise_stream_kernel<2, 1><<<grid, kThreads, 0, stream>>>(a);
+  }
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }

@@ -124,3 +124,20 @@ def test_attn_bf16_errors():
     kv = torch.randn(4, 64, 1, 128, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(RuntimeError):  # group 3
         hpc.attention_decode_bf16(q, kv, kv, bid, lens)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_seq_q", [1, 2, 5])
+@pytest.mark.parametrize("kvcache_shape", ["NHD", "HND"])
+@pytest.mark.parametrize("solo", [True, False])
+def test_attn_bf16_bins_of_short_requests(num_seq_q, kvcache_shape, solo):
+    """Bins packed with 1-4 tile tasks run one task per wave (min_process_len 512 packs 8 tiles per
+    bin); tuning key 5 = 1 forces the 4-wave team path on the same inputs."""
+    import hpc
+
+    lens = torch.tensor([3, 64, 65, 128, 200, 250, 17, 1] * 6 + [5000], dtype=torch.int32)
+    hpc._C.lib.hpc_tuning_set(5, 0 if solo else 1)
+    try:
+        _run(len(lens), num_seq_q, lens, 64, (2, 16), True, False, True, kvcache_shape, min_process_len=512)
+    finally:
+        hpc._C.lib.hpc_tuning_set(5, 0)

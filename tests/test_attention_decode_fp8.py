@@ -117,3 +117,20 @@ def test_attn_fp8_kpertoken(num_batch, num_seq_q, kv_head_q_head, use_dynamic_sc
 def test_attn_fp8_small_pages_and_split(k_per_token, block_size):
     lens = torch.tensor([9000, 3, 130, 65, 2049], dtype=torch.int32)
     _run(5, 2, lens, block_size, (2, 16), k_per_token, False, True, "NHD", 0.2 if not k_per_token else 0.1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k_per_token", [False, True])
+@pytest.mark.parametrize("num_seq_q", [1, 3])
+@pytest.mark.parametrize("solo", [True, False])
+def test_attn_fp8_bins_of_short_requests(k_per_token, num_seq_q, solo):
+    """Many short requests + one long one: bins packed with 1-4 tile tasks run one task per wave
+    (no workgroup merge); tuning key 5 = 1 forces the team path on the same inputs."""
+    import hpc
+
+    lens = torch.tensor([3, 64, 65, 128, 200, 250, 17, 1] * 6 + [5000], dtype=torch.int32)
+    hpc._C.lib.hpc_tuning_set(5, 0 if solo else 1)
+    try:
+        _run(len(lens), num_seq_q, lens, 64, (2, 16), k_per_token, True, True, "NHD", 0.1 if k_per_token else 0.2)
+    finally:
+        hpc._C.lib.hpc_tuning_set(5, 0)

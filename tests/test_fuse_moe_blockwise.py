@@ -90,9 +90,15 @@ def test_moe_routing_is_bit_exact():
 @pytest.mark.gpu
 @pytest.mark.parametrize("num_group,actual_m,n,k", [(16, 30, 1024, 4096), (8, 5, 256, 512),
                                                     (4, 70, 384, 1408)])
-def test_group_gemm_blockwise(num_group, actual_m, n, k):
+@pytest.mark.parametrize("forced_mt", [0, 1, 2, 4, 16, 32])
+def test_group_gemm_blockwise(num_group, actual_m, n, k, forced_mt):
+    """forced_mt pins one streaming-kernel variant (tuning key 1: tokens per pass / waves per workgroup),
+    0 = the launcher's own choice; every variant must meet the same bar."""
     import hpc
     from oracle import fuse_moe as omoe
+
+    if forced_mt >= 16 and n % 128:
+        pytest.skip("8-wave variants need n % 128 == 0")
 
     torch.manual_seed(0)
     seqlens = torch.full((num_group,), actual_m, dtype=torch.int32)
@@ -113,9 +119,13 @@ def test_group_gemm_blockwise(num_group, actual_m, n, k):
     for g in range(num_group):
         c0 = int(cu_tiles[g]) * tile_m
         xs_t[:, c0 : c0 + int(seqlens[g])] = xs_rows[int(cu[g]) : int(cu[g]) + int(seqlens[g])].t()
-    my = hpc.group_gemm_blockwise_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), xs_t.cuda(),
-                                      wscale.cuda(), num_seq_per_group_avg=actual_m)
-    torch.cuda.synchronize()
+    hpc._C.lib.hpc_tuning_set(1, forced_mt)
+    try:
+        my = hpc.group_gemm_blockwise_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), xs_t.cuda(),
+                                          wscale.cuda(), num_seq_per_group_avg=actual_m)
+        torch.cuda.synchronize()
+    finally:
+        hpc._C.lib.hpc_tuning_set(1, 0)
     assert allclose(gt.float(), my.cpu().float(), rtol=0.01, atol=0.02)
 
 

@@ -1,0 +1,122 @@
+"""SURVEY 8(d) measurement sweep on one MI355X: every hot-path config with its roofline figure.
+Writes gpurun_out/suite.json (copy to profiles/<round>_suite.json).  Development / reporting tool:
+not product, not a test.  usage: python tools/suite.py [--quick]"""
+import json
+import math
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "hpc-ops_amd"))
+sys.path.insert(0, str(ROOT))
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+import hpc  # noqa: E402
+
+dev = torch.device("cuda", 0)
+F8 = torch.float8_e4m3fn
+HBM = 8000.0
+out = {}
+
+
+def pages(lens, P, gen_dev=dev):
+    nbl = (lens + P - 1) // P
+    total = int(nbl.sum())
+    nblk = int(total * 1.2) + len(lens) + 8
+    bid = torch.zeros(len(lens), int(nbl.max()), dtype=torch.int32, device=gen_dev)
+    perm = torch.randperm(nblk, device=gen_dev).to(torch.int32)
+    off = 0
+    for i, n in enumerate(nbl.tolist()):
+        bid[i, :n] = perm[off : off + n]
+        off += n
+    return bid, nblk
+
+
+def decode_case(name, lens_c, Hkv, Hq, layout, fp8, minlen, sq=1):
+    P, D = 64, 128
+    B = len(lens_c)
+    torch.manual_seed(41)
+    bid, nblk = pages(lens_c, P)
+    shape = (nblk, P, Hkv, D) if layout == "NHD" else (nblk, Hkv, P, D)
+    k = torch.randn(shape, device=dev, dtype=torch.bfloat16) / math.sqrt(D)
+    v = torch.randn(shape, device=dev, dtype=torch.bfloat16)
+    if fp8:
+        k, v = (k * 8).to(F8), v.to(F8)
+    if layout == "HND":
+        k, v = k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)
+    lens = lens_c.to(dev)
+    tm = hpc.get_attention_decode_task_workspace(B, int(lens_c.max()), Hkv, minlen)
+    sched_us = bench.timed(lambda: hpc.assign_attention_decode_task(lens, tm, Hkv, sq, True, minlen), graph=True, reps=10)
+    hpc.assign_attention_decode_task(lens, tm, Hkv, sq, True, minlen)
+    o = torch.empty(B * sq, Hq, D, dtype=torch.bfloat16, device=dev)
+    if fp8:
+        q = torch.randn(B * sq, Hq, D, device=dev).to(F8)
+        qs = torch.rand(B * sq, Hq, device=dev) * 0.01 + 0.005
+        ks, vs = torch.tensor([0.02], device=dev), torch.tensor([0.03], device=dev)
+        fn = lambda: hpc.attention_decode_fp8(q, k, v, bid, lens, qs, ks, vs, sq - 1, True,  # noqa: E731
+                                              hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, True, tm, None, o)
+    else:
+        q = torch.randn(B * sq, Hq, D, dtype=torch.bfloat16, device=dev) / math.sqrt(D)
+        fn = lambda: hpc.attention_decode_bf16(q, k, v, bid, lens, sq - 1, True, True, tm, None, o)  # noqa: E731
+    us = bench.timed(fn, graph=True, reps=4 if int(lens_c.sum()) < 200000 else 1)
+    kvb = int(lens_c.sum()) * Hkv * 2 * D * (1 if fp8 else 2) + 2 * B * sq * Hq * D * (1.5 if fp8 else 2)
+    out[name] = {"us": round(us, 1), "GBps": round(kvb / us / 1e3, 1), "hbm_frac": round(kvb / us / 1e3 / HBM, 3),
+                 "scheduler_us": round(sched_us, 1), "bytes": int(kvb)}
+    print(name, out[name], flush=True)
+
+
+def main():
+    quick = "--quick" in sys.argv
+    B = 64
+    g = torch.Generator().manual_seed(41)
+    uni8k = torch.full((B,), 8192, dtype=torch.int32)
+    uni4k = torch.full((B,), 4096, dtype=torch.int32)
+    rnd = torch.randint(1, 8192, (B,), generator=g).to(torch.int32)
+    logu = torch.exp(torch.rand(B, generator=g) * (math.log(32768) - math.log(128)) + math.log(128)).to(torch.int32)
+    # ---- C2: bf16 decode (benchmark/attention_decode/bench_attention_decode_bf16.py cases) ----
+    for nm, lens in (("uniform8k", uni8k), ("uniform4k", uni4k), ("randint_1_8192", rnd)):
+        for layout in ("NHD", "HND"):
+            decode_case(f"C2_bf16_{nm}_g8_{layout}", lens, 8, 64, layout, False, 64)
+        if not quick:
+            decode_case(f"C2_bf16_{nm}_g4_NHD", lens, 8, 32, "NHD", False, 64)
+    decode_case("C2_bf16_uniform8k_g8_NHD_mtp1", uni8k, 8, 64, "NHD", False, 64, sq=2)
+    # ---- C3: fp8 decode, dynamic scheduler (bench_attention_decode_fp8.py:57-67 cases + log-uniform) ----
+    cases = {
+        "skewed_mix_32x128_32x4k": [128] * 32 + [4096] * 32,
+        "skewed_extreme_15x64_1x16k": [64] * 15 + [16384],
+        "two_32k_30x4k": [32768] * 2 + [4096] * 30,
+        "one_64k_31x4k": [65536] + [4096] * 31,
+        "loguniform_128_32k_x64": logu.tolist(),
+        "uniform8k_x64": [8192] * 64,
+    }
+    for nm, ll in cases.items():
+        lens = torch.tensor(ll, dtype=torch.int32)
+        for hkv, hq in ((8, 64), (1, 8)):
+            if quick and hkv == 1:
+                continue
+            decode_case(f"C3_fp8_{nm}_h{hkv}_{hq}_NHD", lens, hkv, hq, "NHD", True, 512)
+    decode_case("C3_fp8_loguniform_128_32k_x64_h8_64_HND", logu, 8, 64, "HND", True, 512)
+    # ---- C4: fused MoE blockwise ----
+    toks = (4, 16, 64, 128, 256, 1024, 4096) if not quick else (16, 256)
+    out.update(bench.extra_moe(dev, hpc, tokens=toks))
+    # ---- C1: RMSNorm + fp8 quant ----
+    torch.manual_seed(0)
+    x = torch.randn(1024, 4096, device=dev).bfloat16()
+    w = torch.rand(1, 4096, device=dev).bfloat16()
+    for nm, sc, moe in (("C1_rmsnorm_fp8", [2.5], False), ("C1_rmsnorm_fp8_moe", [2.5, 5.0], True)):
+        s = torch.tensor(sc, device=dev)
+        us = bench.timed(lambda: hpc.fused_rmsnorm_with_scale(x, w, 1e-6, s, moe), graph=True, reps=20)
+        byt = 1024 * 4096 * (3 + (5 if moe else 0)) + 8192
+        out[nm] = {"us": round(us, 2), "GBps": round(byt / us / 1e3, 1)}
+        print(nm, out[nm], flush=True)
+    # ---- widening rows ----
+    out.update(bench.extra_rope(dev, hpc))
+    out.update(bench.extra_router_gemm(dev, hpc))
+    Path(ROOT / "gpurun_out").mkdir(exist_ok=True)
+    (ROOT / "gpurun_out" / "suite.json").write_text(json.dumps(out, indent=1))
+    print("wrote gpurun_out/suite.json")
+
+
+if __name__ == "__main__":
+    main()
