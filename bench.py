@@ -213,6 +213,25 @@ def extra_router_gemm(dev, hpc):
     return {"gemm_bf16xfp32_n256_k4096": out}
 
 
+def extra_sampler(dev, hpc):
+    """fused_sampler, V = 120832 fp32 logits (reference vocabulary); bytes = logits (+ noise when injected)."""
+    out = {}
+    V = 120832
+    torch.manual_seed(41)
+    for B in (1, 64):
+        logits = torch.randn(B, V, device=dev)
+        u = torch.rand(B, V, device=dev).clamp_min_(1e-20)
+        gum = -(-u.log()).log()
+        topk = torch.full((B,), 20, dtype=torch.int32, device=dev)
+        topp = torch.full((B,), 0.9, device=dev)
+        us = timed(lambda: hpc.fused_sampler(logits, temperature=0.7, softmax_policy=2, topk=topk, topp=topp,
+                                             max_topk=32, gumbel_noise=gum), graph=True, reps=10)
+        out[f"topk_topp_B{B}"] = {"us": round(us, 1), "GBps": round(B * V * 4 / us / 1e3, 1)}
+        us = timed(lambda: hpc.fused_sampler(logits, temperature=0.7, seed=7), graph=True, reps=10)
+        out[f"temperature_own_noise_B{B}"] = {"us": round(us, 1), "GBps": round(B * V * 4 / us / 1e3, 1)}
+    return {"fused_sampler_V120832": out}
+
+
 def extra_moe(dev, hpc, tokens=(16, 64, 256, 4096)):
     """fused MoE FP8 blockwise, BASELINE configs[3]: 64 experts top-8, hidden 4096, ffn 11008."""
     E, k, H, I = 64, 8, 4096, 11008
@@ -422,9 +441,9 @@ def main():
             ar = {"fuse_allreduce_rmsnorm": {"error": repr(e)[:200]}}
         extras.update(ar)
 
-    if rank == 0 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras:  # N-independent single-GPU numbers: reported at N=1
         del graph
-        for fn in (extra_decode, extra_moe, extra_rope, extra_router_gemm):
+        for fn in (extra_decode, extra_moe, extra_rope, extra_router_gemm, extra_sampler):
             try:
                 extras.update(fn(dev, hpc))
             except Exception as e:  # noqa: BLE001
@@ -460,7 +479,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBPS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": nbytes,
-                "kernel": "hpc::decode::decode_bf16_kernel<1> (+ combine), HIP events per launch",
+                "kernel": "hpc::decode::decode_kernel<false,1,1,2> (+ decode_combine_kernel), HIP events per launch",
             },
             "cpu_baseline": cpu,
             "extras": extras,

@@ -262,6 +262,31 @@ int hpc_gemm_bf16xfp32_async(void* y, void* splitk_y, void* split_flag, const vo
                              const void* w_low, int m, int n, int k, float scale, int use_fp32_output,
                              int splits, int flag_ld, hpc_stream_t stream);
 
+/* ---- fused sampler (end of the decode step) ----
+ * reference: fused_sampler_async / fused_sampler_temperature_async, src/sampler/sampler.h:17-45
+ *            (kernels src/sampler/fused_sampler.cu, fused_sampler_temperature.cu; entry src/sampler/entry.cc).
+ * logits [B, V] fp32 (dtype 0) or bf16 (1), inner stride 1, row stride in elements; V % 8 == 0, V < 2^20.
+ * Pipeline: repetition penalty (bit mask rows selected by slot_id) -> temperature -> [softmax over V,
+ * policy 1] -> top-k (k <= max_topk in {32, 64}; 0 / out of range = max_topk) -> [softmax over the top-k,
+ * policy 2] -> top-p -> Gumbel-max (gumbel_noise [B, V] fp32, or Philox noise from rng_seed when null) ->
+ * token_ids int32 [B] and the sampled token's bit OR-ed into its penalty row.  Ties resolve towards the
+ * smaller token id.  workspace: hpc_fused_sampler_workspace_bytes (full sampler) or
+ * batch_size * hpc_sampler_segments(V) * 8 bytes (temperature path). */
+int hpc_sampler_segments(int vocab_size);
+int64_t hpc_fused_sampler_workspace_bytes(int batch_size, int vocab_size, int max_topk);
+int hpc_fused_sampler_async(void* token_ids, void* workspace, const void* logits, int logits_dtype,
+                            void* penalty_mask, int64_t penalty_mask_row_bytes, const void* slot_id,
+                            const void* repetition_penalty, float repetition_penalty_val,
+                            const void* temperature, float temperature_val, int softmax_policy,
+                            const void* topk, int topk_int_bytes, int topk_val, const void* topp,
+                            float topp_val, const void* gumbel_noise, int batch_size, int vocab_size,
+                            int64_t logits_row_stride, int max_topk, uint64_t rng_seed, hpc_stream_t stream);
+int hpc_fused_sampler_temperature_async(void* token_ids, void* workspace, const void* logits,
+                                        int logits_dtype, int64_t logits_row_stride, const void* temperature,
+                                        float temperature_val, const void* gumbel_noise,
+                                        const void* draft_token_ids, int batch_size, int vocab_size,
+                                        uint64_t rng_seed, hpc_stream_t stream);
+
 /* ---- communicator: socket rendezvous + symmetric device buffers (HIP IPC over xGMI) ---------------
  * reference: src/communicator/{communicator,channel,listener,connector,protocol}.cc (rank-0 star over
  *            an abstract unix socket "unix://name" / bare name, or "tcp://ip:port"),

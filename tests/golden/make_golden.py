@@ -202,6 +202,51 @@ def golden_fp():
     assert torch.equal(mh, w_high) and torch.equal(ml, w_low) and torch.equal(gt, ogemm.ground_truth(x, w))
     st.update(rgemm_x=x.view(torch.int16).numpy(), rgemm_w=w.numpy(), rgemm_wh=w_high.view(torch.int16).numpy(),
               rgemm_wl=w_low.view(torch.int16).numpy(), rgemm_gt=gt.numpy())
+    # ---- fused sampler (tests/test_sampler.py:36-165, :430-436, :490-505) --------------------------------
+    from enum import IntEnum
+    from typing import Optional
+    from oracle import sampler as osamp
+
+    class SoftmaxPolicy(IntEnum):  # hpc/sampler.py:8-28 (the reference model only compares against it)
+        NONE = 0
+        BEFORE_TOPK = 1
+        AFTER_TOPK = 2
+
+    r = load("tests/test_sampler.py", ["ref_fused_sampler", "ref_temperature_sample",
+                                        "_ref_temperature_sample_with_mask"],
+             extra={"SoftmaxPolicy": SoftmaxPolicy, "Optional": Optional})
+    torch.manual_seed(99)
+    B, V = 3, 4096
+    logits = torch.randn(B, V)  # fp32 randn: no equal values, so torch.topk's tie order cannot matter
+    gum = osamp.gumbel0_like(logits)
+    pen = torch.randint(0, 256, (B + 2, V // 8)).to(torch.uint8)
+    slot = torch.tensor([4, 0, 2], dtype=torch.int32)
+    st.update(samp_logits=logits.numpy(), samp_gumbel=gum.numpy(), samp_pen=pen.numpy(), samp_slot=slot.numpy())
+    cfgs = [dict(), dict(softmax_policy=1, topk=20, topp=0.9), dict(softmax_policy=2, topk=50, topp=0.9, max_topk=64),
+            dict(softmax_policy=2, topk=torch.tensor([3, 20, 32]), topp=torch.tensor([0.5, 0.9, 0.2]), temperature=0.7,
+                 repetition_penalty=1.05, penalty_mask=pen, slot_id=slot)]
+    for i, cfg in enumerate(cfgs):
+        kw = dict(cfg)
+        kw["softmax_policy"] = SoftmaxPolicy(kw.get("softmax_policy", 0))
+        if "penalty_mask" in kw:
+            kw["penalty_mask"] = pen.clone()
+        ref_tok, ref_pen = r["ref_fused_sampler"](logits, gumbel_noise=gum, **kw)
+        mk = dict(cfg)
+        if "penalty_mask" in mk:
+            mk["penalty_mask"] = pen.clone()
+        my_tok, my_pen = osamp.ref_fused_sampler(logits, gumbel_noise=gum, **mk)
+        assert torch.equal(ref_tok, my_tok), (i, ref_tok, my_tok)
+        assert (ref_pen is None and my_pen is None) or torch.equal(ref_pen, my_pen)
+        st[f"samp_tok_{i}"] = ref_tok.numpy()
+        if ref_pen is not None:
+            st[f"samp_pen_{i}"] = ref_pen.numpy()
+    temp = torch.tensor([0.4, 1.0, 1.7])
+    draft = torch.tensor([int(logits[0].argmax()), -1, V + 5])
+    t_ref = r["ref_temperature_sample"](logits, temp, gum)
+    t_ref_m = r["_ref_temperature_sample_with_mask"](logits, temp, gum, draft, V)
+    assert torch.equal(t_ref, osamp.ref_temperature_sample(logits, temp, gum))
+    assert torch.equal(t_ref_m, osamp.ref_temperature_sample(logits, temp, gum, draft))
+    st.update(samp_temp=temp.numpy(), samp_draft=draft.numpy(), samp_ttok=t_ref.numpy(), samp_ttok_mask=t_ref_m.numpy())
     np.savez_compressed(ROOT / "tests" / "golden" / "fp_golden.npz", **st)
     print("wrote fp_golden.npz:", len(st), "arrays")
 

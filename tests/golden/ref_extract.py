@@ -16,10 +16,11 @@ import torch.nn.functional as F
 REF = Path("/root/reference")
 
 
-def load(rel_path, names):
+def load(rel_path, names, extra=None):
     src = (REF / rel_path).read_text()
     tree = ast.parse(src)
     ns = {"torch": torch, "math": math, "F": F, "Tuple": Tuple}
+    ns.update(extra or {})
     found = []
     for node in tree.body:
         if isinstance(node, ast.FunctionDef) and node.name in names:

@@ -182,3 +182,56 @@ def test_hip_router_gemm_vs_reference_golden(fp32_out):
 
     y = hpc.gemm_bf16xfp32(bf("rgemm_x").cuda(), bf("rgemm_wh").cuda(), bf("rgemm_wl").cuda(), 1 / 256, fp32_out)
     assert allclose(t("rgemm_gt"), y.float().cpu(), rtol=0.08, atol=0.01)
+
+
+# ---------------------------------------------------------------------------- fused sampler
+_SAMP_CFGS = [
+    dict(),
+    dict(softmax_policy=1, topk=20, topp=0.9),
+    dict(softmax_policy=2, topk=50, topp=0.9, max_topk=64),
+    dict(softmax_policy=2, topk=torch.tensor([3, 20, 32]), topp=torch.tensor([0.5, 0.9, 0.2]), temperature=0.7,
+         repetition_penalty=1.05, with_mask=True),
+]
+
+
+@pytest.mark.parametrize("i", range(4))
+def test_oracle_sampler_matches_reference_output(i):
+    from oracle import sampler as osamp
+
+    cfg = dict(_SAMP_CFGS[i])
+    if cfg.pop("with_mask", False):
+        cfg.update(penalty_mask=t("samp_pen"), slot_id=t("samp_slot"))
+    tok, pen = osamp.ref_fused_sampler(t("samp_logits"), gumbel_noise=t("samp_gumbel"), **cfg)
+    assert torch.equal(tok, t(f"samp_tok_{i}"))
+    if pen is not None:
+        assert torch.equal(pen, t(f"samp_pen_{i}"))
+    if i == 0:
+        assert torch.equal(osamp.ref_temperature_sample(t("samp_logits"), t("samp_temp"), t("samp_gumbel")),
+                           t("samp_ttok"))
+        assert torch.equal(osamp.ref_temperature_sample(t("samp_logits"), t("samp_temp"), t("samp_gumbel"),
+                                                        t("samp_draft")), t("samp_ttok_mask"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("i", range(4))
+def test_hip_sampler_vs_reference_golden(i):
+    import hpc
+
+    cfg = dict(_SAMP_CFGS[i])
+    pen = None
+    if cfg.pop("with_mask", False):
+        pen = t("samp_pen").cuda()
+        cfg.update(penalty_mask=pen, slot_id=t("samp_slot").cuda())
+    cfg = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in cfg.items()}
+    if "topk" in cfg and torch.is_tensor(cfg["topk"]):
+        cfg["topk"] = cfg["topk"].to(torch.int64)
+    cfg["softmax_policy"] = hpc.SoftmaxPolicy(cfg.get("softmax_policy", 0))
+    tok = hpc.fused_sampler(t("samp_logits").cuda(), gumbel_noise=t("samp_gumbel").cuda(), **cfg)
+    assert torch.equal(tok.cpu(), t(f"samp_tok_{i}"))
+    if pen is not None:
+        assert torch.equal(pen.cpu(), t(f"samp_pen_{i}"))
+    if i == 0:
+        lg, gm = t("samp_logits").cuda(), t("samp_gumbel").cuda()
+        assert torch.equal(hpc.fused_sampler(lg, temperature=t("samp_temp").cuda(), gumbel_noise=gm).cpu(), t("samp_ttok"))
+        assert torch.equal(hpc.fused_sampler(lg, temperature=t("samp_temp").cuda(), gumbel_noise=gm,
+                                             draft_token_ids=t("samp_draft").cuda()).cpu(), t("samp_ttok_mask"))
