@@ -232,6 +232,28 @@ def extra_sampler(dev, hpc):
     return {"fused_sampler_V120832": out}
 
 
+def extra_prefill(dev, hpc):
+    """attention_with_kvcache_prefill_fp8: 4 requests x 4096 tokens (q = kv, causal), Hq 64 / Hkv 8, pages of 64.
+    FLOPs = 4 * D * Hq * sum_b (Sq * (2L - Sq + 1) / 2)."""
+    B, S, Hq, Hkv, D, P = 4, 4096, 64, 8, 128, 64
+    torch.manual_seed(41)
+    q = (torch.randn(B * S, Hq, D, device=dev) / math.sqrt(D)).to(torch.float8_e4m3fn)
+    nb = S // P
+    kc = (torch.randn(B * nb + 8, P, Hkv, D, device=dev) / math.sqrt(D)).to(torch.float8_e4m3fn)
+    vc = torch.randn(B * nb + 8, P, Hkv, D, device=dev).to(torch.float8_e4m3fn)
+    bid = torch.randperm(B * nb + 8, device=dev)[: B * nb].to(torch.int32).reshape(B, nb).contiguous()
+    qs = torch.rand(B, Hq, S, device=dev) * 0.1 + 0.01
+    ks, vs = torch.tensor([0.5], device=dev), torch.tensor([0.7], device=dev)
+    cu = torch.arange(0, (B + 1) * S, S, dtype=torch.int32, device=dev)
+    lens = torch.full((B,), S, dtype=torch.int32, device=dev)
+    y = torch.empty(B * S, Hq, D, dtype=torch.bfloat16, device=dev)
+    us = timed(lambda: hpc.attention_with_kvcache_prefill_fp8(q, kc, vc, qs, ks, vs, cu, bid, lens, S, output=y),
+               iters=10, warm=2, graph=True)
+    flops = 4.0 * D * Hq * B * (S * (S + 1) / 2)
+    return {"attention_prefill_fp8_4x4096_h64_8": {"us": round(us, 1), "TFLOPS": round(flops / us / 1e6, 1),
+                                                    "mfma_frac_of_2.5PF": round(flops / us / 1e6 / 2500, 4)}}
+
+
 def extra_moe(dev, hpc, tokens=(16, 64, 256, 4096)):
     """fused MoE FP8 blockwise, BASELINE configs[3]: 64 experts top-8, hidden 4096, ffn 11008."""
     E, k, H, I = 64, 8, 4096, 11008
@@ -443,7 +465,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras:  # N-independent single-GPU numbers: reported at N=1
         del graph
-        for fn in (extra_decode, extra_moe, extra_rope, extra_router_gemm, extra_sampler):
+        for fn in (extra_decode, extra_moe, extra_rope, extra_router_gemm, extra_sampler, extra_prefill):
             try:
                 extras.update(fn(dev, hpc))
             except Exception as e:  # noqa: BLE001

@@ -1,0 +1,385 @@
+// Paged-KV causal prefill attention, FP8 (e4m3) Q/K/V, bf16 output - gfx950.
+//
+// Replaces reference attention_with_kvcache_prefill_*_fp8_async (src/attention/prefill/prefill.h,
+// kernels src/attention/prefill/sm90/**, entry src/attention/entry.cc:152-262): the chunked-prefill step
+// that runs before decode on the same paged cache (q tokens of request b are the LAST seqlen_q[b] of its
+// seqlens_kvcache[b] cached tokens; row s attends keys j <= (L_b - Sq_b) + s).
+//
+// MI355X design (first version): the decode kernel's tile machinery, re-mapped.  Same
+// MFMA orientation (64 KV tokens on M, q rows on N: S^T = K Q^T, O^T = V^T P^T with
+// v_mfma_f32_16x16x32_fp8_fp8), same full-row K loads transposed through a wave-private LDS tile, same
+// private 8x8 V byte transposes, same base-2 online softmax with P quantised as e4m3(256 p) against the
+// running max.  What changes: a wave owns 32 q rows (= 32/G consecutive positions x the G q heads of
+// one kv head), walks the KV tiles its rows can see (causal: fully visible tiles first, then the masked
+// ones) and finishes alone - no split-KV, no merge.  A workgroup = 4 waves = 128 consecutive rows that
+// share K/V tiles through L1/L2.  MFMA-bound shape; staging K/V once per workgroup in LDS is the
+// next step.
+#include "hpc_common.h"
+#include "../../include/hpc_amd.h"
+
+namespace hpc {
+namespace prefill {
+
+struct Args {
+  const void* q;
+  const void* kcache;
+  const void* vcache;
+  const int* block_ids;
+  const int* cu_seqlens_q;
+  const int* seqlens_kv;
+  uint16_t* y;
+  const float* qscale;  // [B][Hq][qs_pad]
+  const float* kscale;  // [1] or base of the per-token K-scale rows
+  const float* vscale;  // [1] or [Hkv]
+  int num_batch, num_head_q, num_head_kv, g_shift, page_shift, max_blocks, qs_pad;
+  int ldq, ldy;
+  long k_block_stride, k_token_stride, k_head_stride;  // elements (= bytes)
+  long v_block_stride, v_token_stride, v_head_stride;
+  long ks_block_stride, ks_row_stride, ks_head_stride;  // bytes
+  float scale_log2;
+};
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kNB = 2;                  // 16-row q blocks per wave
+constexpr int kRowsPerWave = 16 * kNB;  // 32
+constexpr float kNegInf = -__builtin_inff();
+constexpr int kKRow = 128 + 16;  // padded LDS row of the K transpose tile
+
+__device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
+  return static_cast<long>(static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32));
+}
+
+// kQuant 1: q per token / per head, k and v per tensor.  kQuant 0: k per token / per head (scales in
+// the page tail rows), v per kv head.
+template <int kQuant, int kAux>
+__global__ __launch_bounds__(kThreads, 1) void prefill_fp8_kernel(const Args a) {
+  __shared__ __attribute__((aligned(16))) float s_o[kWaves][16][128 + 4];
+  __shared__ float s_l[kWaves][16];
+  __shared__ __attribute__((aligned(16))) uint8_t s_kt[kWaves][2][16 * kKRow];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int G = 1 << a.g_shift;
+  const int q0 = as_const(a.cu_seqlens_q)[b];
+  const int Sq = as_const(a.cu_seqlens_q)[b + 1] - q0;
+  const int L = as_const(a.seqlens_kv)[b];
+  const int row0 = (blockIdx.x * kWaves + wave) * kRowsPerWave;  // first (position, head) row of this wave
+  const int pos_first = row0 >> a.g_shift;
+  if (pos_first >= Sq) return;
+  const int pos_last = min(Sq - 1, (row0 + kRowsPerWave - 1) >> a.g_shift);
+  const int past = L - Sq;  // cached tokens before the first q token
+  const int num_seqkv = past + pos_last + 1;             // keys any row of this wave can see
+  const int ntile = (num_seqkv + 63) >> 6;
+  const int ntile_full = max(past + pos_first + 1, 0) >> 6;  // tiles visible to every row: no mask needed
+  const int page_mask = (1 << a.page_shift) - 1;
+  const uint8_t* qbase = static_cast<const uint8_t*>(a.q);
+  const uint8_t* kbase = static_cast<const uint8_t*>(a.kcache);
+  const uint8_t* vbase = static_cast<const uint8_t*>(a.vcache);
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane (n, g) holds 16-byte chunks g and g+4 of row n ----
+  u32x4 qf[kNB][2];
+  float row_scale[kNB];
+  int row_pos[kNB];
+  bool row_ok[kNB];
+#pragma unroll
+  for (int nb = 0; nb < kNB; ++nb) {
+    const int row = row0 + nb * 16 + n;
+    const int pos = row >> a.g_shift;
+    const int hq = (h << a.g_shift) + (row & (G - 1));
+    row_ok[nb] = pos < Sq;
+    row_pos[nb] = pos;
+    const long qoff = static_cast<long>(q0 + pos) * a.ldq + hq * 128;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      qf[nb][c] = u32x4{0u, 0u, 0u, 0u};
+      if (row_ok[nb]) qf[nb][c] = ld16(qbase + qoff + (g + 4 * c) * 16);
+    }
+    float qs = row_ok[nb] ? a.qscale[(static_cast<long>(b) * a.num_head_q + hq) * a.qs_pad + pos] : 0.f;
+    if constexpr (kQuant == 1) qs *= a.kscale[0];
+    row_scale[nb] = a.scale_log2 * qs;
+  }
+  const float out_scale = (kQuant == 1 ? a.vscale[0] : a.vscale[h]) * (1.0f / 256.0f);
+
+  const cint_ptr bid_row = as_const(a.block_ids) + static_cast<long>(b) * a.max_blocks;
+  const int last_blk16 = (num_seqkv - 1) >> 4;
+  auto tile_pages = [&](int t, int (&pid)[4], int (&inpage)[4]) {
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      int blk = t * 4 + tb;
+      blk = blk < last_blk16 ? blk : last_blk16;
+      const int gtok = blk << 4;
+      pid[tb] = __builtin_amdgcn_readfirstlane(bid_row[gtok >> a.page_shift]);
+      inpage[tb] = gtok & page_mask;
+    }
+  };
+
+  u32x4 kf[4][2];
+  u32x2 vf8[2][8];
+  f32x4 ksc[kQuant == 0 ? 4 : 1];
+  const int k_chunk = lane & 7, k_rsub = lane >> 3;  // full-row K loads: 8 chunks x 8 rows per instruction
+  const int k_voff = k_rsub * static_cast<int>(a.k_token_stride) + k_chunk * 16;
+  const int k_ld_bytes = 8 * static_cast<int>(a.k_token_stride);
+  const int v_voff = g * 4 * static_cast<int>(a.v_token_stride) + n * 8;
+  const int v_tok_bytes = static_cast<int>(a.v_token_stride);
+  auto load_k = [&](const int (&pid)[4], const int (&inpage)[4], unsigned nrec) {
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      const auto rs = make_rsrc(kbase + pid[tb] * a.k_block_stride + inpage[tb] * a.k_token_stride +
+                                    h * a.k_head_stride, nrec);
+#pragma unroll
+      for (int c = 0; c < 2; ++c) kf[tb][c] = buf_ld16<kAux>(rs, k_voff, c * k_ld_bytes);
+      if constexpr (kQuant == 0) {
+        const auto rk = make_rsrc(reinterpret_cast<const uint8_t*>(a.kscale) + pid[tb] * a.ks_block_stride +
+                                      (inpage[tb] >> 5) * a.ks_row_stride + h * a.ks_head_stride +
+                                      (inpage[tb] & 31) * 4, nrec);
+        const u32x4 raw = buf_ld16<0>(rk, g * 16, 0);
+        ksc[tb] = f32x4{__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]),
+                        __uint_as_float(raw[3])};
+      }
+    }
+  };
+  auto load_v = [&](const int (&pid)[4], const int (&inpage)[4], unsigned nrec) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        const int tb = 2 * ks + hb;
+        const auto rs = make_rsrc(vbase + pid[tb] * a.v_block_stride + inpage[tb] * a.v_token_stride +
+                                      h * a.v_head_stride, nrec);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vf8[ks][hb * 4 + r] = buf_ld8<kAux>(rs, v_voff, r * v_tok_bytes);
+      }
+  };
+
+  f32x4 o[kNB][8];
+  float m_run[kNB], l_run[kNB];
+#pragma unroll
+  for (int nb = 0; nb < kNB; ++nb) {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) o[nb][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m_run[nb] = kNegInf;
+    l_run[nb] = 0.f;
+  }
+
+  int pid[4], inpage[4];
+  tile_pages(0, pid, inpage);
+  __builtin_amdgcn_sched_barrier(0);
+  load_k(pid, inpage, 0xffffffffu);
+  __builtin_amdgcn_sched_barrier(0);
+  load_v(pid, inpage, 0xffffffffu);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int t = 0; t < ntile; ++t) {
+    const unsigned nrec = t + 1 < ntile ? 0xffffffffu : 0u;
+    tile_pages(t + 1 < ntile ? t + 1 : ntile - 1, pid, inpage);
+
+    // ---- S^T = K Q^T --------------------------------------------------------------------------------
+    f32x4 s[kNB][4];
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      uint8_t* kt = s_kt[wave][tb & 1];
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        *reinterpret_cast<u32x4*>(kt + (c * 8 + k_rsub) * kKRow + k_chunk * 16) = kf[tb][c];
+      u32x4 ka[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) ka[c] = *reinterpret_cast<const u32x4*>(kt + n * kKRow + (g + 4 * c) * 16);
+#pragma unroll
+      for (int nb = 0; nb < kNB; ++nb) {
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(ka[c][0], ka[c][1]),
+                                                          pack64(qf[nb][c][0], qf[nb][c][1]), acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(ka[c][2], ka[c][3]),
+                                                          pack64(qf[nb][c][2], qf[nb][c][3]), acc, 0, 0, 0);
+        }
+        s[nb][tb] = acc;
+      }
+    }
+    f32x4 ksc_cur[kQuant == 0 ? 4 : 1];
+    if constexpr (kQuant == 0) {
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) ksc_cur[tb] = ksc[tb];
+    }
+    load_k(pid, inpage, nrec);
+
+    // ---- online softmax, base 2 ---------------------------------------------------------------------
+    uint32_t pf[kNB][2][2];
+    const bool masked = t >= ntile_full;
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) {
+      float mt = kNegInf;
+      const int lim = row_ok[nb] ? past + row_pos[nb] : -1;  // last visible key of this lane's q row
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = s[nb][tb][r] * row_scale[nb];
+          if constexpr (kQuant == 0) x *= ksc_cur[tb][r];
+          if (masked) {
+            const int tok = t * 64 + tb * 16 + g * 4 + r;
+            x = tok <= lim ? x : kNegInf;
+          }
+          s[nb][tb][r] = x;
+          mt = fmaxf(mt, x);
+        }
+      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float m_new = fmaxf(m_run[nb], mt);
+      const float m_use = m_new == kNegInf ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_use);
+      m_run[nb] = m_new;
+      float psum = 0.f;
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) {
+        float p[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p[r] = __builtin_amdgcn_exp2f(s[nb][tb][r] - m_use);
+          psum += p[r];
+        }
+        pf[nb][tb >> 1][tb & 1] = cvt_4xe4m3(p[0] * 256.f, p[1] * 256.f, p[2] * 256.f, p[3] * 256.f);
+      }
+      l_run[nb] = l_run[nb] * alpha + psum;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) o[nb][jj] *= alpha;
+    }
+
+    // ---- O^T += V^T P^T (private 8x8 byte transposes feed the A operand) --------------------------------
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint32_t st[2][2][4];
+#pragma unroll
+      for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+        for (int tq = 0; tq < 2; ++tq) {
+          const uint32_t r0 = vf8[ks][tq * 4 + 0][dh], r1 = vf8[ks][tq * 4 + 1][dh];
+          const uint32_t r2 = vf8[ks][tq * 4 + 2][dh], r3 = vf8[ks][tq * 4 + 3][dh];
+          st[dh][tq][0] = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
+          st[dh][tq][1] = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
+          st[dh][tq][2] = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
+          st[dh][tq][3] = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
+        }
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const int dh = jj >> 2, dp = (jj >> 1) & 1;
+        const uint32_t sel = (jj & 1) ? 0x07060302u : 0x05040100u;
+        const uint32_t lo = __builtin_amdgcn_perm(st[dh][0][2 + dp], st[dh][0][dp], sel);
+        const uint32_t hi = __builtin_amdgcn_perm(st[dh][1][2 + dp], st[dh][1][dp], sel);
+#pragma unroll
+        for (int nb = 0; nb < kNB; ++nb)
+          o[nb][jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(lo, hi), pack64(pf[nb][ks][0], pf[nb][ks][1]),
+                                                                 o[nb][jj], 0, 0, 0);
+        if (jj & 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    load_v(pid, inpage, nrec);
+  }
+
+  // ---- finish: row-major re-read through the wave's LDS tile, scale, bf16 store ---------------------------
+#pragma unroll
+  for (int nb = 0; nb < kNB; ++nb) {
+    float l = l_run[nb];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    if (g == 0) s_l[wave][n] = l;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_o[wave][n][8 * (g * 4 + r) + jj] = o[nb][jj][r];
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+      const int row16 = it * 4 + (lane >> 4), c8 = lane & 15;
+      const int row = row0 + nb * 16 + row16;
+      const int pos = row >> a.g_shift;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(&s_o[wave][row16][c8 * 8]);
+      const f32x4 x1 = *reinterpret_cast<const f32x4*>(&s_o[wave][row16][c8 * 8 + 4]);
+      const float L2 = s_l[wave][row16];
+      const float inv = (L2 > 0.f ? 1.0f / L2 : 0.f) * out_scale;
+      if (pos < Sq) {
+        u32x4 pk;
+        pk[0] = pack_bf16x2(x0[0] * inv, x0[1] * inv);
+        pk[1] = pack_bf16x2(x0[2] * inv, x0[3] * inv);
+        pk[2] = pack_bf16x2(x1[0] * inv, x1[1] * inv);
+        pk[3] = pack_bf16x2(x1[2] * inv, x1[3] * inv);
+        st16(a.y + static_cast<long>(q0 + pos) * a.ldy + ((h << a.g_shift) + (row & (G - 1))) * 128 + c8 * 8, pk);
+      }
+    }
+  }
+}
+
+}  // namespace prefill
+}  // namespace hpc
+
+// reference: attention_with_kvcache_prefill_{qpertoken_perhead_kvpertensor,qkpertoken_perhead_vperhead}_fp8_async
+// (src/attention/prefill/prefill.h; argument meaning kept; TMA scratch dropped).  quant_type 1 / 0 as in
+// hpc_attention_decode_fp8_async; kscale strides (bytes) only for quant_type 0.
+extern "C" int hpc_attention_with_kvcache_prefill_fp8_async(
+    void* y_ptr, const void* q_ptr, const void* kcache_ptr, const void* vcache_ptr, const void* qscale_ptr,
+    const void* kscale_ptr, const void* vscale_ptr, const void* cu_seqlens_q_ptr, const void* block_ids_ptr,
+    const void* seqlens_kvcache_ptr, int quant_type, int num_batch, int max_seqlens_q, int max_seqlens_q_pad,
+    int num_dim_qk, int num_dim_v, int num_head_q, int num_head_kv, int block_size, int num_seq_max_blocks,
+    int ldY, int ldQ, int64_t kcache_block_stride, int64_t kcache_token_stride, int64_t kcache_head_stride,
+    int64_t vcache_block_stride, int64_t vcache_token_stride, int64_t vcache_head_stride,
+    int64_t kscale_block_stride_bytes, int64_t kscale_row_stride_bytes, int64_t kscale_head_stride_bytes,
+    hipStream_t stream) {
+  using namespace hpc::prefill;
+  if (!y_ptr || !q_ptr || !kcache_ptr || !vcache_ptr || !qscale_ptr || !kscale_ptr || !vscale_ptr ||
+      !cu_seqlens_q_ptr || !block_ids_ptr || !seqlens_kvcache_ptr)
+    return HPC_ERR_INVALID;
+  if (quant_type != 0 && quant_type != 1) return HPC_ERR_INVALID;
+  if (num_batch <= 0 || max_seqlens_q <= 0) return num_batch < 0 || max_seqlens_q < 0 ? HPC_ERR_INVALID : HPC_OK;
+  if (num_dim_qk != 128 || num_dim_v != 128) return HPC_ERR_UNSUPPORTED;
+  if (block_size != 16 && block_size != 32 && block_size != 64) return HPC_ERR_UNSUPPORTED;
+  if (quant_type == 0 && block_size < 32) return HPC_ERR_UNSUPPORTED;
+  if (num_head_kv <= 0 || num_head_q % num_head_kv) return HPC_ERR_INVALID;
+  const int group = num_head_q / num_head_kv;
+  if (group != 1 && group != 2 && group != 4 && group != 8 && group != 16) return HPC_ERR_UNSUPPORTED;
+  if ((ldQ & 15) || (ldY & 7) || (kcache_token_stride & 15) || (vcache_token_stride & 7) ||
+      (kcache_head_stride & 15) || (vcache_head_stride & 7) || (kcache_block_stride & 15) ||
+      (vcache_block_stride & 7))
+    return HPC_ERR_UNSUPPORTED;
+  Args a{};
+  a.q = q_ptr;
+  a.kcache = kcache_ptr;
+  a.vcache = vcache_ptr;
+  a.block_ids = static_cast<const int*>(block_ids_ptr);
+  a.cu_seqlens_q = static_cast<const int*>(cu_seqlens_q_ptr);
+  a.seqlens_kv = static_cast<const int*>(seqlens_kvcache_ptr);
+  a.y = static_cast<uint16_t*>(y_ptr);
+  a.qscale = static_cast<const float*>(qscale_ptr);
+  a.kscale = static_cast<const float*>(kscale_ptr);
+  a.vscale = static_cast<const float*>(vscale_ptr);
+  a.num_batch = num_batch;
+  a.num_head_q = num_head_q;
+  a.num_head_kv = num_head_kv;
+  a.g_shift = group == 1 ? 0 : (group == 2 ? 1 : (group == 4 ? 2 : (group == 8 ? 3 : 4)));
+  a.page_shift = block_size == 64 ? 6 : (block_size == 32 ? 5 : 4);
+  a.max_blocks = num_seq_max_blocks;
+  a.qs_pad = max_seqlens_q_pad;
+  a.ldq = ldQ;
+  a.ldy = ldY;
+  a.k_block_stride = kcache_block_stride;
+  a.k_token_stride = kcache_token_stride;
+  a.k_head_stride = kcache_head_stride;
+  a.v_block_stride = vcache_block_stride;
+  a.v_token_stride = vcache_token_stride;
+  a.v_head_stride = vcache_head_stride;
+  a.ks_block_stride = kscale_block_stride_bytes;
+  a.ks_row_stride = kscale_row_stride_bytes;
+  a.ks_head_stride = kscale_head_stride_bytes;
+  a.scale_log2 = 1.4426950408889634f / 11.313708498984761f;  // log2(e) / sqrt(128)
+  const long rows = static_cast<long>(max_seqlens_q) * group;
+  dim3 grid(static_cast<unsigned>((rows + kWaves * kRowsPerWave - 1) / (kWaves * kRowsPerWave)), num_head_kv, num_batch);
+  if (grid.z > 65535 || grid.y > 65535) return HPC_ERR_UNSUPPORTED;
+  // default (temporal) cache policy: K/V tiles are re-read by every q tile of the request from L2
+  if (quant_type == 1)
+    prefill_fp8_kernel<1, 0><<<grid, kThreads, 0, stream>>>(a);
+  else
+    prefill_fp8_kernel<0, 0><<<grid, kThreads, 0, stream>>>(a);
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}

@@ -229,3 +229,68 @@ def _attention_decode_fp8_entry(q, kcache, vcache, block_ids, num_seq_kvcache, q
 
 
 _T.impl("attention_decode_fp8", _attention_decode_fp8_entry, "CUDA")
+
+
+# ---------------------------------------------------------------------------- fp8 paged prefill
+_T.define(
+    "attention_with_kvcache_prefill_fp8(Tensor q, Tensor kcache, Tensor vcache, Tensor qscale, Tensor kscale, "
+    "Tensor vscale, Tensor cu_seqlens_q, Tensor block_ids, Tensor seqlens_kvcache, int max_seqlens_q, "
+    "int quant_type, Tensor? output) -> Tensor"
+)
+
+
+def _attention_prefill_fp8_entry(q, kcache, vcache, qscale, kscale, vscale, cu_seqlens_q, block_ids,
+                                 seqlens_kvcache, max_seqlens_q, quant_type, output=None):
+    # reference attention_with_kvcache_prefill_fp8_entry, src/attention/entry.cc:152-262
+    for t, name in ((q, "q"), (kcache, "kcache"), (vcache, "vcache"), (qscale, "qscale"), (kscale, "kscale"),
+                    (vscale, "vscale"), (cu_seqlens_q, "cu_seqlens_q"), (block_ids, "block_ids"),
+                    (seqlens_kvcache, "seqlens_kvcache")):
+        _C.require(t.is_cuda, f"{name} tensor must be cuda")
+    _C.require(quant_type in (0, 1), "quant_type only support 0/1")
+    _C.require(kscale.element_size() in (1, 4), "kscale dtype must be float or fp8")
+    _C.require(q.dtype == torch.float8_e4m3fn, "q dtype must be float8_e4m3fn")
+    _C.require(kcache.dtype == torch.float8_e4m3fn, "kcache dtype must be float8_e4m3fn")
+    _C.require(vcache.dtype == torch.float8_e4m3fn, "vcache dtype must be float8_e4m3fn")
+    _C.require(q.dim() == 3 and q.stride(2) == 1 and q.stride(1) == q.size(2), "q must be [total_seq, Hq, D] row-major")
+    total_q, num_head_q, dim_qk = q.shape
+    num_batch = cu_seqlens_q.size(0) - 1
+    block_size, num_head_kv, dim_v = kcache.size(1), kcache.size(2), vcache.size(3)
+    _C.require(dim_qk == 128 and dim_v == 128,
+               f"attention_with_kvcache_prefill_fp8: expected dim_qk=128 and dim_v=128, got dim_qk={dim_qk} dim_v={dim_v}")
+    _C.require(kcache.stride(3) == 1 and vcache.stride(3) == 1, "kv cache head dim must be contiguous")
+    _C.require(qscale.dtype == torch.float32 and qscale.dim() == 3 and qscale.is_contiguous()
+               and qscale.size(0) == num_batch and qscale.size(1) == num_head_q and qscale.size(2) >= max_seqlens_q,
+               "qscale must be float32 [num_batch, num_head_q, max_seqlens_q_pad]")
+    for t, name in ((cu_seqlens_q, "cu_seqlens_q"), (block_ids, "block_ids"), (seqlens_kvcache, "seqlens_kvcache")):
+        _C.require(t.dtype == torch.int32 and t.is_contiguous(), f"{name} must be contiguous int32")
+    _C.require(vscale.dtype == torch.float32, "vscale must be float32")
+    if quant_type == 0:
+        _C.require(kscale.dim() == 4 and kscale.stride(3) == 1, "per-token kscale must be the K-cache tail rows view")
+        es = kscale.element_size()
+        ks = (kscale.stride(0) * es, kscale.stride(1) * es, kscale.stride(2) * es)
+        _C.require(vscale.numel() >= num_head_kv, "vscale must hold one value per kv head")
+    else:
+        _C.require(kscale.dtype == torch.float32 and kscale.numel() >= 1, "kscale must be float32 [1]")
+        ks = (0, 0, 0)
+    if output is not None:
+        _C.require(output.is_cuda and output.device == q.device, "output tensor must be on the same device as q")
+        _C.require(output.dtype == torch.bfloat16, "output dtype must be bfloat16")
+        _C.require(output.is_contiguous(), "output tensor must be contiguous")
+        _C.require(tuple(output.shape) == (total_q, num_head_q, dim_v),
+                   "output must have shape [total_seq_q, num_head_q, num_dim_v]")
+        y = output
+    else:
+        y = torch.empty((total_q, num_head_q, dim_v), dtype=torch.bfloat16, device=q.device)
+    if total_q == 0:
+        return y
+    rc = _C.lib.hpc_attention_with_kvcache_prefill_fp8_async(
+        _C.ptr(y), _C.ptr(q), _C.ptr(kcache), _C.ptr(vcache), _C.ptr(qscale), _C.ptr(kscale), _C.ptr(vscale),
+        _C.ptr(cu_seqlens_q), _C.ptr(block_ids), _C.ptr(seqlens_kvcache), int(quant_type), num_batch,
+        int(max_seqlens_q), qscale.size(2), dim_qk, dim_v, num_head_q, num_head_kv, block_size, block_ids.size(1),
+        y.stride(0), q.stride(0), kcache.stride(0), kcache.stride(1), kcache.stride(2), vcache.stride(0),
+        vcache.stride(1), vcache.stride(2), ks[0], ks[1], ks[2], _C.stream_of(q))
+    _C.check(rc, "attention_with_kvcache_prefill_fp8")
+    return y
+
+
+_T.impl("attention_with_kvcache_prefill_fp8", _attention_prefill_fp8_entry, "CUDA")

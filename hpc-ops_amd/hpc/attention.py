@@ -186,3 +186,38 @@ def attention_decode_fp8_fake(
     quant_type, splitk, task_map=None, split_flag=None, output=None,
 ):
     return torch.empty_like(q, dtype=torch.bfloat16)
+
+
+def attention_with_kvcache_prefill_fp8(
+    q: Tensor,
+    kcache: Tensor,
+    vcache: Tensor,
+    qscale: Tensor,
+    kscale: Tensor,
+    vscale: Tensor,
+    cu_seqlens_q: Tensor,
+    block_ids: Tensor,
+    seqlens_kvcache: Tensor,
+    max_seqlens_q: int,
+    quant_type: QuantType = QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR,
+    output: Tensor = None,
+) -> Tensor:
+    """Causal paged-KV prefill attention with FP8 q/k/v (reference hpc/attention.py:148-251).
+
+    q e4m3 [total_seq, Hq, 128]; kcache / vcache e4m3 logical [num_blocks, block_size, Hkv, 128] (NHD or
+    HND-backed strides); qscale f32 [num_batch, Hq, max_seqlens_q_pad] (per token, per head);
+    kscale f32 [1] / vscale f32 [1] (per tensor) or the K-scale tail rows + vscale [Hkv];
+    cu_seqlens_q int32 [num_batch+1]; block_ids int32 [num_batch, max_blocks]; seqlens_kvcache int32
+    [num_batch]: tokens of each request in the cache, the request's q tokens being the last ones (q row s
+    attends keys j <= L - Sq + s, as in the reference tests' oracle).  Returns bf16 [total_seq, Hq, 128]."""
+    return torch.ops.hpc.attention_with_kvcache_prefill_fp8(
+        q, kcache, vcache, qscale, kscale, vscale, cu_seqlens_q, block_ids, seqlens_kvcache, int(max_seqlens_q),
+        quant_type.value, output)
+
+
+@torch.library.register_fake("hpc::attention_with_kvcache_prefill_fp8")
+def _attention_with_kvcache_prefill_fp8_fake(q, kcache, vcache, qscale, kscale, vscale, cu_seqlens_q, block_ids,
+                                             seqlens_kvcache, max_seqlens_q, quant_type, output=None):
+    if output is not None:
+        return output
+    return torch.empty((q.shape[0], q.shape[1], vcache.shape[-1]), dtype=torch.bfloat16, device=q.device)

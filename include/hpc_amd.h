@@ -262,6 +262,24 @@ int hpc_gemm_bf16xfp32_async(void* y, void* splitk_y, void* split_flag, const vo
                              const void* w_low, int m, int n, int k, float scale, int use_fp32_output,
                              int splits, int flag_ld, hpc_stream_t stream);
 
+/* ---- paged-KV causal prefill attention, FP8 ----
+ * reference: attention_with_kvcache_prefill_{qpertoken_perhead_kvpertensor,qkpertoken_perhead_vperhead}_fp8_async
+ *            (src/attention/prefill/prefill.h, entry src/attention/entry.cc:152-262).
+ * q e4m3 [total_q, Hq, 128]; caches as in hpc_attention_decode_fp8_async (strides in elements); qscale f32
+ * [B, Hq, max_seqlens_q_pad]; cu_seqlens_q int32 [B+1]; seqlens_kvcache int32 [B] = cached tokens INCLUDING
+ * the request's q tokens (q row s attends keys j <= L_b - Sq_b + s); y bf16 [total_q, Hq, 128].
+ * quant_type 1: kscale/vscale f32 [1]; 0: kscale = K-scale tail rows of the cache (strides in bytes),
+ * vscale f32 [Hkv].  head dims 128, page size 16/32/64, Hq/Hkv in {1,2,4,8,16}. */
+int hpc_attention_with_kvcache_prefill_fp8_async(
+    void* y, const void* q, const void* kcache, const void* vcache, const void* qscale, const void* kscale,
+    const void* vscale, const void* cu_seqlens_q, const void* block_ids, const void* seqlens_kvcache,
+    int quant_type, int num_batch, int max_seqlens_q, int max_seqlens_q_pad, int num_dim_qk, int num_dim_v,
+    int num_head_q, int num_head_kv, int block_size, int num_seq_max_blocks, int ldY, int ldQ,
+    int64_t kcache_block_stride, int64_t kcache_token_stride, int64_t kcache_head_stride,
+    int64_t vcache_block_stride, int64_t vcache_token_stride, int64_t vcache_head_stride,
+    int64_t kscale_block_stride_bytes, int64_t kscale_row_stride_bytes, int64_t kscale_head_stride_bytes,
+    hpc_stream_t stream);
+
 /* ---- fused sampler (end of the decode step) ----
  * reference: fused_sampler_async / fused_sampler_temperature_async, src/sampler/sampler.h:17-45
  *            (kernels src/sampler/fused_sampler.cu, fused_sampler_temperature.cu; entry src/sampler/entry.cc).

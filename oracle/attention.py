@@ -147,3 +147,35 @@ def ref_attn_fp8(q, kvcache, block_ids, nblocks, num_seq_q, num_seq_kvcache, q_s
             y = y * (v_scale / 256.0)
         out[bi] = y.transpose(0, 1).to(torch.bfloat16)
     return out.reshape(-1, num_head_q, head_dim)
+
+
+def ref_prefill_fp8(q8, kcache8, vcache8, qscale, kscale, vscale, cu_seqlens_q, block_ids, seqlens_kv):
+    """FP8 paged causal prefill oracle: restates naive_attn_with_kvcache_func of reference
+    tests/test_attention_with_kvcache_qpertoken_perhead_kvpertensor_prefill_fp8.py:14-83 (per-tensor K/V
+    scales; P quantised as e4m3(256 p) against the row maximum, O / sum * vscale / 256), generalised to a
+    different q length per request.  q8 [total_q, Hq, D] e4m3, caches [nblk, P, Hkv, D] e4m3,
+    qscale [B, Hq, pad], seqlens_kv = cached tokens including the q tokens.  Returns bf16 [total_q, Hq, D]."""
+    total_q, hq, d = q8.shape
+    P, hkv = kcache8.shape[1], kcache8.shape[2]
+    group = hq // hkv
+    out = torch.empty(total_q, hq, vcache8.shape[3], dtype=torch.bfloat16)
+    for b in range(cu_seqlens_q.numel() - 1):
+        a0, a1 = int(cu_seqlens_q[b]), int(cu_seqlens_q[b + 1])
+        sq, L = a1 - a0, int(seqlens_kv[b])
+        if sq == 0:
+            continue
+        nblk = (L + P - 1) // P
+        ids = block_ids[b, :nblk].long()
+        BQ = q8[a0:a1].float().transpose(0, 1)  # [Hq, sq, D]
+        BK = kcache8[ids].float().reshape(-1, hkv, d).transpose(0, 1)[:, :L].repeat_interleave(group, dim=0)
+        BV = vcache8[ids].float().reshape(-1, hkv, vcache8.shape[3]).transpose(0, 1)[:, :L].repeat_interleave(group, dim=0)
+        scale = qscale[b, :, :sq].unsqueeze(-1)
+        scores = torch.matmul(BQ, BK.transpose(-2, -1)) * scale * kscale[0] / math.sqrt(d)
+        mask = torch.tril(torch.ones(L, L, dtype=torch.bool))[L - sq :, :]
+        scores = scores.masked_fill(~mask, float("-inf"))
+        w = torch.exp(scores - scores.max(dim=-1, keepdim=True)[0])
+        gsum = w.sum(dim=-1, keepdim=True)
+        w8 = (w * 256.0).to(torch.float8_e4m3fn).float()
+        o = torch.matmul(w8, BV) / gsum * (vscale[0] / 256.0)
+        out[a0:a1] = o.transpose(0, 1).to(torch.bfloat16)
+    return out

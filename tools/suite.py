@@ -114,6 +114,7 @@ def main():
     out.update(bench.extra_rope(dev, hpc))
     out.update(bench.extra_router_gemm(dev, hpc))
     out.update(bench.extra_sampler(dev, hpc))
+    out.update(bench.extra_prefill(dev, hpc))
     Path(ROOT / "gpurun_out").mkdir(exist_ok=True)
     (ROOT / "gpurun_out" / "suite.json").write_text(json.dumps(out, indent=1))
     print("wrote gpurun_out/suite.json")
