@@ -10,10 +10,9 @@
 // v_mfma_f32_16x16x32_fp8_fp8), same full-row K loads transposed through a wave-private LDS tile, same
 // private 8x8 V byte transposes, same base-2 online softmax with P quantised as e4m3(256 p) against the
 // running max.  What changes: a wave owns 32 q rows (= 32/G consecutive positions x the G q heads of
-// one kv head), walks the KV tiles its rows can see (causal: fully visible tiles first, then the masked
-// ones) and finishes alone - no split-KV, no merge.  A workgroup = 4 waves = 128 consecutive rows that
-// share K/V tiles through L1/L2.  MFMA-bound shape; staging K/V once per workgroup in LDS is the
-// next step.
+// one kv head) and finishes alone - no split-KV, no merge; a workgroup = 4 waves = 128 consecutive rows
+// that walk the KV tiles together (causal: each wave masks what its rows cannot see) and share every
+// K/V tile through a double-buffered LDS stage filled one tile ahead.
 #include "hpc_common.h"
 #include "../../include/hpc_amd.h"
 
@@ -52,11 +51,18 @@ __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
 
 // kQuant 1: q per token / per head, k and v per tensor.  kQuant 0: k per token / per head (scales in
 // the page tail rows), v per kv head.
-template <int kQuant, int kAux>
+//
+// K/V staging: every 64-token tile is fetched ONCE per workgroup - wave w loads token block w of K and
+// of V (16 rows x 128 B each, full-row loads, one tile ahead, held in 4+4 VGPRs while the current tile
+// computes) and drops them into a double-buffered LDS tile; one barrier per tile; all waves then read K
+// in MFMA A-operand layout (ds_read_b128) and V as 8-byte row pieces for the private transposes.
+template <int kQuant>
 __global__ __launch_bounds__(kThreads, 1) void prefill_fp8_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) float s_o[kWaves][16][128 + 4];
   __shared__ float s_l[kWaves][16];
-  __shared__ __attribute__((aligned(16))) uint8_t s_kt[kWaves][2][16 * kKRow];
+  __shared__ __attribute__((aligned(16))) uint8_t s_k[2][64 * kKRow];
+  __shared__ __attribute__((aligned(16))) uint8_t s_v[2][64 * kKRow];
+  __shared__ __attribute__((aligned(16))) float s_ks[2][64];  // per-token K scales of the tile (kQuant 0)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,14 +72,16 @@ __global__ __launch_bounds__(kThreads, 1) void prefill_fp8_kernel(const Args a) 
   const int q0 = as_const(a.cu_seqlens_q)[b];
   const int Sq = as_const(a.cu_seqlens_q)[b + 1] - q0;
   const int L = as_const(a.seqlens_kv)[b];
-  const int row0 = (blockIdx.x * kWaves + wave) * kRowsPerWave;  // first (position, head) row of this wave
+  const int wg_row0 = blockIdx.x * kWaves * kRowsPerWave;
+  if ((wg_row0 >> a.g_shift) >= Sq) return;  // whole workgroup past the request (uniform exit)
+  const int row0 = wg_row0 + wave * kRowsPerWave;  // first (position, head) row of this wave
   const int pos_first = row0 >> a.g_shift;
-  if (pos_first >= Sq) return;
-  const int pos_last = min(Sq - 1, (row0 + kRowsPerWave - 1) >> a.g_shift);
   const int past = L - Sq;  // cached tokens before the first q token
-  const int num_seqkv = past + pos_last + 1;             // keys any row of this wave can see
+  // the workgroup walks the tiles its LAST row can see; a wave's own rows mask what they cannot
+  const int wg_pos_last = min(Sq - 1, (wg_row0 + kWaves * kRowsPerWave - 1) >> a.g_shift);
+  const int num_seqkv = past + wg_pos_last + 1;
   const int ntile = (num_seqkv + 63) >> 6;
-  const int ntile_full = max(past + pos_first + 1, 0) >> 6;  // tiles visible to every row: no mask needed
+  const int ntile_full = max(past + pos_first + 1, 0) >> 6;  // tiles visible to every row of this wave
   const int page_mask = (1 << a.page_shift) - 1;
   const uint8_t* qbase = static_cast<const uint8_t*>(a.q);
   const uint8_t* kbase = static_cast<const uint8_t*>(a.kcache);
@@ -82,76 +90,67 @@ __global__ __launch_bounds__(kThreads, 1) void prefill_fp8_kernel(const Args a) 
   // ---- Q fragments (B operand of S^T = K Q^T): lane (n, g) holds 16-byte chunks g and g+4 of row n ----
   u32x4 qf[kNB][2];
   float row_scale[kNB];
-  int row_pos[kNB];
-  bool row_ok[kNB];
+  int row_lim[kNB];  // last visible key of this lane's q row (-1: row does not exist)
 #pragma unroll
   for (int nb = 0; nb < kNB; ++nb) {
     const int row = row0 + nb * 16 + n;
     const int pos = row >> a.g_shift;
     const int hq = (h << a.g_shift) + (row & (G - 1));
-    row_ok[nb] = pos < Sq;
-    row_pos[nb] = pos;
+    const bool ok = pos < Sq;
+    row_lim[nb] = ok ? past + pos : -1;
     const long qoff = static_cast<long>(q0 + pos) * a.ldq + hq * 128;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       qf[nb][c] = u32x4{0u, 0u, 0u, 0u};
-      if (row_ok[nb]) qf[nb][c] = ld16(qbase + qoff + (g + 4 * c) * 16);
+      if (ok) qf[nb][c] = ld16(qbase + qoff + (g + 4 * c) * 16);
     }
-    float qs = row_ok[nb] ? a.qscale[(static_cast<long>(b) * a.num_head_q + hq) * a.qs_pad + pos] : 0.f;
+    float qs = ok ? a.qscale[(static_cast<long>(b) * a.num_head_q + hq) * a.qs_pad + pos] : 0.f;
     if constexpr (kQuant == 1) qs *= a.kscale[0];
     row_scale[nb] = a.scale_log2 * qs;
   }
   const float out_scale = (kQuant == 1 ? a.vscale[0] : a.vscale[h]) * (1.0f / 256.0f);
 
+  // ---- staging role: token block `wave` of each tile, lane -> (row lane/8 (+8), 16-byte chunk lane%8) ----
   const cint_ptr bid_row = as_const(a.block_ids) + static_cast<long>(b) * a.max_blocks;
   const int last_blk16 = (num_seqkv - 1) >> 4;
-  auto tile_pages = [&](int t, int (&pid)[4], int (&inpage)[4]) {
+  const int st_chunk = lane & 7, st_rsub = lane >> 3;
+  const int k_voff = st_rsub * static_cast<int>(a.k_token_stride) + st_chunk * 16;
+  const int v_voff = st_rsub * static_cast<int>(a.v_token_stride) + st_chunk * 16;
+  const int k_ld_bytes = 8 * static_cast<int>(a.k_token_stride), v_ld_bytes = 8 * static_cast<int>(a.v_token_stride);
+  u32x4 kst[2], vst[2];
+  float ksst = 0.f;
+  auto fetch = [&](int t) {  // unconditional: tiles past the end re-read the last block (never used)
+    int blk = t * 4 + wave;
+    blk = blk < last_blk16 ? blk : last_blk16;
+    const int gtok = blk << 4;
+    const int pid = __builtin_amdgcn_readfirstlane(bid_row[gtok >> a.page_shift]);
+    const int inpage = gtok & page_mask;
+    const auto rk = make_rsrc(kbase + pid * a.k_block_stride + inpage * a.k_token_stride + h * a.k_head_stride,
+                              0xffffffffu);
+    const auto rv = make_rsrc(vbase + pid * a.v_block_stride + inpage * a.v_token_stride + h * a.v_head_stride,
+                              0xffffffffu);
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
-      int blk = t * 4 + tb;
-      blk = blk < last_blk16 ? blk : last_blk16;
-      const int gtok = blk << 4;
-      pid[tb] = __builtin_amdgcn_readfirstlane(bid_row[gtok >> a.page_shift]);
-      inpage[tb] = gtok & page_mask;
+    for (int c = 0; c < 2; ++c) {
+      kst[c] = buf_ld16<0>(rk, k_voff, c * k_ld_bytes);
+      vst[c] = buf_ld16<0>(rv, v_voff, c * v_ld_bytes);
+    }
+    if constexpr (kQuant == 0) {
+      // scales of tokens inpage .. inpage+15: tail row (tok >> 5), float (tok & 31); lanes 0..15 fetch one each
+      const uint8_t* sp = reinterpret_cast<const uint8_t*>(a.kscale) + pid * a.ks_block_stride +
+                          (inpage >> 5) * a.ks_row_stride + h * a.ks_head_stride + ((inpage & 31) + (lane & 15)) * 4;
+      ksst = *reinterpret_cast<const float*>(sp);
     }
   };
-
-  u32x4 kf[4][2];
-  u32x2 vf8[2][8];
-  f32x4 ksc[kQuant == 0 ? 4 : 1];
-  const int k_chunk = lane & 7, k_rsub = lane >> 3;  // full-row K loads: 8 chunks x 8 rows per instruction
-  const int k_voff = k_rsub * static_cast<int>(a.k_token_stride) + k_chunk * 16;
-  const int k_ld_bytes = 8 * static_cast<int>(a.k_token_stride);
-  const int v_voff = g * 4 * static_cast<int>(a.v_token_stride) + n * 8;
-  const int v_tok_bytes = static_cast<int>(a.v_token_stride);
-  auto load_k = [&](const int (&pid)[4], const int (&inpage)[4], unsigned nrec) {
+  auto stash = [&](int buf) {
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
-      const auto rs = make_rsrc(kbase + pid[tb] * a.k_block_stride + inpage[tb] * a.k_token_stride +
-                                    h * a.k_head_stride, nrec);
-#pragma unroll
-      for (int c = 0; c < 2; ++c) kf[tb][c] = buf_ld16<kAux>(rs, k_voff, c * k_ld_bytes);
-      if constexpr (kQuant == 0) {
-        const auto rk = make_rsrc(reinterpret_cast<const uint8_t*>(a.kscale) + pid[tb] * a.ks_block_stride +
-                                      (inpage[tb] >> 5) * a.ks_row_stride + h * a.ks_head_stride +
-                                      (inpage[tb] & 31) * 4, nrec);
-        const u32x4 raw = buf_ld16<0>(rk, g * 16, 0);
-        ksc[tb] = f32x4{__uint_as_float(raw[0]), __uint_as_float(raw[1]), __uint_as_float(raw[2]),
-                        __uint_as_float(raw[3])};
-      }
+    for (int c = 0; c < 2; ++c) {
+      const int off = (wave * 16 + c * 8 + st_rsub) * kKRow + st_chunk * 16;
+      *reinterpret_cast<u32x4*>(&s_k[buf][off]) = kst[c];
+      *reinterpret_cast<u32x4*>(&s_v[buf][off]) = vst[c];
     }
-  };
-  auto load_v = [&](const int (&pid)[4], const int (&inpage)[4], unsigned nrec) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int hb = 0; hb < 2; ++hb) {
-        const int tb = 2 * ks + hb;
-        const auto rs = make_rsrc(vbase + pid[tb] * a.v_block_stride + inpage[tb] * a.v_token_stride +
-                                      h * a.v_head_stride, nrec);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vf8[ks][hb * 4 + r] = buf_ld8<kAux>(rs, v_voff, r * v_tok_bytes);
-      }
+    if constexpr (kQuant == 0) {
+      if (lane < 16) s_ks[buf][wave * 16 + lane] = ksst;
+    }
   };
 
   f32x4 o[kNB][8];
@@ -164,28 +163,23 @@ __global__ __launch_bounds__(kThreads, 1) void prefill_fp8_kernel(const Args a) 
     l_run[nb] = 0.f;
   }
 
-  int pid[4], inpage[4];
-  tile_pages(0, pid, inpage);
-  __builtin_amdgcn_sched_barrier(0);
-  load_k(pid, inpage, 0xffffffffu);
-  __builtin_amdgcn_sched_barrier(0);
-  load_v(pid, inpage, 0xffffffffu);
-  __builtin_amdgcn_sched_barrier(0);
+  fetch(0);
+  stash(0);
+  __syncthreads();
   for (int t = 0; t < ntile; ++t) {
-    const unsigned nrec = t + 1 < ntile ? 0xffffffffu : 0u;
-    tile_pages(t + 1 < ntile ? t + 1 : ntile - 1, pid, inpage);
+    const int buf = t & 1;
+    fetch(t + 1);
+    const uint8_t* kt = s_k[buf];
+    const uint8_t* vt = s_v[buf];
 
     // ---- S^T = K Q^T --------------------------------------------------------------------------------
     f32x4 s[kNB][4];
 #pragma unroll
     for (int tb = 0; tb < 4; ++tb) {
-      uint8_t* kt = s_kt[wave][tb & 1];
-#pragma unroll
-      for (int c = 0; c < 2; ++c)
-        *reinterpret_cast<u32x4*>(kt + (c * 8 + k_rsub) * kKRow + k_chunk * 16) = kf[tb][c];
       u32x4 ka[2];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) ka[c] = *reinterpret_cast<const u32x4*>(kt + n * kKRow + (g + 4 * c) * 16);
+      for (int c = 0; c < 2; ++c)
+        ka[c] = *reinterpret_cast<const u32x4*>(kt + (tb * 16 + n) * kKRow + (g + 4 * c) * 16);
 #pragma unroll
       for (int nb = 0; nb < kNB; ++nb) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -199,12 +193,6 @@ __global__ __launch_bounds__(kThreads, 1) void prefill_fp8_kernel(const Args a) 
         s[nb][tb] = acc;
       }
     }
-    f32x4 ksc_cur[kQuant == 0 ? 4 : 1];
-    if constexpr (kQuant == 0) {
-#pragma unroll
-      for (int tb = 0; tb < 4; ++tb) ksc_cur[tb] = ksc[tb];
-    }
-    load_k(pid, inpage, nrec);
 
     // ---- online softmax, base 2 ---------------------------------------------------------------------
     uint32_t pf[kNB][2][2];
@@ -212,20 +200,22 @@ __global__ __launch_bounds__(kThreads, 1) void prefill_fp8_kernel(const Args a) 
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) {
       float mt = kNegInf;
-      const int lim = row_ok[nb] ? past + row_pos[nb] : -1;  // last visible key of this lane's q row
 #pragma unroll
-      for (int tb = 0; tb < 4; ++tb)
+      for (int tb = 0; tb < 4; ++tb) {
+        f32x4 kscl = f32x4{1.f, 1.f, 1.f, 1.f};
+        if constexpr (kQuant == 0) kscl = *reinterpret_cast<const f32x4*>(&s_ks[buf][tb * 16 + g * 4]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float x = s[nb][tb][r] * row_scale[nb];
-          if constexpr (kQuant == 0) x *= ksc_cur[tb][r];
+          if constexpr (kQuant == 0) x *= kscl[r];
           if (masked) {
             const int tok = t * 64 + tb * 16 + g * 4 + r;
-            x = tok <= lim ? x : kNegInf;
+            x = tok <= row_lim[nb] ? x : kNegInf;
           }
           s[nb][tb][r] = x;
           mt = fmaxf(mt, x);
         }
+      }
       mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
       const float m_new = fmaxf(m_run[nb], mt);
@@ -248,16 +238,22 @@ __global__ __launch_bounds__(kThreads, 1) void prefill_fp8_kernel(const Args a) 
       for (int jj = 0; jj < 8; ++jj) o[nb][jj] *= alpha;
     }
 
-    // ---- O^T += V^T P^T (private 8x8 byte transposes feed the A operand) --------------------------------
+    // ---- O^T += V^T P^T: lane (n, g) reads dims 8n..8n+7 of tokens 16tb + 4g + r, transposes 8x8 bytes ----
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      u32x2 vf[8];
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          vf[hb * 4 + r] = *reinterpret_cast<const u32x2*>(vt + ((2 * ks + hb) * 16 + g * 4 + r) * kKRow + n * 8);
       uint32_t st[2][2][4];
 #pragma unroll
       for (int dh = 0; dh < 2; ++dh)
 #pragma unroll
         for (int tq = 0; tq < 2; ++tq) {
-          const uint32_t r0 = vf8[ks][tq * 4 + 0][dh], r1 = vf8[ks][tq * 4 + 1][dh];
-          const uint32_t r2 = vf8[ks][tq * 4 + 2][dh], r3 = vf8[ks][tq * 4 + 3][dh];
+          const uint32_t r0 = vf[tq * 4 + 0][dh], r1 = vf[tq * 4 + 1][dh];
+          const uint32_t r2 = vf[tq * 4 + 2][dh], r3 = vf[tq * 4 + 3][dh];
           st[dh][tq][0] = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
           st[dh][tq][1] = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
           st[dh][tq][2] = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
@@ -273,10 +269,10 @@ __global__ __launch_bounds__(kThreads, 1) void prefill_fp8_kernel(const Args a) 
         for (int nb = 0; nb < kNB; ++nb)
           o[nb][jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(lo, hi), pack64(pf[nb][ks][0], pf[nb][ks][1]),
                                                                  o[nb][jj], 0, 0, 0);
-        if (jj & 1) __builtin_amdgcn_sched_barrier(0);
       }
     }
-    load_v(pid, inpage, nrec);
+    stash(buf ^ 1);
+    __syncthreads();
   }
 
   // ---- finish: row-major re-read through the wave's LDS tile, scale, bf16 store ---------------------------
@@ -377,9 +373,9 @@ extern "C" int hpc_attention_with_kvcache_prefill_fp8_async(
   if (grid.z > 65535 || grid.y > 65535) return HPC_ERR_UNSUPPORTED;
   // default (temporal) cache policy: K/V tiles are re-read by every q tile of the request from L2
   if (quant_type == 1)
-    prefill_fp8_kernel<1, 0><<<grid, kThreads, 0, stream>>>(a);
+    prefill_fp8_kernel<1><<<grid, kThreads, 0, stream>>>(a);
   else
-    prefill_fp8_kernel<0, 0><<<grid, kThreads, 0, stream>>>(a);
+    prefill_fp8_kernel<0><<<grid, kThreads, 0, stream>>>(a);
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }

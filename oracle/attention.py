@@ -149,12 +149,15 @@ def ref_attn_fp8(q, kvcache, block_ids, nblocks, num_seq_q, num_seq_kvcache, q_s
     return out.reshape(-1, num_head_q, head_dim)
 
 
-def ref_prefill_fp8(q8, kcache8, vcache8, qscale, kscale, vscale, cu_seqlens_q, block_ids, seqlens_kv):
+def ref_prefill_fp8(q8, kcache8, vcache8, qscale, kscale, vscale, cu_seqlens_q, block_ids, seqlens_kv,
+                    k_per_token=False):
     """FP8 paged causal prefill oracle: restates naive_attn_with_kvcache_func of reference
     tests/test_attention_with_kvcache_qpertoken_perhead_kvpertensor_prefill_fp8.py:14-83 (per-tensor K/V
     scales; P quantised as e4m3(256 p) against the row maximum, O / sum * vscale / 256), generalised to a
     different q length per request.  q8 [total_q, Hq, D] e4m3, caches [nblk, P, Hkv, D] e4m3,
-    qscale [B, Hq, pad], seqlens_kv = cached tokens including the q tokens.  Returns bf16 [total_q, Hq, D]."""
+    qscale [B, Hq, pad], seqlens_kv = cached tokens including the q tokens.  Returns bf16 [total_q, Hq, D].
+    k_per_token: kscale is the byte view of the cache tail rows, vscale [Hkv] - the scale handling of
+    tests/test_attention_with_kvcache_qkpertoken_perhead_vperhead_prefill_fp8.py, same as ref_attn_fp8."""
     total_q, hq, d = q8.shape
     P, hkv = kcache8.shape[1], kcache8.shape[2]
     group = hq // hkv
@@ -170,12 +173,22 @@ def ref_prefill_fp8(q8, kcache8, vcache8, qscale, kscale, vscale, cu_seqlens_q, 
         BK = kcache8[ids].float().reshape(-1, hkv, d).transpose(0, 1)[:, :L].repeat_interleave(group, dim=0)
         BV = vcache8[ids].float().reshape(-1, hkv, vcache8.shape[3]).transpose(0, 1)[:, :L].repeat_interleave(group, dim=0)
         scale = qscale[b, :, :sq].unsqueeze(-1)
-        scores = torch.matmul(BQ, BK.transpose(-2, -1)) * scale * kscale[0] / math.sqrt(d)
+        scores = torch.matmul(BQ, BK.transpose(-2, -1)) * scale / math.sqrt(d)
+        if k_per_token:
+            ksb = (kscale[ids].contiguous().view(torch.float32).permute(0, 1, 3, 2).reshape(-1, hkv)
+                   .transpose(0, 1)[:, :L].repeat_interleave(group, dim=0)).float()
+            scores = scores * ksb.unsqueeze(1)
+        else:
+            scores = scores * kscale[0]
         mask = torch.tril(torch.ones(L, L, dtype=torch.bool))[L - sq :, :]
         scores = scores.masked_fill(~mask, float("-inf"))
         w = torch.exp(scores - scores.max(dim=-1, keepdim=True)[0])
         gsum = w.sum(dim=-1, keepdim=True)
         w8 = (w * 256.0).to(torch.float8_e4m3fn).float()
-        o = torch.matmul(w8, BV) / gsum * (vscale[0] / 256.0)
+        o = torch.matmul(w8, BV) / gsum
+        if k_per_token:
+            o = o * vscale[:, None, None].repeat_interleave(group, dim=0) / 256.0
+        else:
+            o = o * (vscale[0] / 256.0)
         out[a0:a1] = o.transpose(0, 1).to(torch.bfloat16)
     return out

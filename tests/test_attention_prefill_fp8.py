@@ -96,3 +96,28 @@ def test_prefill_fp8_errors():
         hpc.attention_with_kvcache_prefill_fp8(d[0].to(torch.bfloat16), *d[1:], 8)
     with pytest.raises(RuntimeError):
         hpc.attention_with_kvcache_prefill_fp8(*d, 8, output=torch.empty(8, 4, 128, device="cuda"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hq,hkv", [(8, 1), (16, 4)])
+@pytest.mark.parametrize("block_size", [32, 64])
+def test_prefill_fp8_k_per_token(hq, hkv, block_size):
+    """quant_type QPERTOKEN_PERHEAD_KPERTOKEN_PERHEAD_VPERHEAD: K scales in the page tail rows, V per head."""
+    import hpc
+
+    seq_q, seq_kv = [200, 1, 64, 333], [700, 90, 64, 333]
+    q, kv, qscale, _, _, cu, bid, lens = make_case(seq_q, seq_kv, hq, hkv, block_size, seed=11)
+    g = torch.Generator().manual_seed(5)
+    rows = block_size * 4 // 128
+    raw = torch.randn(kv.shape[0], 2, block_size + rows, hkv, 128, generator=g).bfloat16()
+    kc, _ = oattn.quant_paged_cache_pertoken(raw[:, 0], block_size)
+    vc, vscale = oattn.quant_paged_cache_perhead(raw[:, 1], block_size)
+    kscale = kc[:, block_size:]
+    gt = oattn.ref_prefill_fp8(q, kc[:, :block_size], vc[:, :block_size], qscale, kscale, vscale, cu, bid, lens,
+                               k_per_token=True)
+    kcd, vcd = kc.cuda(), vc.cuda()
+    my = hpc.attention_with_kvcache_prefill_fp8(
+        q.cuda(), kcd[:, :block_size], vcd[:, :block_size], qscale.cuda(), kcd[:, block_size:], vscale.cuda(),
+        cu.cuda(), bid.cuda(), lens.cuda(), max(seq_q),
+        quant_type=hpc.QuantType.QPERTOKEN_PERHEAD_KPERTOKEN_PERHEAD_VPERHEAD)
+    assert allclose(gt, my.cpu(), atol=0.1, rtol=0.02)
