@@ -29,3 +29,5 @@ struct Args {
 // tiled (MFMA-bound) form for large groups; `cu_tiles` = exclusive scan of ceil(seqlens / 128).
 int hpc_ggemm_launch_tiled(const hpc::ggemm::Args& a, const int* cu_tiles, int num_group, int m, int n,
                            hipStream_t stream);
+int hpc_ggemm_launch_tiled256(const hpc::ggemm::Args& a, const int* cu_tiles, int num_group, int m, int n,
+                              hipStream_t stream);

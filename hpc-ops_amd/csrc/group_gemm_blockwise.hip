@@ -243,10 +243,15 @@ namespace {
 int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const void* cu_tiles128,
                        hipStream_t stream) {
   using namespace hpc::ggemm;
-  // large groups: MFMA-bound 128x128-tile kernel (needs the scan of ceil(seqlens/128))
-  const int tiled_mode = hpc_tuning_get(3);  // 0 auto, 1 never, 2 always (when possible)
-  if (cu_tiles128 && n % 128 == 0 && tiled_mode != 1 && (tiled_mode == 2 || m / num_group > 32))
+  // groups above ~24 tokens: tiled kernels (need the scan of ceil(seqlens/128)): the 256 x 128 LDS-DMA ring
+  // kernel when n allows (measured faster than the streaming form from 32 tokens per group on: one pass
+  // over the weights for up to 128 tokens), else the 128 x 128 register-staged one
+  const int tiled_mode = hpc_tuning_get(3);  // 0 auto, 1 never, 2 always (when possible), 3 always, 128x128 only
+  if (cu_tiles128 && n % 128 == 0 && tiled_mode != 1 && (tiled_mode >= 2 || m / num_group > 24)) {
+    if (n % 256 == 0 && a.K >= 128 && tiled_mode != 3)
+      return hpc_ggemm_launch_tiled256(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);
     return hpc_ggemm_launch_tiled(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);
+  }
   // tokens served per pass over the weights, from the average group size (the reference picks its
   // tileM the same way, fuse_moe/entry.cc:525-543); larger groups take several passes
   const int avg = m / num_group;

@@ -1,0 +1,210 @@
+// Grouped FP8 GEMM, 256 x 128 tile with an LDS-DMA ring ("throughput" form, second generation) - gfx950.
+//
+// Same contract as group_gemm_tiled.hip / group_gemm_blockwise.hip (reference
+// src/group_gemm/kernels.cuh:215-892).  The 128 x 128 register-staged kernel tops out near 0.6 PFLOP/s:
+// one k-step of prefetch cannot cover HBM/L2 latency and a deeper register ring does not fit next to
+// 128 accumulator registers.  Here a workgroup of 8 waves (4 x 2, 64 x 64 outputs per wave) owns a
+// 256 (weight rows) x 128 (tokens) tile and streams 128-byte k-slabs of W and X straight into a 3-deep
+// LDS ring with `buffer_load ... lds` (16 bytes per lane, no staging registers, no ds_write pass):
+//   * the LDS image of a piece is lane-linear (HW rule), so the XOR swizzle that makes the MFMA operand
+//     reads conflict-free is applied on the SOURCE side: lane l of an 8-row piece fetches chunk
+//     (l % 8) ^ (l / 8) of row l / 8, and a reader asks for position chunk ^ (row & 7);
+//   * two slabs stay in flight across the single barrier of a k-step: counted `s_waitcnt vmcnt(N)` and a
+//     raw `s_barrier` (a __syncthreads() would drain the DMA queue);
+//   * the per-token activation scales of the slab ride in the same ring (4-byte DMA), the weight-block
+//     scale is a scalar load; fp32 partial of a 128-k block is rescaled into the running sum as before.
+#include "hpc_common.h"
+#include "../../include/hpc_amd.h"
+#include "group_gemm.h"
+
+namespace hpc {
+namespace ggemm {
+namespace {
+
+constexpr int kThreads = 512;
+constexpr int kBN = 256, kBM = 128, kBK = 128;
+constexpr int kStages = 3;
+constexpr int kWBytes = kBN * kBK, kXBytes = kBM * kBK, kXsBytes = 8 * 256;
+constexpr int kStageBytes = kWBytes + kXBytes + kXsBytes;
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
+  return static_cast<long>(static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32));
+}
+
+template <bool kHasXs>
+__global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Args a, const int* __restrict__ cu_tiles,
+                                                                        int num_group) {
+  __shared__ __attribute__((aligned(1024))) uint8_t s_ring[kStages * kStageBytes];
+  constexpr int kDmaPerStage = 4 + 2 + (kHasXs ? 1 : 0);  // per wave
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const cint_ptr cut = as_const(cu_tiles);
+  const int tile_id = blockIdx.y;
+  if (tile_id >= cut[num_group]) return;
+  int lo = 0, hi = num_group;  // first e with cu_tiles[e + 1] > tile_id
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cut[mid + 1] <= tile_id) lo = mid + 1; else hi = mid;
+  }
+  const int e = lo;
+  const int m_cnt = as_const(a.seqlens)[e];
+  const int m0 = as_const(a.cu_seqlens)[e];
+  const int mt0 = (tile_id - cut[e]) * kBM;
+  const int n0 = blockIdx.x * kBN;
+  const int K = a.K, KB = a.KB;
+  const int wn = wave >> 1, wm = wave & 1;
+
+  // ---- DMA roles ----------------------------------------------------------------------------------------
+  // 8-row pieces (1 KB): lane -> row piece*8 + lane/8, LDS position lane%8 <- global chunk (lane%8) ^ (lane/8)
+  const int p_row = lane >> 3, p_chunk = (lane & 7) ^ (lane >> 3);
+  const uint8_t* wsrc = a.w + (static_cast<long>(e) * a.N + n0) * K;
+  const unsigned w_bytes = static_cast<unsigned>(kBN) * static_cast<unsigned>(K);
+  unsigned w_voff[4], x_voff[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w_voff[q] = static_cast<unsigned>((wave * 4 + q) * 8 + p_row) * K + p_chunk * 16;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int slot = mt0 + (wave * 2 + q) * 8 + p_row;
+    const int sc = slot < m_cnt ? slot : m_cnt - 1;
+    const int xrow = a.row_index ? a.row_index[m0 + sc] : m0 + sc;
+    x_voff[q] = static_cast<unsigned>(xrow) * static_cast<unsigned>(K) + p_chunk * 16;
+  }
+  unsigned xs_voff = 0;
+  if constexpr (kHasXs) {
+    const int slot = mt0 + (wave & 1) * 64 + lane;
+    const int sc = slot < m_cnt ? slot : m_cnt - 1;
+    const long col0 = a.col_base ? static_cast<long>(as_const(a.col_base)[e]) * a.tile_m : 0;
+    const long term = a.col_base ? col0 + sc : static_cast<long>(a.row_index ? a.row_index[m0 + sc] : m0 + sc);
+    xs_voff = static_cast<unsigned>(term * a.xs_row_stride * 4);
+  }
+  const int xs_kb_bytes = static_cast<int>(a.xs_kb_stride * 4);
+
+  auto issue = [&](int st) {  // k-slab st -> ring slot st % kStages; past the end: empty descriptors (zeros)
+    const bool on = st < KB;
+    const int koff = st * kBK;
+    uint8_t* base = s_ring + (st % kStages) * kStageBytes;
+    const auto rw = make_rsrc(wsrc, on ? w_bytes : 0u);
+    const auto rx = make_rsrc(a.x, on ? a.x_bytes : 0u);
+    // K % 128 == 64 (per-tensor scales): chunks past K get an out-of-range offset and land as zeros
+    const bool k_ok = koff + p_chunk * 16 < K;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + (wave * 4 + q) * 1024), 16,
+                                           k_ok ? w_voff[q] : 0xffffff00u, koff, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(base + kWBytes + (wave * 2 + q) * 1024), 16,
+                                           k_ok ? x_voff[q] : 0xffffff00u, koff, 0, 0);
+    if constexpr (kHasXs) {
+      const auto rs = make_rsrc(a.xs, on && wave < 2 ? 0xffffffffu : 0u);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(base + kWBytes + kXBytes + wave * 256), 4, xs_voff,
+                                           st * xs_kb_bytes, 0, 0);
+    }
+  };
+
+  const cint_ptr ws_row = as_const(reinterpret_cast<const int*>(a.ws)) + static_cast<long>(e) * a.ws_group_stride +
+                          ((n0 + wn * 64) >> 7) * a.ws_ntile_stride;
+
+  f32x4 tot[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // operand read offsets inside a slab (swizzled): row r, chunk c -> r*128 + ((c ^ (r & 7)) << 4)
+  int a_off[4][2], b_off[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int ra = wn * 64 + i * 16 + r16, rb = wm * 64 + i * 16 + r16;
+      a_off[i][c] = ra * kBK + (((g4 + 4 * c) ^ (ra & 7)) << 4);
+      b_off[i][c] = kWBytes + rb * kBK + (((g4 + 4 * c) ^ (rb & 7)) << 4);
+    }
+
+#pragma unroll
+  for (int st = 0; st < kStages - 1; ++st) issue(st);
+
+  for (int kb = 0; kb < KB; ++kb) {
+    // slab kb has landed when at most (kStages - 2) younger slabs are outstanding
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (kDmaPerStage * (kStages - 2)));
+    __builtin_amdgcn_s_barrier();
+    issue(kb + kStages - 1);
+    const uint8_t* slab = s_ring + (kb % kStages) * kStageBytes;
+    const float wsk = __int_as_float(ws_row[kb * a.ws_kb_stride]);
+    float f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f[j] = wsk;
+      if constexpr (kHasXs)
+        f[j] *= *reinterpret_cast<const float*>(slab + kWBytes + kXBytes + wm * 256 + (j * 16 + r16) * 4);
+    }
+    f32x4 part[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) part[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      u32x4 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4*>(slab + a_off[i][c]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const u32x4*>(slab + b_off[j][c]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          part[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(af[i][0], af[i][1]),
+                                                                 pack64(bf[j][0], bf[j][1]), part[i][j], 0, 0, 0);
+          part[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(af[i][2], af[i][3]),
+                                                                 pack64(bf[j][2], bf[j][3]), part[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tot[i][j][r] = fmaf(part[i][j][r], f[j], tot[i][j][r]);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the (empty) tail DMAs before the workgroup's LDS is released
+
+  // ---- epilogue: lane holds rows n = wn*64 + i*16 + g4*4 + r of token column wm*64 + j*16 + r16 --------------
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int slot = mt0 + wm * 64 + j * 16 + r16;
+    if (slot < m_cnt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        u32x2 pk;
+        pk[0] = pack_bf16x2(tot[i][j][0], tot[i][j][1]);
+        pk[1] = pack_bf16x2(tot[i][j][2], tot[i][j][3]);
+        *reinterpret_cast<u32x2*>(a.y + static_cast<long>(m0 + slot) * a.N + n0 + wn * 64 + i * 16 + g4 * 4) = pk;
+      }
+    }
+  }
+}
+
+}  // namespace
+}  // namespace ggemm
+}  // namespace hpc
+
+int hpc_ggemm_launch_tiled256(const hpc::ggemm::Args& a, const int* cu_tiles, int num_group, int m, int n,
+                              hipStream_t stream) {
+  using namespace hpc::ggemm;
+  if (n % kBN || a.K < kBK) return HPC_ERR_UNSUPPORTED;
+  const int max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 128)
+  dim3 grid(n / kBN, max_tiles);
+  // (a non-temporal policy on the weight DMA for single-token-tile groups measured no difference)
+  if (a.has_xs)
+    gemm_fp8_tiled256_kernel<true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  else
+    gemm_fp8_tiled256_kernel<false><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}

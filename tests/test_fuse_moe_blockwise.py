@@ -145,3 +145,39 @@ def test_reduce():
         gt = omoe.reduce(x, pos, sc, shared)
         my = hpc.reduce(x.cuda(), pos.cuda(), sc.cuda(), None if shared is None else shared.cuda())
         assert allclose(gt.float(), my.cpu().float(), rtol=0.01, atol=0.01)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiled_mode", [2, 3])  # 2: 256x128 LDS-DMA ring kernel when n allows; 3: 128x128 kernel
+@pytest.mark.parametrize("n,k", [(512, 1024), (768, 4096), (384, 1408)])
+def test_group_gemm_blockwise_tiled_kernels(tiled_mode, n, k):
+    """the MFMA-bound tiled kernels on ragged groups (empty, 1 token, > 128 tokens, > 256 tokens)."""
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(1)
+    seqlens = torch.tensor([300, 0, 129, 5, 128, 1, 257], dtype=torch.int32)
+    num_group, total = len(seqlens), int(seqlens.sum())
+    x = (torch.randn((total, k)) / 10).to(F8)
+    w = (torch.randn((num_group, n, k)) / 10).to(F8)
+    kb = k // 128
+    xs_rows = torch.randn((total, kb))
+    wscale = torch.randn((num_group, n // 128, (kb + 3) // 4 * 4))
+    cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
+    gt = omoe.group_gemm_blockwise(x, w, seqlens, cu, xs_rows, wscale)
+    avg = total // num_group
+    tile_m = hpc._entry_fuse_moe.aligned_size(avg)
+    tiles = (seqlens + tile_m - 1) // tile_m
+    cu_tiles = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(tiles, 0)])
+    xs_t = torch.zeros((kb, int(cu_tiles[-1]) * tile_m + 64))
+    for g in range(num_group):
+        c0 = int(cu_tiles[g]) * tile_m
+        xs_t[:, c0 : c0 + int(seqlens[g])] = xs_rows[int(cu[g]) : int(cu[g]) + int(seqlens[g])].t()
+    hpc._C.lib.hpc_tuning_set(3, tiled_mode)
+    try:
+        my = hpc.group_gemm_blockwise_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), xs_t.cuda(), wscale.cuda(),
+                                          num_seq_per_group_avg=avg)
+        torch.cuda.synchronize()
+    finally:
+        hpc._C.lib.hpc_tuning_set(3, 0)
+    assert allclose(gt.float(), my.cpu().float(), rtol=0.01, atol=0.02)

@@ -102,3 +102,29 @@ def test_act_mul_and_quant(use_bf16_mul):
     assert agree > 0.995, agree
     q = hpc.scaled_fp8_quant(gate_up.cuda(), scale.cuda())
     assert torch.equal(q.cpu().view(torch.uint8), (gate_up.float() * scale).to(F8).view(torch.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiled_mode", [2, 3])
+@pytest.mark.parametrize("k", [1792, 1088, 192])  # 1088 and 192 end in a half k-block (K % 128 == 64)
+def test_group_gemm_pertensor_tiled_kernels(tiled_mode, k):
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(2)
+    n = 512
+    seqlens = torch.tensor([200, 0, 129, 3, 260], dtype=torch.int32)
+    G, total = len(seqlens), int(seqlens.sum())
+    x = torch.randn((total, k)).to(F8)
+    w = torch.randn((G, n, k)).to(F8)
+    scale = torch.rand(G) + 0.5
+    cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
+    gt = omoe.group_gemm_pertensor(x, w, seqlens, cu, scale)
+    hpc._C.lib.hpc_tuning_set(3, tiled_mode)
+    try:
+        my = hpc.group_gemm_pertensor_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), scale.cuda(),
+                                          num_seq_per_group_avg=total // G)
+        torch.cuda.synchronize()
+    finally:
+        hpc._C.lib.hpc_tuning_set(3, 0)
+    assert allclose(gt.float(), my.cpu().float(), rtol=0.08, atol=0.5)
