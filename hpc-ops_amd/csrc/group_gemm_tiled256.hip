@@ -42,19 +42,30 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g4 = lane >> 4;
+  // ---- which (group, token tile, weight tile)?  XCD-aware order -------------------------------------------
+  // Work items are ordered group -> weight tile -> token tile, so the token tiles that share a weight
+  // tile are neighbours; hardware deals consecutive workgroup ids round-robin over the 8 XCDs, so id L
+  // runs item (L % 8) * chunk + L / 8: each XCD walks one contiguous eighth of the list and the 2-4 token
+  // tiles of a weight tile (and the group's activation tiles) meet in ONE L2 instead of eight.
   const cint_ptr cut = as_const(cu_tiles);
-  const int tile_id = blockIdx.y;
-  if (tile_id >= cut[num_group]) return;
-  int lo = 0, hi = num_group;  // first e with cu_tiles[e + 1] > tile_id
+  const int nt = a.N / kBN;
+  const int total = cut[num_group] * nt;
+  const int chunk = (total + 7) >> 3;
+  const int lin = blockIdx.x;
+  const int item = (lin & 7) * chunk + (lin >> 3);
+  if ((lin >> 3) >= chunk || item >= total) return;
+  int lo = 0, hi = num_group;  // first e with cu_tiles[e + 1] * nt > item
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
-    if (cut[mid + 1] <= tile_id) lo = mid + 1; else hi = mid;
+    if (cut[mid + 1] * nt <= item) lo = mid + 1; else hi = mid;
   }
   const int e = lo;
+  const int mtiles = cut[e + 1] - cut[e];
+  const int rem = item - cut[e] * nt;
   const int m_cnt = as_const(a.seqlens)[e];
   const int m0 = as_const(a.cu_seqlens)[e];
-  const int mt0 = (tile_id - cut[e]) * kBM;
-  const int n0 = blockIdx.x * kBN;
+  const int mt0 = (rem % mtiles) * kBM;
+  const int n0 = (rem / mtiles) * kBN;
   const int K = a.K, KB = a.KB;
   const int wn = wave >> 1, wm = wave & 1;
 
@@ -198,8 +209,10 @@ int hpc_ggemm_launch_tiled256(const hpc::ggemm::Args& a, const int* cu_tiles, in
                               hipStream_t stream) {
   using namespace hpc::ggemm;
   if (n % kBN || a.K < kBK) return HPC_ERR_UNSUPPORTED;
-  const int max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 128)
-  dim3 grid(n / kBN, max_tiles);
+  const long max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 128)
+  const long items = max_tiles * (n / kBN) + 8;  // + 8: the per-XCD chunks round up
+  if (items > 0x7fffffffl) return HPC_ERR_UNSUPPORTED;
+  dim3 grid(static_cast<unsigned>(items));
   // (a non-temporal policy on the weight DMA for single-token-tile groups measured no difference)
   if (a.has_xs)
     gemm_fp8_tiled256_kernel<true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);

@@ -8,7 +8,7 @@ out = ROOT / "profiles"; out.mkdir(exist_ok=True)
 g = ROOT / "gpurun_out"
 def ours(name): return name.startswith(("hpc::", "void hpc::"))
 for src, dst in (("prof_bench", f"{tag}_bench_kernel_stats.csv"), ("prof_all", f"{tag}_hotpath_kernel_stats.csv")):
-    f = next(iter((g / src).glob("*kernel_stats.csv")), None)
+    f = next(iter((g / src).rglob("*kernel_stats.csv")), None)
     if f is None: continue
     rows = list(csv.DictReader(open(f)))
     with open(out / dst, "w") as fo:
@@ -17,7 +17,7 @@ for src, dst in (("prof_bench", f"{tag}_bench_kernel_stats.csv"), ("prof_all", f
             if ours(r["Name"]): w.writerow(r)
 agg = {}
 for name, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    f = next(iter((g / d).glob("*counter_collection.csv")), None)
+    f = next(iter((g / d).rglob("*counter_collection.csv")), None)
     if f is None: continue
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if "decode_kernel<false" in r["Kernel_Name"]]
     if vals: agg[name] = {"launches": len(vals), "avg_KB": sum(vals) / len(vals), "min_KB": min(vals), "max_KB": max(vals)}

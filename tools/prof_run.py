@@ -22,5 +22,10 @@ if what in ("decode", "all"):
 if what in ("fp8", "all"):
     print(bench.extra_decode(dev, hpc))
 if what in ("moe", "all"):
-    print(bench.extra_moe(dev, hpc, tokens=(64,)))
+    print(bench.extra_moe(dev, hpc, tokens=(64, 4096)))
+if what in ("next", "all"):  # the widening rows: rope + KV store, router GEMM, sampler, fp8 prefill
+    print(bench.extra_rope(dev, hpc))
+    print(bench.extra_router_gemm(dev, hpc))
+    print(bench.extra_sampler(dev, hpc))
+    print(bench.extra_prefill(dev, hpc))
 torch.cuda.synchronize()
