@@ -57,7 +57,7 @@ __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
 // computes) and drops them into a double-buffered LDS tile; one barrier per tile; all waves then read K
 // in MFMA A-operand layout (ds_read_b128) and V as 8-byte row pieces for the private transposes.
 template <int kQuant>
-__global__ __launch_bounds__(kThreads, 1) void prefill_fp8_kernel(const Args a) {
+__global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) float s_o[kWaves][16][128 + 4];
   __shared__ float s_l[kWaves][16];
   __shared__ __attribute__((aligned(16))) uint8_t s_k[2][64 * kKRow];
@@ -108,7 +108,8 @@ __global__ __launch_bounds__(kThreads, 1) void prefill_fp8_kernel(const Args a) 
     if constexpr (kQuant == 1) qs *= a.kscale[0];
     row_scale[nb] = a.scale_log2 * qs;
   }
-  const float out_scale = (kQuant == 1 ? a.vscale[0] : a.vscale[h]) * (1.0f / 256.0f);
+  // O = (sum_j e4m3(256 p_j) v_j) / (sum_j 256 p_j) * vscale: the two 256 (row sum units, P units) cancel
+  const float out_scale = kQuant == 1 ? a.vscale[0] : a.vscale[h];
 
   // ---- staging role: token block `wave` of each tile, lane -> (row lane/8 (+8), 16-byte chunk lane%8) ----
   const cint_ptr bid_row = as_const(a.block_ids) + static_cast<long>(b) * a.max_blocks;
@@ -194,26 +195,42 @@ __global__ __launch_bounds__(kThreads, 1) void prefill_fp8_kernel(const Args a) 
       }
     }
 
-    // ---- online softmax, base 2 ---------------------------------------------------------------------
+    // ---- online softmax, base 2.  p is produced as 256 p (the +8 rides in the exponent): it feeds the
+    // e4m3 pack directly and the row sum is kept in the same units (undone once in the epilogue). -------
     uint32_t pf[kNB][2][2];
     const bool masked = t >= ntile_full;
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) {
-      float mt = kNegInf;
+      const float rs = row_scale[nb];
+      float mt;
+      const bool fast = kQuant == 1 && !masked;  // per-row scale only, nothing to mask: never form s * rs
+      if (fast) {
+        float mx = kNegInf, mn = -kNegInf;
 #pragma unroll
-      for (int tb = 0; tb < 4; ++tb) {
-        f32x4 kscl = f32x4{1.f, 1.f, 1.f, 1.f};
-        if constexpr (kQuant == 0) kscl = *reinterpret_cast<const f32x4*>(&s_ks[buf][tb * 16 + g * 4]);
+        for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x = s[nb][tb][r] * row_scale[nb];
-          if constexpr (kQuant == 0) x *= kscl[r];
-          if (masked) {
-            const int tok = t * 64 + tb * 16 + g * 4 + r;
-            x = tok <= row_lim[nb] ? x : kNegInf;
+          for (int r = 0; r < 4; ++r) {
+            mx = fmaxf(mx, s[nb][tb][r]);
+            mn = fminf(mn, s[nb][tb][r]);
           }
-          s[nb][tb][r] = x;
-          mt = fmaxf(mt, x);
+        mt = rs >= 0.f ? rs * mx : rs * mn;
+      } else {
+        mt = kNegInf;
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+          f32x4 kscl = f32x4{1.f, 1.f, 1.f, 1.f};
+          if constexpr (kQuant == 0) kscl = *reinterpret_cast<const f32x4*>(&s_ks[buf][tb * 16 + g * 4]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float x = s[nb][tb][r] * rs;
+            if constexpr (kQuant == 0) x *= kscl[r];
+            if (masked) {
+              const int tok = t * 64 + tb * 16 + g * 4 + r;
+              x = tok <= row_lim[nb] ? x : kNegInf;
+            }
+            s[nb][tb][r] = x;
+            mt = fmaxf(mt, x);
+          }
         }
       }
       mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
@@ -222,16 +239,17 @@ __global__ __launch_bounds__(kThreads, 1) void prefill_fp8_kernel(const Args a) 
       const float m_use = m_new == kNegInf ? 0.f : m_new;
       const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_use);
       m_run[nb] = m_new;
+      const float bias = 8.0f - m_use;  // exp2(x - m + 8) = 256 p
       float psum = 0.f;
 #pragma unroll
       for (int tb = 0; tb < 4; ++tb) {
         float p[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p[r] = __builtin_amdgcn_exp2f(s[nb][tb][r] - m_use);
+          p[r] = __builtin_amdgcn_exp2f(fast ? fmaf(s[nb][tb][r], rs, bias) : s[nb][tb][r] + bias);
           psum += p[r];
         }
-        pf[nb][tb >> 1][tb & 1] = cvt_4xe4m3(p[0] * 256.f, p[1] * 256.f, p[2] * 256.f, p[3] * 256.f);
+        pf[nb][tb >> 1][tb & 1] = cvt_4xe4m3(p[0], p[1], p[2], p[3]);
       }
       l_run[nb] = l_run[nb] * alpha + psum;
 #pragma unroll
