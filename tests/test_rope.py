@@ -147,6 +147,9 @@ def test_rope_bypass_outputs():
 def test_rope_norm_store_kv_fp8(hq, hkv, policy, quant_policy, num_req, is_prefill, mtp):
     import hpc
 
+    if num_req == 16 and (policy != 1 or hq != 64):
+        pytest.skip("the 16-request batch (no align-8 padding) is sampled once per mode / quant policy")
+
     inp = make_inputs(num_req, is_prefill, mtp, hq, hkv, seed=num_req * 5 + policy + 3 * quant_policy)
     ref_q, kr, vr = oracle(inp, num_req, policy)
     qkv, ns, qi, kc, vc, ki, qw, kw, cs, real = [t.cuda() if torch.is_tensor(t) else t for t in inp]
