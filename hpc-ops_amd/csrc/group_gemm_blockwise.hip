@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * kWaves, (kWaves == 8 || kMT * kR >= 8) ? 1 : 2
           const int kbc = kb < KB ? kb : KB - 1;
           const float wsk = kb < KB ? __int_as_float(ws_row[kbc * a.ws_kb_stride]) : 0.f;
           // token blocks two at a time: their MFMA chains (4 dependent k-steps each) interleave
-          constexpr int kPair = kMT >= 2 ? 2 : 1;
+          constexpr int kPair = (kMT % 2 == 0) ? 2 : 1;
 #pragma unroll
           for (int mt0 = 0; mt0 < kMT; mt0 += kPair) {
             u32x4 b0[kPair], b1[kPair];
@@ -243,11 +243,11 @@ namespace {
 int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const void* cu_tiles128,
                        hipStream_t stream) {
   using namespace hpc::ggemm;
-  // groups above ~24 tokens: tiled kernels (need the scan of ceil(seqlens/128)): the 256 x 128 LDS-DMA ring
-  // kernel when n allows (measured faster than the streaming form from 32 tokens per group on: one pass
-  // over the weights for up to 128 tokens), else the 128 x 128 register-staged one
+  // groups above ~40 tokens: tiled kernels (need the scan of ceil(seqlens/128)): the 256 x 128 LDS-DMA ring
+  // kernel when n allows (one pass over the weights for up to 128 tokens; measured faster than the
+  // streaming form from ~40 tokens per group on), else the 128 x 128 register-staged one
   const int tiled_mode = hpc_tuning_get(3);  // 0 auto, 1 never, 2 always (when possible), 3 always, 128x128 only
-  if (cu_tiles128 && n % 128 == 0 && tiled_mode != 1 && (tiled_mode >= 2 || m / num_group > 24)) {
+  if (cu_tiles128 && n % 128 == 0 && tiled_mode != 1 && (tiled_mode >= 2 || m / num_group > 40)) {
     if (n % 256 == 0 && a.K >= 128 && tiled_mode != 3)
       return hpc_ggemm_launch_tiled256(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);
     return hpc_ggemm_launch_tiled(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);
@@ -256,8 +256,11 @@ int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const v
   // tileM the same way, fuse_moe/entry.cc:525-543); larger groups take several passes
   const int avg = m / num_group;
   const int forced = hpc_tuning_get(1);
-  // forced: 1 / 2 / 4 = tokens-per-pass 16 / 32 / 64 with 16 rows per wave; 8 = 64 tokens, 32 rows per wave
-  const int mt = forced ? forced : (avg <= 10 ? 1 : 2);
+  // forced: 1 / 2 / 3 / 4 = tokens-per-pass 16 / 32 / 48 / 64 with 16 rows per wave; 8 = 64 tokens, 32 rows per
+  // wave; 16 / 32 = 64 / 32 tokens with 8 waves per workgroup
+  // measured on E64 / top-8: 16 tokens per pass up to ~10 per group, 32 up to ~22, then 48 (one pass still
+  // covers nearly every group of a 32-average batch; 64 per pass is register-bound and slower)
+  const int mt = forced ? forced : (avg <= 10 ? 1 : (avg <= 22 ? 2 : 3));
   if (mt == 8 && n % 128 == 0) {
     dim3 grid(n / 128, num_group);
     gemm_blockwise_stream_kernel<4, 2><<<grid, kThreads, 0, stream>>>(a);
@@ -271,6 +274,8 @@ int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const v
     dim3 grid(n / 64, num_group);
     if (mt == 1)
       gemm_blockwise_stream_kernel<1, 1><<<grid, kThreads, 0, stream>>>(a);
+    else if (mt == 3)
+      gemm_blockwise_stream_kernel<3, 1, 4, 3><<<grid, kThreads, 0, stream>>>(a);
     else if (mt == 4)
       gemm_blockwise_stream_kernel<4, 1, 4, 3><<<grid, kThreads, 0, stream>>>(a);
     else

@@ -41,7 +41,7 @@ def aligned_size(avg: int) -> int:
 
 def _cu_tiles128(seqlens, m, num_group, stream):
     """Scan of ceil(seqlens/128) for the tiled (large-group) GEMM kernel; None keeps the streaming one."""
-    if m // max(num_group, 1) <= 24:
+    if m // max(num_group, 1) <= 40:
         return None
     tiles = torch.empty(num_group, dtype=torch.int32, device=seqlens.device)
     cu = torch.empty(num_group + 1, dtype=torch.int32, device=seqlens.device)

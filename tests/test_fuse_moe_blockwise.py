@@ -90,7 +90,7 @@ def test_moe_routing_is_bit_exact():
 @pytest.mark.gpu
 @pytest.mark.parametrize("num_group,actual_m,n,k", [(16, 30, 1024, 4096), (8, 5, 256, 512),
                                                     (4, 70, 384, 1408)])
-@pytest.mark.parametrize("forced_mt", [0, 1, 2, 4, 16, 32])
+@pytest.mark.parametrize("forced_mt", [0, 1, 2, 3, 4, 16, 32])
 def test_group_gemm_blockwise(num_group, actual_m, n, k, forced_mt):
     """forced_mt pins one streaming-kernel variant (tuning key 1: tokens per pass / waves per workgroup),
     0 = the launcher's own choice; every variant must meet the same bar."""
