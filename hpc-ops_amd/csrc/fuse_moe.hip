@@ -363,6 +363,39 @@ extern "C" int hpc_moe_tiles_async(const void* seqlens, int num_group, int tile_
   return HPC_OK;
 }
 
+// ---- x_scale [rows, K/128] (per group: rows cu_seqlens[g] ..) -> transposed, tile-padded, compact
+//      [K/128, m_pad]: column = (sum_{j<g} ceil(seqlens[j] / tilem)) * tilem + slot.
+// reference: reformat_x_scale_async (src/group_gemm/group_gemm.h:27-29), the DeepEP-layout companion of
+// group_gemm_blockwise_fp8.  Padding columns are left untouched.
+namespace {
+__global__ void reformat_x_scale_kernel(float* __restrict__ out, const float* __restrict__ xs,
+                                        const int* __restrict__ seqlens, const int* __restrict__ cu_seqlens,
+                                        int m, int n, int tilem) {
+  const int g = blockIdx.x;
+  int col0 = 0;
+  for (int j = 0; j < g; ++j) col0 += (seqlens[j] + tilem - 1) / tilem;
+  col0 *= tilem;
+  const int cnt = seqlens[g], row0 = cu_seqlens[g];
+  for (int i = threadIdx.x; i < cnt * n; i += blockDim.x) {
+    const int slot = i / n, kb = i % n;  // coalesced reads; the transposed writes are small
+    out[static_cast<long>(kb) * m + col0 + slot] = xs[static_cast<long>(row0 + slot) * n + kb];
+  }
+}
+}  // namespace
+
+extern "C" int hpc_reformat_x_scale_async(void* output_ptr, const void* xscale_ptr, const void* seqlens_ptr,
+                                          const void* cu_seqlens_ptr, int num_group, int m, int n, int tilem,
+                                          hipStream_t stream) {
+  if (!output_ptr || !xscale_ptr || !seqlens_ptr || !cu_seqlens_ptr) return HPC_ERR_INVALID;
+  if (num_group <= 0 || m <= 0 || n <= 0 || tilem <= 0) return HPC_ERR_INVALID;
+  reformat_x_scale_kernel<<<num_group, 256, 0, stream>>>(static_cast<float*>(output_ptr),
+                                                         static_cast<const float*>(xscale_ptr),
+                                                         static_cast<const int*>(seqlens_ptr),
+                                                         static_cast<const int*>(cu_seqlens_ptr), m, n, tilem);
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}
+
 // ---- activation + block quant ---------------------------------------------------------------------
 extern "C" int hpc_act_mul_and_blockwise_quant_async(void* out_ptr, void* out_scale_ptr,
                                                      const void* gate_up_ptr,

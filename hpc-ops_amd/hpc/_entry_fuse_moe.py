@@ -341,3 +341,68 @@ def _scaled_fp8_quant_entry(input, scale, output):
 
 
 _T.impl("scaled_fp8_quant", _scaled_fp8_quant_entry, "CUDA")
+
+
+# ---- DeepEP-format helper + the reference's raw cp.async group-GEMM ops ------------------------------------
+_T.define("reformat_x_scale(Tensor x_scale, Tensor seqlens, Tensor cu_seqlens, "
+          "Tensor? out_x_scale, int num_seq_per_group_avg) -> (Tensor)")
+_T.define("group_gemm_fp8_cp_async(Tensor x, Tensor weight, Tensor y_scale, Tensor seqlens, Tensor "
+          "cu_seqlens, Tensor tiles, Tensor cu_tiles, bool use_task_map=False) -> (Tensor)")
+_T.define("group_gemm_fp8_scatter_cp_async(Tensor x, Tensor weight, Tensor y_scale, Tensor "
+          "row_indices, Tensor seqlens, Tensor cu_seqlens, Tensor tiles, "
+          "Tensor cu_tiles, bool use_task_map=False) -> (Tensor)")
+
+
+def _reformat_x_scale_entry(x_scale, seqlens, cu_seqlens, out_x_scale, num_seq_per_group_avg):
+    # reference reformat_x_scale_entry, src/group_gemm/entry.cc:170-222
+    for t, name in ((x_scale, "x_scale"), (seqlens, "seqlens"), (cu_seqlens, "cu_seqlens")):
+        _C.require(t.is_cuda, f"{name} tensor must be cuda")
+        _C.require(t.is_contiguous(), f"{name} tensor a must be contiguous")
+    _C.require(x_scale.dtype == torch.float32 and x_scale.dim() == 2, "x_scale must be float32 [rows, K/128]")
+    m, n = x_scale.shape
+    num_group = seqlens.size(0)
+    avg = int(num_seq_per_group_avg)
+    tilem = 8 if avg <= 8 else 16 if avg <= 16 else 32 if avg <= 32 else 48 if avg <= 48 else 64
+    _C.require((m // num_group) % tilem == 0,
+               "The sparse pad length of x_scale for each group must be aligned to multiple of "
+               "8/16/32/48/64 according to num_seq_per_group_avg")
+    out = out_x_scale if out_x_scale is not None else torch.empty((n, m), dtype=x_scale.dtype, device=x_scale.device)
+    _C.require(out.is_contiguous() and out.dtype == torch.float32 and out.numel() >= n * m,
+               "out_x_scale must be a contiguous float32 [K/128, rows] tensor")
+    _C.check(_C.lib.hpc_reformat_x_scale_async(_C.ptr(out), _C.ptr(x_scale), _C.ptr(seqlens), _C.ptr(cu_seqlens),
+                                               num_group, m, n, tilem, _C.stream_of(x_scale)), "reformat_x_scale")
+    return out
+
+
+def _group_gemm_cp_async(x, weight, y_scale, row_indices, seqlens, cu_seqlens):
+    _cuda_contig(x, "x")
+    _cuda_contig(weight, "weight")
+    _C.require(x.dtype == torch.float8_e4m3fn and weight.dtype == torch.float8_e4m3fn, "x / weight must be fp8_e4m3")
+    _C.require(y_scale.dtype == torch.float32 and seqlens.dtype == torch.int32 and cu_seqlens.dtype == torch.int32,
+               "y_scale must be float32, seqlens / cu_seqlens int32")
+    num_group, n, k = weight.shape
+    m = row_indices.size(0) if row_indices is not None else x.size(0)
+    y = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
+    s = _C.stream_of(x)
+    rc = _C.lib.hpc_group_gemm_pertensor_fp8_async(
+        _C.ptr(y), _C.ptr(x), _C.ptr(weight), _C.ptr(seqlens), _C.ptr(cu_seqlens), _C.ptr(y_scale),
+        _C.ptr(row_indices), num_group, m, x.size(0), n, k, _cu_tiles128(seqlens, m, num_group, s), s)
+    _C.check(rc, "group_gemm_fp8_cp_async")
+    return y
+
+
+def _group_gemm_fp8_cp_async_entry(x, weight, y_scale, seqlens, cu_seqlens, tiles, cu_tiles, use_task_map=False):
+    # reference src/group_gemm/cp_async/entry.cc (the caller's 64-row tile tables are not needed here)
+    return _group_gemm_cp_async(x, weight, y_scale, None, seqlens, cu_seqlens)
+
+
+def _group_gemm_fp8_scatter_cp_async_entry(x, weight, y_scale, row_indices, seqlens, cu_seqlens, tiles, cu_tiles,
+                                           use_task_map=False):
+    _C.require(row_indices.is_cuda and row_indices.dtype == torch.int32 and row_indices.is_contiguous(),
+               "row_indices must be a contiguous cuda int32 tensor")
+    return _group_gemm_cp_async(x, weight, y_scale, row_indices, seqlens, cu_seqlens)
+
+
+_T.impl("reformat_x_scale", _reformat_x_scale_entry, "CUDA")
+_T.impl("group_gemm_fp8_cp_async", _group_gemm_fp8_cp_async_entry, "CUDA")
+_T.impl("group_gemm_fp8_scatter_cp_async", _group_gemm_fp8_scatter_cp_async_entry, "CUDA")

@@ -52,3 +52,37 @@ def group_gemm_fp8(x: Tensor, weight: Tensor, seqlens: Tensor, cu_seqlens: Tenso
     """Alias kept by the reference (hpc/group_gemm.py:110-131)."""
     return torch.ops.hpc.group_gemm_fp8(x, weight, seqlens, cu_seqlens, y_scale, num_seq_per_group_avg,
                                         output, tma_desc, task_map_workspace)
+
+
+def reformat_x_scale(
+    x_scale: Tensor,
+    seqlens: Tensor,
+    cu_seqlens: Tensor,
+    num_seq_per_group_avg: int,
+    output: Tensor = None,
+) -> Tensor:
+    """Transpose, tile-pad and compact the activation scales of DeepEP-format inputs into the layout
+    group_gemm_blockwise_fp8 reads (reference hpc/group_gemm.py:8-48).
+
+    x_scale f32 [total_seq_pad, K/128] (group g's rows start at cu_seqlens[g], seqlens[g] of them valid);
+    returns f32 [K/128, total_seq_pad] where group g starts at column (sum_{j<g} ceil(seqlens[j]/tileM))*tileM,
+    tileM = 8/16/32/48/64 from num_seq_per_group_avg.  Padding columns are left as they are."""
+    return torch.ops.hpc.reformat_x_scale(x_scale, seqlens, cu_seqlens, output, num_seq_per_group_avg)
+
+
+@torch.library.register_fake("hpc::reformat_x_scale")
+def _reformat_x_scale_fake(x_scale, seqlens, cu_seqlens, out_x_scale, num_seq_per_group_avg):
+    if out_x_scale is not None:
+        return out_x_scale
+    return torch.empty((x_scale.shape[1], x_scale.shape[0]), dtype=x_scale.dtype, device=x_scale.device)
+
+
+@torch.library.register_fake("hpc::group_gemm_fp8_cp_async")
+def _group_gemm_fp8_cp_async_fake(x, weight, y_scale, seqlens, cu_seqlens, tiles, cu_tiles, use_task_map=False):
+    return torch.empty((x.shape[0], weight.shape[1]), dtype=torch.bfloat16, device=x.device)
+
+
+@torch.library.register_fake("hpc::group_gemm_fp8_scatter_cp_async")
+def _group_gemm_fp8_scatter_cp_async_fake(x, weight, y_scale, row_indices, seqlens, cu_seqlens, tiles, cu_tiles,
+                                          use_task_map=False):
+    return torch.empty((row_indices.shape[0], weight.shape[1]), dtype=torch.bfloat16, device=x.device)

@@ -262,6 +262,12 @@ int hpc_gemm_bf16xfp32_async(void* y, void* splitk_y, void* split_flag, const vo
                              const void* w_low, int m, int n, int k, float scale, int use_fp32_output,
                              int splits, int flag_ld, hpc_stream_t stream);
 
+/* x_scale [rows, n = K/128] -> transposed, tile-padded, compact [n, m] layout that
+ * hpc_group_gemm_blockwise_fp8_async reads (DeepEP-format inputs).
+ * reference: reformat_x_scale_async, src/group_gemm/group_gemm.h:27-29 (entry src/group_gemm/entry.cc:170-222). */
+int hpc_reformat_x_scale_async(void* output, const void* x_scale, const void* seqlens, const void* cu_seqlens,
+                               int num_group, int m, int n, int tilem, hpc_stream_t stream);
+
 /* ---- paged-KV causal prefill attention, FP8 ----
  * reference: attention_with_kvcache_prefill_{qpertoken_perhead_kvpertensor,qkpertoken_perhead_vperhead}_fp8_async
  *            (src/attention/prefill/prefill.h, entry src/attention/entry.cc:152-262).

@@ -181,3 +181,42 @@ def test_group_gemm_blockwise_tiled_kernels(tiled_mode, n, k):
     finally:
         hpc._C.lib.hpc_tuning_set(3, 0)
     assert allclose(gt.float(), my.cpu().float(), rtol=0.01, atol=0.02)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_group,actual_m,m", [(8, 30, 1280), (8, 7, 64), (4, 48, 96), (4, 100, 128)])
+def test_reformat_x_scale_and_deepep_group_gemm(num_group, actual_m, m):
+    """reformat_x_scale (reference tests/test_group_gemm_blockwise.py:86-148) and the DeepEP-format call it
+    serves: every group owns m padded rows of x, seqlens[g] of them valid (:162-223)."""
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    k, n = 4096, 256
+    g = torch.Generator().manual_seed(3)
+    total_pad = m * num_group
+    xscale = torch.rand((total_pad, k // 128), generator=g)
+    seqlens = torch.full((num_group,), actual_m, dtype=torch.int32)
+    seqlens[-1] = actual_m - 3
+    cu = torch.arange(0, (num_group + 1) * m, m, dtype=torch.int32)
+    mean = int(seqlens.sum()) // num_group
+    tilem = 8 if mean <= 8 else 16 if mean <= 16 else 32 if mean <= 32 else 48 if mean <= 48 else 64
+    ref = torch.zeros((k // 128, total_pad))
+    col = 0
+    for i in range(num_group):
+        c = int(seqlens[i])
+        ref[:, col : col + c] = xscale[int(cu[i]) : int(cu[i]) + c].t()
+        col += (c + tilem - 1) // tilem * tilem
+    out = torch.zeros((k // 128, total_pad), device="cuda")
+    got = hpc.reformat_x_scale(xscale.cuda(), seqlens.cuda(), cu.cuda(), mean, out)
+    assert got.data_ptr() == out.data_ptr()
+    assert torch.equal(ref, got.cpu())  # pure data movement: bit-exact, padding columns untouched (zeros)
+    # the grouped GEMM on the reformatted scales == the oracle on the valid rows
+    x = (torch.randn((total_pad, k), generator=g) / 10).to(F8)
+    w = (torch.randn((num_group, n, k), generator=g) / 10).to(F8)
+    wscale = torch.randn((num_group, n // 128, k // 128), generator=g)
+    gt = omoe.group_gemm_blockwise(x, w, seqlens, cu, xscale, wscale)
+    my = hpc.group_gemm_blockwise_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), got, wscale.cuda(),
+                                      num_seq_per_group_avg=mean)
+    for i in range(num_group):
+        a, c = int(cu[i]), int(seqlens[i])
+        assert allclose(gt[a : a + c].float(), my.cpu()[a : a + c].float(), rtol=0.01, atol=0.05)

@@ -128,3 +128,36 @@ def test_group_gemm_pertensor_tiled_kernels(tiled_mode, k):
     finally:
         hpc._C.lib.hpc_tuning_set(3, 0)
     assert allclose(gt.float(), my.cpu().float(), rtol=0.08, atol=0.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_group,actual_m,n,k", [(48, 64, 512, 256), (48, 42, 512, 192), (16, 8, 1024, 256),
+                                                    (8, 200, 256, 1024)])
+@pytest.mark.parametrize("scatter", [False, True])
+def test_group_gemm_cp_async_ops(num_group, actual_m, n, k, scatter):
+    """raw torch.ops.hpc.group_gemm_fp8[_scatter]_cp_async (reference tests/test_group_gemm_cp_async.py:65-110):
+    the scatter form reads its rows from a pool through row_indices."""
+    import hpc  # noqa: F401
+    from oracle import fuse_moe as omoe
+
+    g = torch.Generator().manual_seed(10086)
+    seqlens = torch.full((num_group,), actual_m, dtype=torch.int32)
+    seqlens[1] = max(actual_m - 5, 0)
+    total = int(seqlens.sum())
+    pool = torch.randn((total + 7, k), generator=g).to(F8)
+    w = torch.randn((num_group, n, k), generator=g).to(F8)
+    scale = torch.rand(num_group, generator=g) + 0.5
+    rows = torch.randperm(total + 7, generator=g)[:total].to(torch.int32)
+    cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
+    tiles = (seqlens + 63) // 64
+    cu_tiles = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(tiles, 0).to(torch.int32)])
+    x_compact = pool[rows.long()]
+    gt = omoe.group_gemm_pertensor(x_compact, w, seqlens, cu, scale)
+    d = lambda t: t.cuda()  # noqa: E731
+    if scatter:
+        my = torch.ops.hpc.group_gemm_fp8_scatter_cp_async(d(pool), d(w), d(scale), d(rows), d(seqlens), d(cu),
+                                                           d(tiles), d(cu_tiles), False)
+    else:
+        my = torch.ops.hpc.group_gemm_fp8_cp_async(d(x_compact), d(w), d(scale), d(seqlens), d(cu), d(tiles),
+                                                   d(cu_tiles), True)
+    assert allclose(gt.float(), my.cpu().float(), rtol=0.08, atol=1)
