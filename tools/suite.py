@@ -100,6 +100,24 @@ def main():
     # ---- C4: fused MoE blockwise ----
     toks = (4, 16, 64, 128, 256, 1024, 4096) if not quick else (16, 256)
     out.update(bench.extra_moe(dev, hpc, tokens=toks))
+    # ---- C4': the per-tensor fused MoE API the reference's benchmark driver calls (same GEMM kernels) ----
+    E, k, H, I = 64, 8, 4096, 11008
+    torch.manual_seed(41)
+    guw = torch.randint(-80, 80, (E, 2 * I, H), dtype=torch.int8, device=dev).view(F8)
+    dw = torch.randint(-80, 80, (E, H, I), dtype=torch.int8, device=dev).view(F8)
+    gus, ds, ams = torch.rand(E, device=dev) * 0.01, torch.rand(E, device=dev) * 0.01, torch.ones(1, device=dev)
+    res = {}
+    for T in ((16, 256, 4096) if not quick else (16,)):
+        ids = torch.sort(torch.multinomial(torch.ones(T, E, device=dev), k).to(torch.int32), dim=1)[0]
+        sc = torch.rand(T, k, device=dev)
+        x = (torch.randn(T, H, device=dev) / 100).to(F8)
+        us = bench.timed(lambda: hpc.fuse_moe_pertensor_fp8(x, guw, dw, gus, ds, ams, ids, sc, 0, E), iters=10, warm=2)
+        hit = int(torch.unique(ids).numel())
+        res[f"T{T}"] = {"us": round(us, 1), "TFLOPS": round(2.0 * T * k * 3 * I * H / us / 1e6, 1),
+                        "weight_GBps": round(hit * 3 * I * H / us / 1e3, 1)}
+    out["fuse_moe_pertensor_fp8_E64_top8_H4096_I11008"] = res
+    print(res, flush=True)
+    del guw, dw
     # ---- C1: RMSNorm + fp8 quant ----
     torch.manual_seed(0)
     x = torch.randn(1024, 4096, device=dev).bfloat16()
