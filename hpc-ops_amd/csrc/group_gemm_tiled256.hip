@@ -137,54 +137,86 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
       b_off[i][c] = kWBytes + rb * kBK + (((g4 + 4 * c) ^ (rb & 7)) << 4);
     }
 
+  // ---- software pipeline --------------------------------------------------------------------------------
+  // The ring holds slabs kb (being consumed), kb+1 (landed by mid-step) and kb+2 (in flight).  Operand
+  // fragments are read one MFMA group ahead - the second half of slab kb before the first half's MFMAs,
+  // the first half of slab kb+1 before the second half's - so LDS latency hides behind 32 MFMAs, and the
+  // single barrier of a k-step sits between the two MFMA groups: past it every wave has finished reading
+  // slab kb (its slot is refilled with slab kb+3) and slab kb+1 is visible.
+  auto read_frags = [&](const uint8_t* slab, int c, u32x4 (&af)[4], u32x4 (&bf)[4]) {
 #pragma unroll
-  for (int st = 0; st < kStages - 1; ++st) issue(st);
-
-  for (int kb = 0; kb < KB; ++kb) {
-    // slab kb has landed when at most (kStages - 2) younger slabs are outstanding
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (kDmaPerStage * (kStages - 2)));
-    __builtin_amdgcn_s_barrier();
-    issue(kb + kStages - 1);
-    const uint8_t* slab = s_ring + (kb % kStages) * kStageBytes;
-    const float wsk = __int_as_float(ws_row[kb * a.ws_kb_stride]);
-    float f[4];
+    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4*>(slab + a_off[i][c]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f[j] = wsk;
-      if constexpr (kHasXs)
-        f[j] *= *reinterpret_cast<const float*>(slab + kWBytes + kXBytes + wm * 256 + (j * 16 + r16) * 4);
-    }
-    f32x4 part[4][4];
+    for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const u32x4*>(slab + b_off[j][c]);
+  };
+  auto mma_group = [&](f32x4 (&acc)[4][4], const u32x4 (&af)[4], const u32x4 (&bf)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) part[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(af[i][0], af[i][1]), pack64(bf[j][0], bf[j][1]),
+                                                              acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(af[i][2], af[i][3]), pack64(bf[j][2], bf[j][3]),
+                                                              acc[i][j], 0, 0, 0);
+      }
+  };
+
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      u32x4 af[4], bf[4];
+  for (int st = 0; st < kStages; ++st) issue(st);
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (kDmaPerStage * (kStages - 1)));  // slab 0 has landed
+  __builtin_amdgcn_s_barrier();
+  u32x4 a0[4], b0[4], a1[4], b1[4];
+  read_frags(s_ring, 0, a0, b0);
+
+  for (int kb = 0; kb < KB; ++kb) {
+    const uint8_t* slab = s_ring + (kb % kStages) * kStageBytes;
+    const uint8_t* next = s_ring + ((kb + 1) % kStages) * kStageBytes;
+    read_frags(slab, 1, a1, b1);
+    float f[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (kHasXs) {
+      const float wsk = __int_as_float(ws_row[kb * a.ws_kb_stride]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4*>(slab + a_off[i][c]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const u32x4*>(slab + b_off[j][c]);
+      for (int j = 0; j < 4; ++j)
+        f[j] = wsk * *reinterpret_cast<const float*>(slab + kWBytes + kXBytes + wm * 256 + (j * 16 + r16) * 4);
+    }
+    f32x4 part[kHasXs ? 4 : 1][kHasXs ? 4 : 1];
+    if constexpr (kHasXs) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          part[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(af[i][0], af[i][1]),
-                                                                 pack64(bf[j][0], bf[j][1]), part[i][j], 0, 0, 0);
-          part[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(af[i][2], af[i][3]),
-                                                                 pack64(bf[j][2], bf[j][3]), part[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j) part[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mma_group(part, a0, b0);
+    } else {
+      // one scale per group: accumulate straight into the running sum, scale once in the epilogue
+      // (the reference scales every k-tile, kernels.cuh:473-476: same value up to fp32 rounding)
+      mma_group(tot, a0, b0);
     }
+    // slab kb+1 has landed when only slab kb+2 is outstanding; lgkmcnt(0): my reads of slab kb are done
+    __builtin_amdgcn_s_waitcnt(0x0070 | kDmaPerStage);
+    __builtin_amdgcn_s_barrier();
+    issue(kb + kStages);
+    read_frags(next, 0, a0, b0);
+    if constexpr (kHasXs) {
+      mma_group(part, a1, b1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tot[i][j][r] = fmaf(part[i][j][r], f[j], tot[i][j][r]);
+          for (int r = 0; r < 4; ++r) tot[i][j][r] = fmaf(part[i][j][r], f[j], tot[i][j][r]);
+    } else {
+      mma_group(tot, a1, b1);
+    }
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the (empty) tail DMAs before the workgroup's LDS is released
 
+  if constexpr (!kHasXs) {
+    const float gs = __int_as_float(ws_row[0]);  // per-tensor form: strides are zero, one scale per group
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tot[i][j] *= gs;
+  }
   // ---- epilogue: lane holds rows n = wn*64 + i*16 + g4*4 + r of token column wm*64 + j*16 + r16 --------------
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
