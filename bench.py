@@ -250,8 +250,18 @@ def extra_prefill(dev, hpc):
     us = timed(lambda: hpc.attention_with_kvcache_prefill_fp8(q, kc, vc, qs, ks, vs, cu, bid, lens, S, output=y),
                iters=10, warm=2, graph=True)
     flops = 4.0 * D * Hq * B * (S * (S + 1) / 2)
-    return {"attention_prefill_fp8_4x4096_h64_8": {"us": round(us, 1), "TFLOPS": round(flops / us / 1e6, 1),
-                                                    "mfma_frac_of_2.5PF": round(flops / us / 1e6 / 2500, 4)}}
+    res = {"us": round(us, 1), "TFLOPS": round(flops / us / 1e6, 1),
+           "mfma_frac_of_2.5PF": round(flops / us / 1e6 / 2500, 4)}
+    # block-sparse form: random 128 x 128 tile mask per q head, half of the causal tiles dropped
+    nt = S // 128
+    bm = torch.rand(B, Hq, nt, nt, device=dev) >= 0.5
+    row, col = torch.arange(nt, device=dev).view(nt, 1), torch.arange(nt, device=dev).view(1, nt)
+    bm = ((bm & (col <= row)) | (col == row)).to(torch.uint8).contiguous()
+    us_sp = timed(lambda: hpc.attention_with_kvcache_blocksparse_prefill_fp8(q, kc, vc, qs, ks, vs, cu, bid, lens, S,
+                                                                             block_mask=bm, output=y),
+                  iters=10, warm=2, graph=True)
+    res["blocksparse_skip0.5_us"] = round(us_sp, 1)
+    return {"attention_prefill_fp8_4x4096_h64_8": res}
 
 
 def extra_moe(dev, hpc, tokens=(16, 64, 256, 4096)):

@@ -30,6 +30,8 @@ struct Args {
   const float* qscale;  // [B][Hq][qs_pad]
   const float* kscale;  // [1] or base of the per-token K-scale rows
   const float* vscale;  // [1] or [Hkv]
+  const uint8_t* block_mask;  // null, or [B][Hq][mask_tiles_m][mask_tiles_kv]: 128 x 128 (q pos x kv token) tiles
+  int mask_tiles_m, mask_tiles_kv;
   int num_batch, num_head_q, num_head_kv, g_shift, page_shift, max_blocks, qs_pad;
   int ldq, ldy;
   long k_block_stride, k_token_stride, k_head_stride;  // elements (= bytes)
@@ -91,6 +93,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   u32x4 qf[kNB][2];
   float row_scale[kNB];
   int row_lim[kNB];  // last visible key of this lane's q row (-1: row does not exist)
+  const uint8_t* row_mask[kNB];  // block-sparse: this row's [kv tile] mask bytes
 #pragma unroll
   for (int nb = 0; nb < kNB; ++nb) {
     const int row = row0 + nb * 16 + n;
@@ -98,6 +101,10 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
     const int hq = (h << a.g_shift) + (row & (G - 1));
     const bool ok = pos < Sq;
     row_lim[nb] = ok ? past + pos : -1;
+    row_mask[nb] = a.block_mask
+                       ? a.block_mask + ((static_cast<long>(b) * a.num_head_q + hq) * a.mask_tiles_m +
+                                         min(pos >> 7, a.mask_tiles_m - 1)) * a.mask_tiles_kv
+                       : nullptr;
     const long qoff = static_cast<long>(q0 + pos) * a.ldq + hq * 128;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -164,14 +171,34 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
     l_run[nb] = 0.f;
   }
 
+  // block-sparse: a 64-token tile t belongs to mask column t / 2.  A row computes the tile only if its
+  // (head, q tile) bit is set; the workgroup's rows all sit in one 128-position q tile and share the
+  // G heads of this kv head, so "no row needs tile t" is the same in every wave: such tiles are neither
+  // fetched nor computed.
+  auto tile_bits = [&](int t, bool (&bit)[kNB]) {
+    bool any = false;
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) {
+      bit[nb] = true;
+      // (rows past the request still read their head's byte: the decision below must not depend on
+      //  which rows exist, or waves of the last workgroup would disagree about fetching the tile)
+      if (a.block_mask) bit[nb] = row_mask[nb][min(t >> 1, a.mask_tiles_kv - 1)] != 0;
+      any |= bit[nb];
+    }
+    return a.block_mask ? __ballot(any) != 0 : true;
+  };
+  bool bit_cur[kNB], bit_next[kNB] = {};
+  bool need_cur = tile_bits(0, bit_cur);
   fetch(0);
   stash(0);
   __syncthreads();
   for (int t = 0; t < ntile; ++t) {
     const int buf = t & 1;
-    fetch(t + 1);
+    const bool need_next = t + 1 < ntile && tile_bits(t + 1, bit_next);
+    if (need_next) fetch(t + 1);
     const uint8_t* kt = s_k[buf];
     const uint8_t* vt = s_v[buf];
+    if (need_cur) {
 
     // ---- S^T = K Q^T --------------------------------------------------------------------------------
     f32x4 s[kNB][4];
@@ -198,10 +225,14 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
     // ---- online softmax, base 2.  p is produced as 256 p (the +8 rides in the exponent): it feeds the
     // e4m3 pack directly and the row sum is kept in the same units (undone once in the epilogue). -------
     uint32_t pf[kNB][2][2];
-    const bool masked = t >= ntile_full;
+    bool all_bits = true;
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) all_bits &= bit_cur[nb] || row_lim[nb] < 0;
+    const bool masked = t >= ntile_full || (a.block_mask && __ballot(!all_bits) != 0);
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) {
       const float rs = row_scale[nb];
+      const int lim = bit_cur[nb] ? row_lim[nb] : -1;
       float mt;
       const bool fast = kQuant == 1 && !masked;  // per-row scale only, nothing to mask: never form s * rs
       if (fast) {
@@ -226,7 +257,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
             if constexpr (kQuant == 0) x *= kscl[r];
             if (masked) {
               const int tok = t * 64 + tb * 16 + g * 4 + r;
-              x = tok <= row_lim[nb] ? x : kNegInf;
+              x = tok <= lim ? x : kNegInf;
             }
             s[nb][tb][r] = x;
             mt = fmaxf(mt, x);
@@ -289,8 +320,12 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
                                                                  o[nb][jj], 0, 0, 0);
       }
     }
-    stash(buf ^ 1);
+    }  // need_cur
+    if (need_next) stash(buf ^ 1);
     __syncthreads();
+    need_cur = need_next;
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) bit_cur[nb] = bit_next[nb];
   }
 
   // ---- finish: row-major re-read through the wave's LDS tile, scale, bf16 store ---------------------------
@@ -331,7 +366,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
 // reference: attention_with_kvcache_prefill_{qpertoken_perhead_kvpertensor,qkpertoken_perhead_vperhead}_fp8_async
 // (src/attention/prefill/prefill.h; argument meaning kept; TMA scratch dropped).  quant_type 1 / 0 as in
 // hpc_attention_decode_fp8_async; kscale strides (bytes) only for quant_type 0.
-extern "C" int hpc_attention_with_kvcache_prefill_fp8_async(
+static int prefill_fp8_launch(const void* block_mask_ptr, int mask_tiles_m, int mask_tiles_kv,
     void* y_ptr, const void* q_ptr, const void* kcache_ptr, const void* vcache_ptr, const void* qscale_ptr,
     const void* kscale_ptr, const void* vscale_ptr, const void* cu_seqlens_q_ptr, const void* block_ids_ptr,
     const void* seqlens_kvcache_ptr, int quant_type, int num_batch, int max_seqlens_q, int max_seqlens_q_pad,
@@ -367,6 +402,10 @@ extern "C" int hpc_attention_with_kvcache_prefill_fp8_async(
   a.qscale = static_cast<const float*>(qscale_ptr);
   a.kscale = static_cast<const float*>(kscale_ptr);
   a.vscale = static_cast<const float*>(vscale_ptr);
+  a.block_mask = static_cast<const uint8_t*>(block_mask_ptr);
+  a.mask_tiles_m = mask_tiles_m;
+  a.mask_tiles_kv = mask_tiles_kv;
+  if (block_mask_ptr && (mask_tiles_m <= 0 || mask_tiles_kv <= 0)) return HPC_ERR_INVALID;
   a.num_batch = num_batch;
   a.num_head_q = num_head_q;
   a.num_head_kv = num_head_kv;
@@ -396,4 +435,44 @@ extern "C" int hpc_attention_with_kvcache_prefill_fp8_async(
     prefill_fp8_kernel<0><<<grid, kThreads, 0, stream>>>(a);
   HPC_CHECK_LAUNCH();
   return HPC_OK;
+}
+
+extern "C" int hpc_attention_with_kvcache_prefill_fp8_async(
+    void* y_ptr, const void* q_ptr, const void* kcache_ptr, const void* vcache_ptr, const void* qscale_ptr,
+    const void* kscale_ptr, const void* vscale_ptr, const void* cu_seqlens_q_ptr, const void* block_ids_ptr,
+    const void* seqlens_kvcache_ptr, int quant_type, int num_batch, int max_seqlens_q, int max_seqlens_q_pad,
+    int num_dim_qk, int num_dim_v, int num_head_q, int num_head_kv, int block_size, int num_seq_max_blocks,
+    int ldY, int ldQ, int64_t kcache_block_stride, int64_t kcache_token_stride, int64_t kcache_head_stride,
+    int64_t vcache_block_stride, int64_t vcache_token_stride, int64_t vcache_head_stride,
+    int64_t kscale_block_stride_bytes, int64_t kscale_row_stride_bytes, int64_t kscale_head_stride_bytes,
+    hipStream_t stream) {
+  return prefill_fp8_launch(nullptr, 0, 0, y_ptr, q_ptr, kcache_ptr, vcache_ptr, qscale_ptr, kscale_ptr, vscale_ptr,
+                            cu_seqlens_q_ptr, block_ids_ptr, seqlens_kvcache_ptr, quant_type, num_batch,
+                            max_seqlens_q, max_seqlens_q_pad, num_dim_qk, num_dim_v, num_head_q, num_head_kv,
+                            block_size, num_seq_max_blocks, ldY, ldQ, kcache_block_stride, kcache_token_stride,
+                            kcache_head_stride, vcache_block_stride, vcache_token_stride, vcache_head_stride,
+                            kscale_block_stride_bytes, kscale_row_stride_bytes, kscale_head_stride_bytes, stream);
+}
+
+// reference: attention_with_kvcache_blocksparse_prefill_fp8 (src/attention/entry.cc:264-409): the same
+// kernel family with an optional uint8 block mask [B, Hq, ceil(max_seqlens_q / 128), mask_tiles_kv] over
+// 128 (q positions) x 128 (kv tokens) tiles; null mask = dense.
+extern "C" int hpc_attention_with_kvcache_blocksparse_prefill_fp8_async(
+    void* y_ptr, const void* q_ptr, const void* kcache_ptr, const void* vcache_ptr, const void* qscale_ptr,
+    const void* kscale_ptr, const void* vscale_ptr, const void* cu_seqlens_q_ptr, const void* block_ids_ptr,
+    const void* seqlens_kvcache_ptr, const void* block_mask_ptr, int mask_tiles_m, int mask_tiles_kv,
+    int quant_type, int num_batch, int max_seqlens_q, int max_seqlens_q_pad, int num_dim_qk, int num_dim_v,
+    int num_head_q, int num_head_kv, int block_size, int num_seq_max_blocks, int ldY, int ldQ,
+    int64_t kcache_block_stride, int64_t kcache_token_stride, int64_t kcache_head_stride,
+    int64_t vcache_block_stride, int64_t vcache_token_stride, int64_t vcache_head_stride,
+    int64_t kscale_block_stride_bytes, int64_t kscale_row_stride_bytes, int64_t kscale_head_stride_bytes,
+    hipStream_t stream) {
+  if (128 % block_size) return HPC_ERR_UNSUPPORTED;
+  return prefill_fp8_launch(block_mask_ptr, mask_tiles_m, mask_tiles_kv, y_ptr, q_ptr, kcache_ptr, vcache_ptr,
+                            qscale_ptr, kscale_ptr, vscale_ptr, cu_seqlens_q_ptr, block_ids_ptr, seqlens_kvcache_ptr,
+                            quant_type, num_batch, max_seqlens_q, max_seqlens_q_pad, num_dim_qk, num_dim_v,
+                            num_head_q, num_head_kv, block_size, num_seq_max_blocks, ldY, ldQ, kcache_block_stride,
+                            kcache_token_stride, kcache_head_stride, vcache_block_stride, vcache_token_stride,
+                            vcache_head_stride, kscale_block_stride_bytes, kscale_row_stride_bytes,
+                            kscale_head_stride_bytes, stream);
 }

@@ -76,6 +76,8 @@ _sig("hpc_gemm_bf16xfp32_splits", I, I, I, I, I)
 _sig("hpc_gemm_bf16xfp32_async", I, P, P, P, P, P, P, I, I, I, F, I, I, I, P)
 _sig("hpc_attention_with_kvcache_prefill_fp8_async", I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I,
      I, I, L, L, L, L, L, L, L, L, L, P)
+_sig("hpc_attention_with_kvcache_blocksparse_prefill_fp8_async", I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I,
+     I, I, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, P)
 _sig("hpc_reformat_x_scale_async", I, P, P, P, P, I, I, I, I, P)
 _sig("hpc_sampler_segments", I, I)
 _sig("hpc_fused_sampler_workspace_bytes", L, I, I, I)

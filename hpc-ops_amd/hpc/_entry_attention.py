@@ -240,7 +240,8 @@ _T.define(
 
 
 def _attention_prefill_fp8_entry(q, kcache, vcache, qscale, kscale, vscale, cu_seqlens_q, block_ids,
-                                 seqlens_kvcache, max_seqlens_q, quant_type, output=None):
+                                 seqlens_kvcache, max_seqlens_q, quant_type, output=None, block_mask=None,
+                                 blocksparse=False):
     # reference attention_with_kvcache_prefill_fp8_entry, src/attention/entry.cc:152-262
     for t, name in ((q, "q"), (kcache, "kcache"), (vcache, "vcache"), (qscale, "qscale"), (kscale, "kscale"),
                     (vscale, "vscale"), (cu_seqlens_q, "cu_seqlens_q"), (block_ids, "block_ids"),
@@ -283,6 +284,29 @@ def _attention_prefill_fp8_entry(q, kcache, vcache, qscale, kscale, vscale, cu_s
         y = torch.empty((total_q, num_head_q, dim_v), dtype=torch.bfloat16, device=q.device)
     if total_q == 0:
         return y
+    if blocksparse:
+        _C.require(128 % block_size == 0, "unsupported block_size for FP8 blocksparse prefill")
+        tiles_m = (int(max_seqlens_q) + 127) // 128
+        tiles_kv = 0
+        if block_mask is not None:
+            _C.require(block_mask.device == q.device, "block_mask tensor must be on the same device as q")
+            _C.require(block_mask.dtype == torch.uint8, "block_mask dtype must be uint8")
+            _C.require(block_mask.is_contiguous(), "block_mask tensor must be contiguous")
+            _C.require(block_mask.dim() == 4 and block_mask.size(0) == num_batch and block_mask.size(1) == num_head_q
+                       and block_mask.size(2) == tiles_m,
+                       f"block_mask must have shape [{num_batch}, {num_head_q}, {tiles_m}, Kb] where "
+                       "Kb = ceil(max_kv_len / kTileN=128)")
+            tiles_kv = block_mask.size(3)
+            _C.require(tiles_kv > 0, "block_mask Kb dim must be > 0")
+        rc = _C.lib.hpc_attention_with_kvcache_blocksparse_prefill_fp8_async(
+            _C.ptr(y), _C.ptr(q), _C.ptr(kcache), _C.ptr(vcache), _C.ptr(qscale), _C.ptr(kscale), _C.ptr(vscale),
+            _C.ptr(cu_seqlens_q), _C.ptr(block_ids), _C.ptr(seqlens_kvcache), _C.ptr(block_mask), tiles_m, tiles_kv,
+            int(quant_type), num_batch, int(max_seqlens_q), qscale.size(2), dim_qk, dim_v, num_head_q, num_head_kv,
+            block_size, block_ids.size(1), y.stride(0), q.stride(0), kcache.stride(0), kcache.stride(1),
+            kcache.stride(2), vcache.stride(0), vcache.stride(1), vcache.stride(2), ks[0], ks[1], ks[2],
+            _C.stream_of(q))
+        _C.check(rc, "attention_with_kvcache_blocksparse_prefill_fp8")
+        return y
     rc = _C.lib.hpc_attention_with_kvcache_prefill_fp8_async(
         _C.ptr(y), _C.ptr(q), _C.ptr(kcache), _C.ptr(vcache), _C.ptr(qscale), _C.ptr(kscale), _C.ptr(vscale),
         _C.ptr(cu_seqlens_q), _C.ptr(block_ids), _C.ptr(seqlens_kvcache), int(quant_type), num_batch,
@@ -294,3 +318,21 @@ def _attention_prefill_fp8_entry(q, kcache, vcache, qscale, kscale, vscale, cu_s
 
 
 _T.impl("attention_with_kvcache_prefill_fp8", _attention_prefill_fp8_entry, "CUDA")
+
+
+_T.define(
+    "attention_with_kvcache_blocksparse_prefill_fp8(Tensor q, Tensor kcache, Tensor vcache, Tensor qscale, "
+    "Tensor kscale, Tensor vscale, Tensor cu_seqlens_q, Tensor block_ids, Tensor seqlens_kvcache, "
+    "int max_seqlens_q, int quant_type, Tensor? block_mask, Tensor? output) -> Tensor"
+)
+
+
+def _attention_blocksparse_prefill_fp8_entry(q, kcache, vcache, qscale, kscale, vscale, cu_seqlens_q, block_ids,
+                                             seqlens_kvcache, max_seqlens_q, quant_type, block_mask=None,
+                                             output=None):
+    # reference attention_with_kvcache_blocksparse_prefill_fp8_entry, src/attention/entry.cc:264-409
+    return _attention_prefill_fp8_entry(q, kcache, vcache, qscale, kscale, vscale, cu_seqlens_q, block_ids,
+                                        seqlens_kvcache, max_seqlens_q, quant_type, output, block_mask, True)
+
+
+_T.impl("attention_with_kvcache_blocksparse_prefill_fp8", _attention_blocksparse_prefill_fp8_entry, "CUDA")

@@ -221,3 +221,36 @@ def _attention_with_kvcache_prefill_fp8_fake(q, kcache, vcache, qscale, kscale, 
     if output is not None:
         return output
     return torch.empty((q.shape[0], q.shape[1], vcache.shape[-1]), dtype=torch.bfloat16, device=q.device)
+
+
+def attention_with_kvcache_blocksparse_prefill_fp8(
+    q: Tensor,
+    kcache: Tensor,
+    vcache: Tensor,
+    qscale: Tensor,
+    kscale: Tensor,
+    vscale: Tensor,
+    cu_seqlens_q: Tensor,
+    block_ids: Tensor,
+    seqlens_kvcache: Tensor,
+    max_seqlens_q: int,
+    quant_type: QuantType = QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR,
+    block_mask: Tensor = None,
+    output: Tensor = None,
+) -> Tensor:
+    """Dense / block-sparse causal prefill over the paged FP8 cache (reference hpc/attention.py:253-339).
+    Arguments as attention_with_kvcache_prefill_fp8 plus block_mask uint8
+    [num_batch, num_head_q, ceil(max_seqlens_q/128), Kb]: only 128 x 128 (q positions x kv tokens) tiles marked
+    non-zero are attended (None = dense).  Keep the causal diagonal tile of every q tile set: a q row with no
+    active key yields zeros here (NaN in the reference's PyTorch model)."""
+    return torch.ops.hpc.attention_with_kvcache_blocksparse_prefill_fp8(
+        q, kcache, vcache, qscale, kscale, vscale, cu_seqlens_q, block_ids, seqlens_kvcache, int(max_seqlens_q),
+        quant_type.value, block_mask, output)
+
+
+@torch.library.register_fake("hpc::attention_with_kvcache_blocksparse_prefill_fp8")
+def _attention_blocksparse_prefill_fp8_fake(q, kcache, vcache, qscale, kscale, vscale, cu_seqlens_q, block_ids,
+                                            seqlens_kvcache, max_seqlens_q, quant_type, block_mask=None, output=None):
+    if output is not None:
+        return output
+    return torch.empty((q.shape[0], q.shape[1], vcache.shape[-1]), dtype=torch.bfloat16, device=q.device)

@@ -262,6 +262,19 @@ int hpc_gemm_bf16xfp32_async(void* y, void* splitk_y, void* split_flag, const vo
                              const void* w_low, int m, int n, int k, float scale, int use_fp32_output,
                              int splits, int flag_ld, hpc_stream_t stream);
 
+/* Block-sparse form (reference attention_with_kvcache_blocksparse_prefill_fp8, src/attention/entry.cc:264-409):
+ * block_mask uint8 [B, Hq, ceil(max_seqlens_q/128) = mask_tiles_m, mask_tiles_kv] over 128 (q positions of the
+ * request) x 128 (kv tokens) tiles, non-zero = attend; null = dense.  128 % block_size == 0. */
+int hpc_attention_with_kvcache_blocksparse_prefill_fp8_async(
+    void* y, const void* q, const void* kcache, const void* vcache, const void* qscale, const void* kscale,
+    const void* vscale, const void* cu_seqlens_q, const void* block_ids, const void* seqlens_kvcache,
+    const void* block_mask, int mask_tiles_m, int mask_tiles_kv, int quant_type, int num_batch, int max_seqlens_q,
+    int max_seqlens_q_pad, int num_dim_qk, int num_dim_v, int num_head_q, int num_head_kv, int block_size,
+    int num_seq_max_blocks, int ldY, int ldQ, int64_t kcache_block_stride, int64_t kcache_token_stride,
+    int64_t kcache_head_stride, int64_t vcache_block_stride, int64_t vcache_token_stride,
+    int64_t vcache_head_stride, int64_t kscale_block_stride_bytes, int64_t kscale_row_stride_bytes,
+    int64_t kscale_head_stride_bytes, hpc_stream_t stream);
+
 /* x_scale [rows, n = K/128] -> transposed, tile-padded, compact [n, m] layout that
  * hpc_group_gemm_blockwise_fp8_async reads (DeepEP-format inputs).
  * reference: reformat_x_scale_async, src/group_gemm/group_gemm.h:27-29 (entry src/group_gemm/entry.cc:170-222). */

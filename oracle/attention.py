@@ -150,7 +150,7 @@ def ref_attn_fp8(q, kvcache, block_ids, nblocks, num_seq_q, num_seq_kvcache, q_s
 
 
 def ref_prefill_fp8(q8, kcache8, vcache8, qscale, kscale, vscale, cu_seqlens_q, block_ids, seqlens_kv,
-                    k_per_token=False):
+                    k_per_token=False, block_mask=None):
     """FP8 paged causal prefill oracle: restates naive_attn_with_kvcache_func of reference
     tests/test_attention_with_kvcache_qpertoken_perhead_kvpertensor_prefill_fp8.py:14-83 (per-tensor K/V
     scales; P quantised as e4m3(256 p) against the row maximum, O / sum * vscale / 256), generalised to a
@@ -180,6 +180,10 @@ def ref_prefill_fp8(q8, kcache8, vcache8, qscale, kscale, vscale, cu_seqlens_q, 
             scores = scores * ksb.unsqueeze(1)
         else:
             scores = scores * kscale[0]
+        if block_mask is not None:  # tests/test_attention_blocksparse_..._fp8.py:83-88: 128 x 128 tiles, rows = q index
+            em = block_mask[b].bool().repeat_interleave(128, dim=-2)[:, :sq, :]
+            em = em.repeat_interleave(128, dim=-1)[:, :, :L]
+            scores = scores.masked_fill(~em, float("-inf"))
         mask = torch.tril(torch.ones(L, L, dtype=torch.bool))[L - sq :, :]
         scores = scores.masked_fill(~mask, float("-inf"))
         w = torch.exp(scores - scores.max(dim=-1, keepdim=True)[0])

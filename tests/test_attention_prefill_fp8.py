@@ -121,3 +121,64 @@ def test_prefill_fp8_k_per_token(hq, hkv, block_size):
         cu.cuda(), bid.cuda(), lens.cuda(), max(seq_q),
         quant_type=hpc.QuantType.QPERTOKEN_PERHEAD_KPERTOKEN_PERHEAD_VPERHEAD)
     assert allclose(gt, my.cpu(), atol=0.1, rtol=0.02)
+
+
+def block_sparse_mask(batch, heads, nrow, ncol, skip_ratio, gen):
+    """reference tests/test_attention_blocksparse_qpertoken_perhead_kvpertensor_fp8.py:21-35 (True = attend,
+    causal upper part cleared, the diagonal tile of every q tile kept)."""
+    mask = torch.rand(batch, heads, nrow, ncol, generator=gen) >= skip_ratio
+    row = torch.arange(nrow).view(nrow, 1)
+    col = torch.arange(ncol).view(1, ncol)
+    boundary = row + (ncol - nrow)
+    mask = mask & (col <= boundary)
+    return mask | (col == torch.clamp(boundary, max=ncol - 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kv_layout", ["nhd", "hnd"])
+@pytest.mark.parametrize("num_seq", [1024, 2048])
+@pytest.mark.parametrize("skip_ratio", [0.0, 0.5, 0.9])
+@pytest.mark.parametrize("hq,hkv", [(4, 1), (16, 2)])
+def test_blocksparse_prefill_fp8(kv_layout, num_seq, skip_ratio, hq, hkv):
+    import hpc
+
+    B = 2
+    q, kv, qscale, kscale, vscale, cu, bid, lens = make_case([num_seq] * B, [num_seq] * B, hq, hkv, 64, seed=21)
+    g = torch.Generator().manual_seed(4)
+    nt = (num_seq + 127) // 128
+    bm = block_sparse_mask(B, hq, nt, nt, skip_ratio, g) if skip_ratio > 0 else None
+    gt = oattn.ref_prefill_fp8(q, kv[:, 0], kv[:, 1], qscale, kscale, vscale, cu, bid, lens, block_mask=bm)
+    kvd = kv.cuda()
+    kc, vc = kvd[:, 0], kvd[:, 1]
+    if kv_layout == "hnd":
+        kc = kc.view(torch.uint8).transpose(1, 2).contiguous().transpose(1, 2).view(F8)
+        vc = vc.view(torch.uint8).transpose(1, 2).contiguous().transpose(1, 2).view(F8)
+    my = hpc.attention_with_kvcache_blocksparse_prefill_fp8(
+        q.cuda(), kc, vc, qscale.cuda(), kscale.cuda(), vscale.cuda(), cu.cuda(), bid.cuda(), lens.cuda(), num_seq,
+        block_mask=None if bm is None else bm.to(torch.uint8).cuda())
+    assert allclose(gt, my.cpu(), atol=0.1, rtol=0.02)
+
+
+@pytest.mark.gpu
+def test_blocksparse_prefill_fp8_cached_prefix_and_ragged():
+    """q shorter than kv (mask rows index q positions, columns absolute kv tiles) and ragged requests."""
+    import hpc
+
+    seq_q, seq_kv = [300, 129, 1], [900, 129, 640]
+    hq, hkv = 8, 2
+    q, kv, qscale, kscale, vscale, cu, bid, lens = make_case(seq_q, seq_kv, hq, hkv, 32, seed=8)
+    g = torch.Generator().manual_seed(6)
+    nrow, ncol = (max(seq_q) + 127) // 128, (max(seq_kv) + 127) // 128
+    bm = torch.rand(len(seq_q), hq, nrow, ncol, generator=g) >= 0.4
+    for b, (sq, L) in enumerate(zip(seq_q, seq_kv)):  # keep every row's own diagonal tile
+        for r in range(nrow):
+            last_pos = min(sq - 1, r * 128 + 127)
+            if r * 128 < sq:
+                bm[b, :, r, (L - sq + last_pos) // 128] = True
+                bm[b, :, r, (L - sq + r * 128) // 128] = True
+    gt = oattn.ref_prefill_fp8(q, kv[:, 0], kv[:, 1], qscale, kscale, vscale, cu, bid, lens, block_mask=bm)
+    kvd = kv.cuda()
+    my = hpc.attention_with_kvcache_blocksparse_prefill_fp8(
+        q.cuda(), kvd[:, 0], kvd[:, 1], qscale.cuda(), kscale.cuda(), vscale.cuda(), cu.cuda(), bid.cuda(),
+        lens.cuda(), max(seq_q), block_mask=bm.to(torch.uint8).cuda())
+    assert allclose(gt, my.cpu(), atol=0.1, rtol=0.02)
