@@ -30,6 +30,7 @@ struct Args {
   const float* qscale;  // [B][Hq][qs_pad]
   const float* kscale;  // [1] or base of the per-token K-scale rows
   const float* vscale;  // [1] or [Hkv]
+  int by_head;  // row mapping, see the kernel
   const uint8_t* block_mask;  // null, or [B][Hq][mask_tiles_m][mask_tiles_kv]: 128 x 128 (q pos x kv token) tiles
   int mask_tiles_m, mask_tiles_kv;
   int num_batch, num_head_q, num_head_kv, g_shift, page_shift, max_blocks, qs_pad;
@@ -46,6 +47,7 @@ constexpr int kNB = 2;                  // 16-row q blocks per wave
 constexpr int kRowsPerWave = 16 * kNB;  // 32
 constexpr float kNegInf = -__builtin_inff();
 constexpr int kKRow = 128 + 16;  // padded LDS row of the K transpose tile
+constexpr int kMaskCols = 512;    // block-sparse: mask columns (128-token tiles) cached per head
 
 __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
   return static_cast<long>(static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32));
@@ -58,13 +60,15 @@ __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
 // of V (16 rows x 128 B each, full-row loads, one tile ahead, held in 4+4 VGPRs while the current tile
 // computes) and drops them into a double-buffered LDS tile; one barrier per tile; all waves then read K
 // in MFMA A-operand layout (ds_read_b128) and V as 8-byte row pieces for the private transposes.
-template <int kQuant>
+template <int kQuant, bool kSparse>
 __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) float s_o[kWaves][16][128 + 4];
   __shared__ float s_l[kWaves][16];
   __shared__ __attribute__((aligned(16))) uint8_t s_k[2][64 * kKRow];
   __shared__ __attribute__((aligned(16))) uint8_t s_v[2][64 * kKRow];
   __shared__ __attribute__((aligned(16))) float s_ks[2][64];  // per-token K scales of the tile (kQuant 0)
+  // block-sparse: the mask rows of this workgroup's q tile, one per q head of the kv head (<= 64k tokens)
+  __shared__ uint8_t s_mask[kSparse ? 16 * kMaskCols : 16];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,13 +78,35 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   const int q0 = as_const(a.cu_seqlens_q)[b];
   const int Sq = as_const(a.cu_seqlens_q)[b + 1] - q0;
   const int L = as_const(a.seqlens_kv)[b];
-  const int wg_row0 = blockIdx.x * kWaves * kRowsPerWave;
-  if ((wg_row0 >> a.g_shift) >= Sq) return;  // whole workgroup past the request (uniform exit)
-  const int row0 = wg_row0 + wave * kRowsPerWave;  // first (position, head) row of this wave
-  const int pos_first = row0 >> a.g_shift;
+  // Row mapping of the workgroup's 128 (position, q head) rows.  G <= 8: every 16-row MFMA block is ONE
+  // q head x 16 consecutive positions (block-sparse masks are per head: a whole block can then skip a
+  // tile); G = 16: 8 positions x 16 heads, head fastest.
+  constexpr int kWgRows = kWaves * kRowsPerWave;
+  const int wg_pos0 = (blockIdx.x * kWgRows) >> a.g_shift;  // positions per workgroup = 128 / G
+  if (wg_pos0 >= Sq) return;  // whole workgroup past the request (uniform exit)
+  const bool by_head = a.by_head != 0;
+  const int blk_per_head = by_head ? (kWgRows >> a.g_shift) >> 4 : 0;  // 16-position blocks per head
+  auto map_row = [&](int r, int& pos, int& hl) {  // r in [0, 128) -> position, local q head
+    if (by_head) {
+      const int blk = r >> 4;
+      hl = blk / blk_per_head;
+      pos = wg_pos0 + (blk % blk_per_head) * 16 + (r & 15);
+    } else {
+      hl = r & (G - 1);
+      pos = wg_pos0 + (r >> a.g_shift);
+    }
+  };
+  const int row0 = wave * kRowsPerWave;  // first row of this wave inside the workgroup
+  int pos_first = 0x7fffffff;  // earliest position among this wave's rows (first row of each 16-row block)
+#pragma unroll
+  for (int nb = 0; nb < kNB; ++nb) {
+    int p0, hl0;
+    map_row(row0 + nb * 16, p0, hl0);
+    pos_first = min(pos_first, p0);
+  }
   const int past = L - Sq;  // cached tokens before the first q token
   // the workgroup walks the tiles its LAST row can see; a wave's own rows mask what they cannot
-  const int wg_pos_last = min(Sq - 1, (wg_row0 + kWaves * kRowsPerWave - 1) >> a.g_shift);
+  const int wg_pos_last = min(Sq - 1, wg_pos0 + (kWgRows >> a.g_shift) - 1);
   const int num_seqkv = past + wg_pos_last + 1;
   const int ntile = (num_seqkv + 63) >> 6;
   const int ntile_full = max(past + pos_first + 1, 0) >> 6;  // tiles visible to every row of this wave
@@ -93,18 +119,13 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   u32x4 qf[kNB][2];
   float row_scale[kNB];
   int row_lim[kNB];  // last visible key of this lane's q row (-1: row does not exist)
-  const uint8_t* row_mask[kNB];  // block-sparse: this row's [kv tile] mask bytes
 #pragma unroll
   for (int nb = 0; nb < kNB; ++nb) {
-    const int row = row0 + nb * 16 + n;
-    const int pos = row >> a.g_shift;
-    const int hq = (h << a.g_shift) + (row & (G - 1));
+    int pos, hl;
+    map_row(row0 + nb * 16 + n, pos, hl);
+    const int hq = (h << a.g_shift) + hl;
     const bool ok = pos < Sq;
     row_lim[nb] = ok ? past + pos : -1;
-    row_mask[nb] = a.block_mask
-                       ? a.block_mask + ((static_cast<long>(b) * a.num_head_q + hq) * a.mask_tiles_m +
-                                         min(pos >> 7, a.mask_tiles_m - 1)) * a.mask_tiles_kv
-                       : nullptr;
     const long qoff = static_cast<long>(q0 + pos) * a.ldq + hq * 128;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -175,17 +196,38 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   // (head, q tile) bit is set; the workgroup's rows all sit in one 128-position q tile and share the
   // G heads of this kv head, so "no row needs tile t" is the same in every wave: such tiles are neither
   // fetched nor computed.
-  auto tile_bits = [&](int t, bool (&bit)[kNB]) {
-    bool any = false;
+  int row_hl[kNB];  // local q head of this lane's row in block nb
 #pragma unroll
-    for (int nb = 0; nb < kNB; ++nb) {
-      bit[nb] = true;
-      // (rows past the request still read their head's byte: the decision below must not depend on
-      //  which rows exist, or waves of the last workgroup would disagree about fetching the tile)
-      if (a.block_mask) bit[nb] = row_mask[nb][min(t >> 1, a.mask_tiles_kv - 1)] != 0;
-      any |= bit[nb];
+  for (int nb = 0; nb < kNB; ++nb) {
+    int p_, hl_;
+    map_row(row0 + nb * 16 + n, p_, hl_);
+    row_hl[nb] = hl_;
+  }
+  if constexpr (kSparse) {
+    const int mask_tm = min(wg_pos0 >> 7, a.mask_tiles_m - 1);
+    const int cols = min(a.mask_tiles_kv, kMaskCols);
+    for (int i = tid; i < G * cols; i += kThreads) {
+      const int gq = i / cols, col = i % cols;
+      s_mask[gq * kMaskCols + col] =
+          a.block_mask[((static_cast<long>(b) * a.num_head_q + (h << a.g_shift) + gq) * a.mask_tiles_m + mask_tm) *
+                           a.mask_tiles_kv + col];
     }
-    return a.block_mask ? __ballot(any) != 0 : true;
+    __syncthreads();
+  }
+  auto tile_bits = [&](int t, bool (&bit)[kNB]) {
+    if constexpr (!kSparse) {
+#pragma unroll
+      for (int nb = 0; nb < kNB; ++nb) bit[nb] = true;
+      return true;
+    } else {
+      const int col = min(t >> 1, min(a.mask_tiles_kv, kMaskCols) - 1);
+#pragma unroll
+      for (int nb = 0; nb < kNB; ++nb) bit[nb] = s_mask[row_hl[nb] * kMaskCols + col] != 0;
+      // fetch / skip must be one decision for the whole workgroup: OR over the G heads of this kv head
+      bool need = false;
+      for (int gq = 0; gq < G; ++gq) need |= s_mask[gq * kMaskCols + col] != 0;
+      return need;
+    }
   };
   bool bit_cur[kNB], bit_next[kNB] = {};
   bool need_cur = tile_bits(0, bit_cur);
@@ -198,6 +240,9 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
     if (need_next) fetch(t + 1);
     const uint8_t* kt = s_k[buf];
     const uint8_t* vt = s_v[buf];
+    bool nb_on[kNB];  // block-sparse: does this 16-row block (one head when G <= 8) attend the tile at all?
+#pragma unroll
+    for (int nb = 0; nb < kNB; ++nb) nb_on[nb] = !kSparse || __ballot(bit_cur[nb] && row_lim[nb] >= 0) != 0;
     if (need_cur) {
 
     // ---- S^T = K Q^T --------------------------------------------------------------------------------
@@ -211,12 +256,14 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
 #pragma unroll
       for (int nb = 0; nb < kNB; ++nb) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (nb_on[nb]) {
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(ka[c][0], ka[c][1]),
-                                                          pack64(qf[nb][c][0], qf[nb][c][1]), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(ka[c][2], ka[c][3]),
-                                                          pack64(qf[nb][c][2], qf[nb][c][3]), acc, 0, 0, 0);
+          for (int c = 0; c < 2; ++c) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(ka[c][0], ka[c][1]),
+                                                            pack64(qf[nb][c][0], qf[nb][c][1]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(ka[c][2], ka[c][3]),
+                                                            pack64(qf[nb][c][2], qf[nb][c][3]), acc, 0, 0, 0);
+          }
         }
         s[nb][tb] = acc;
       }
@@ -228,9 +275,12 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
     bool all_bits = true;
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) all_bits &= bit_cur[nb] || row_lim[nb] < 0;
-    const bool masked = t >= ntile_full || (a.block_mask && __ballot(!all_bits) != 0);
+    // head-major blocks share head and q tile: sparsity switches whole blocks (nb_on), never single rows
+    const bool masked = t >= ntile_full || (kSparse && !by_head && __ballot(!all_bits) != 0);
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) {
+      pf[nb][0][0] = pf[nb][0][1] = pf[nb][1][0] = pf[nb][1][1] = 0u;
+      if (!nb_on[nb]) continue;  // nothing of this tile is visible to the block: m, l, O stay as they are
       const float rs = row_scale[nb];
       const int lim = bit_cur[nb] ? row_lim[nb] : -1;
       float mt;
@@ -316,8 +366,9 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
         const uint32_t hi = __builtin_amdgcn_perm(st[dh][1][2 + dp], st[dh][1][dp], sel);
 #pragma unroll
         for (int nb = 0; nb < kNB; ++nb)
-          o[nb][jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(lo, hi), pack64(pf[nb][ks][0], pf[nb][ks][1]),
-                                                                 o[nb][jj], 0, 0, 0);
+          if (nb_on[nb])
+            o[nb][jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(lo, hi), pack64(pf[nb][ks][0], pf[nb][ks][1]),
+                                                                   o[nb][jj], 0, 0, 0);
       }
     }
     }  // need_cur
@@ -342,8 +393,8 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
 #pragma unroll 1
     for (int it = 0; it < 4; ++it) {
       const int row16 = it * 4 + (lane >> 4), c8 = lane & 15;
-      const int row = row0 + nb * 16 + row16;
-      const int pos = row >> a.g_shift;
+      int pos, hl;
+      map_row(row0 + nb * 16 + row16, pos, hl);
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(&s_o[wave][row16][c8 * 8]);
       const f32x4 x1 = *reinterpret_cast<const f32x4*>(&s_o[wave][row16][c8 * 8 + 4]);
       const float L2 = s_l[wave][row16];
@@ -354,7 +405,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
         pk[1] = pack_bf16x2(x0[2] * inv, x0[3] * inv);
         pk[2] = pack_bf16x2(x1[0] * inv, x1[1] * inv);
         pk[3] = pack_bf16x2(x1[2] * inv, x1[3] * inv);
-        st16(a.y + static_cast<long>(q0 + pos) * a.ldy + ((h << a.g_shift) + (row & (G - 1))) * 128 + c8 * 8, pk);
+        st16(a.y + static_cast<long>(q0 + pos) * a.ldy + ((h << a.g_shift) + hl) * 128 + c8 * 8, pk);
       }
     }
   }
@@ -403,9 +454,13 @@ static int prefill_fp8_launch(const void* block_mask_ptr, int mask_tiles_m, int 
   a.kscale = static_cast<const float*>(kscale_ptr);
   a.vscale = static_cast<const float*>(vscale_ptr);
   a.block_mask = static_cast<const uint8_t*>(block_mask_ptr);
+  // head-major 16-row blocks let a block skip masked-out tiles (block-sparse); dense attention measured ~8 %
+  // faster with every wave holding all G heads of a few positions (key 7 overrides: 1 = by head, 2 = by position)
+  a.by_head = group <= 8 && (hpc_tuning_get(7) ? hpc_tuning_get(7) == 1 : block_mask_ptr != nullptr);
   a.mask_tiles_m = mask_tiles_m;
   a.mask_tiles_kv = mask_tiles_kv;
   if (block_mask_ptr && (mask_tiles_m <= 0 || mask_tiles_kv <= 0)) return HPC_ERR_INVALID;
+  if (block_mask_ptr && mask_tiles_kv > kMaskCols) return HPC_ERR_UNSUPPORTED;  // > 64k tokens of mask columns
   a.num_batch = num_batch;
   a.num_head_q = num_head_q;
   a.num_head_kv = num_head_kv;
@@ -429,10 +484,13 @@ static int prefill_fp8_launch(const void* block_mask_ptr, int mask_tiles_m, int 
   dim3 grid(static_cast<unsigned>((rows + kWaves * kRowsPerWave - 1) / (kWaves * kRowsPerWave)), num_head_kv, num_batch);
   if (grid.z > 65535 || grid.y > 65535) return HPC_ERR_UNSUPPORTED;
   // default (temporal) cache policy: K/V tiles are re-read by every q tile of the request from L2
-  if (quant_type == 1)
-    prefill_fp8_kernel<1><<<grid, kThreads, 0, stream>>>(a);
-  else
-    prefill_fp8_kernel<0><<<grid, kThreads, 0, stream>>>(a);
+  if (block_mask_ptr) {
+    if (quant_type == 1) prefill_fp8_kernel<1, true><<<grid, kThreads, 0, stream>>>(a);
+    else prefill_fp8_kernel<0, true><<<grid, kThreads, 0, stream>>>(a);
+  } else {
+    if (quant_type == 1) prefill_fp8_kernel<1, false><<<grid, kThreads, 0, stream>>>(a);
+    else prefill_fp8_kernel<0, false><<<grid, kThreads, 0, stream>>>(a);
+  }
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }
