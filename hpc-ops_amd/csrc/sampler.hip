@@ -103,7 +103,7 @@ __device__ __forceinline__ float load_logit(const Args& a, int b, int i) {
 }
 
 // ---- byte-wise radix select: the K-th largest of n distinct composites in `list` (LDS) ---------------
-// All 256 threads call it; n > K.  hist: 256 counters, misc: 2 ints.
+// All 256 threads call it; n > K.  hist: 256 counters, misc: ints 0, 1 and 4 are used here.
 __device__ uint64_t select_kth(const uint64_t* list, int n, int K, unsigned* hist, int* misc) {
   const int tid = threadIdx.x, lane = tid & 63;
   uint64_t prefix = 0, mask = 0;
@@ -133,6 +133,7 @@ __device__ uint64_t select_kth(const uint64_t* list, int n, int K, unsigned* his
         if (gt < static_cast<unsigned>(need) && static_cast<unsigned>(need) <= gt + h[j]) {
           misc[0] = 4 * lane + j;
           misc[1] = need - static_cast<int>(gt);
+          misc[4] = static_cast<unsigned>(need) == gt + h[j];  // the whole bin is wanted: no need to refine it
         }
         gt += h[j];
       }
@@ -141,6 +142,9 @@ __device__ uint64_t select_kth(const uint64_t* list, int n, int K, unsigned* his
     prefix |= static_cast<uint64_t>(misc[0]) << (8 * p);
     mask |= 255ull << (8 * p);
     need = misc[1];
+    // early exit (the usual case after the 3-4 bytes that carry the float value): every element of the
+    // chosen bin belongs to the top K, so the bin's lower bound is already the threshold
+    if (misc[4]) break;
   }
   return prefix;
 }
@@ -149,7 +153,7 @@ __device__ uint64_t select_kth(const uint64_t* list, int n, int K, unsigned* his
 __global__ __launch_bounds__(kThreads) void sampler_segment_kernel(const Args a) {
   __shared__ uint64_t s_list[kSegMax];
   __shared__ unsigned s_hist[256];
-  __shared__ int s_misc[4];
+  __shared__ int s_misc[6];
   __shared__ float s_red[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = blockIdx.x, b = blockIdx.y;
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void sampler_final_kernel(const Args a) {
   __shared__ uint64_t s_list[kSegMax];
   __shared__ uint64_t s_sel[64];
   __shared__ unsigned s_hist[256];
-  __shared__ int s_misc[4];
+  __shared__ int s_misc[6];
   const int tid = threadIdx.x, lane = tid & 63;
   const int b = blockIdx.x;
   const int K = a.max_topk;
