@@ -261,7 +261,16 @@ def extra_prefill(dev, hpc):
                                                                              block_mask=bm, output=y),
                   iters=10, warm=2, graph=True)
     res["blocksparse_skip0.5_us"] = round(us_sp, 1)
-    return {"attention_prefill_fp8_4x4096_h64_8": res}
+    # bf16 form on the same shape (paged cache)
+    q16 = (torch.randn(B * S, Hq, D, device=dev) / math.sqrt(D)).bfloat16()
+    kc16 = (torch.randn(B * nb + 8, P, Hkv, D, device=dev) / math.sqrt(D)).bfloat16()
+    vc16 = torch.randn(B * nb + 8, P, Hkv, D, device=dev).bfloat16()
+    y16 = torch.empty_like(q16)
+    us16 = timed(lambda: hpc.attention_with_kvcache_prefill_bf16(q16, kc16, vc16, cu, bid, lens, S, output=y16),
+                 iters=10, warm=2, graph=True)
+    return {"attention_prefill_fp8_4x4096_h64_8": res,
+            "attention_prefill_bf16_4x4096_h64_8": {"us": round(us16, 1), "TFLOPS": round(flops / us16 / 1e6, 1),
+                                                     "mfma_frac_of_2.5PF": round(flops / us16 / 1e6 / 2500, 4)}}
 
 
 def extra_moe(dev, hpc, tokens=(16, 64, 256, 4096)):

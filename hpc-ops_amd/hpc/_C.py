@@ -78,6 +78,9 @@ _sig("hpc_attention_with_kvcache_prefill_fp8_async", I, P, P, P, P, P, P, P, P, 
      I, I, L, L, L, L, L, L, L, L, L, P)
 _sig("hpc_attention_with_kvcache_blocksparse_prefill_fp8_async", I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I,
      I, I, I, I, I, I, I, I, L, L, L, L, L, L, L, L, L, P)
+_sig("hpc_attention_with_kvcache_prefill_bf16_async", I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I,
+     L, L, L, L, L, L, P)
+_sig("hpc_attention_prefill_bf16_async", I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P)
 _sig("hpc_reformat_x_scale_async", I, P, P, P, P, I, I, I, I, P)
 _sig("hpc_sampler_segments", I, I)
 _sig("hpc_fused_sampler_workspace_bytes", L, I, I, I)

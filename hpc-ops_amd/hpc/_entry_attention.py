@@ -336,3 +336,76 @@ def _attention_blocksparse_prefill_fp8_entry(q, kcache, vcache, qscale, kscale, 
 
 
 _T.impl("attention_with_kvcache_blocksparse_prefill_fp8", _attention_blocksparse_prefill_fp8_entry, "CUDA")
+
+
+# ---------------------------------------------------------------------------- bf16 prefill
+_T.define("attention_prefill_bf16(Tensor q, Tensor k, Tensor v, Tensor seqlens_q, Tensor cu_seqlens_q, "
+          "int max_seqlens_q, Tensor? output) -> (Tensor)")
+_T.define("attention_with_kvcache_prefill_bf16(Tensor q, Tensor kcache, Tensor vcache,"
+          "Tensor cu_seqlens_q, "
+          "Tensor block_ids, Tensor num_seq_kvcache, int max_seqlens_q, Tensor? output) -> (Tensor)")
+
+
+def _prefill_output(q, output, dim_v):
+    total_q, num_head_q = q.size(0), q.size(1)
+    if output is None:
+        return torch.empty((total_q, num_head_q, dim_v), dtype=torch.bfloat16, device=q.device)
+    _C.require(output.is_cuda and output.device == q.device, "output tensor must be on the same device as q")
+    _C.require(output.dtype == torch.bfloat16, "output dtype must be bfloat16")
+    _C.require(output.is_contiguous(), "output tensor must be contiguous")
+    _C.require(tuple(output.shape) == (total_q, num_head_q, dim_v),
+               "output must have shape [total_seq_q, num_head_q, num_dim_v]")
+    return output
+
+
+def _attention_prefill_bf16_entry(q, k, v, seqlens_q, cu_seqlens_q, max_seqlens_q, output=None):
+    # reference attention_prefill_bf16_entry, src/attention/entry.cc:15-81
+    for t, name in ((q, "q"), (k, "k"), (v, "v"), (seqlens_q, "seqlens_q"), (cu_seqlens_q, "cu_seqlens_q")):
+        _C.require(t.is_cuda, f"{name} tensor must be cuda")
+    for t, name in ((q, "q"), (k, "k"), (v, "v")):
+        _C.require(t.dtype == torch.bfloat16 and t.dim() == 3 and t.stride(2) == 1 and t.stride(1) == t.size(2),
+                   f"{name} must be bfloat16 [total_seq, heads, dim] with contiguous heads")
+    _C.require(cu_seqlens_q.dtype == torch.int32 and cu_seqlens_q.is_contiguous(), "cu_seqlens_q must be contiguous int32")
+    _C.require(q.size(2) == 128 and k.size(2) == 128 and v.size(2) == 128,
+               "attention_prefill_bf16: expected dim_qk=128 and dim_v=128")
+    _C.require(k.size(0) == q.size(0) and v.size(0) == q.size(0) and k.size(1) == v.size(1),
+               "k / v must hold one row per q token and the same number of kv heads")
+    y = _prefill_output(q, output, v.size(2))
+    if q.size(0) == 0:
+        return y
+    rc = _C.lib.hpc_attention_prefill_bf16_async(
+        _C.ptr(y), _C.ptr(q), _C.ptr(k), _C.ptr(v), _C.ptr(cu_seqlens_q), cu_seqlens_q.size(0) - 1, int(max_seqlens_q),
+        128, 128, q.size(1), k.size(1), y.stride(0), q.stride(0), k.stride(0), v.stride(0), _C.stream_of(q))
+    _C.check(rc, "attention_prefill_bf16")
+    return y
+
+
+def _attention_kvcache_prefill_bf16_entry(q, kcache, vcache, cu_seqlens_q, block_ids, num_seq_kvcache, max_seqlens_q,
+                                          output=None):
+    # reference attention_with_kvcache_prefill_bf16_entry, src/attention/entry.cc:83-150
+    for t, name in ((q, "q"), (kcache, "kcache"), (vcache, "vcache"), (cu_seqlens_q, "cu_seqlens_q"),
+                    (block_ids, "block_ids"), (num_seq_kvcache, "seqlens_kvcache")):
+        _C.require(t.is_cuda, f"{name} tensor must be cuda")
+    for t, name in ((q, "q"), (kcache, "kcache"), (vcache, "vcache")):
+        _C.require(t.dtype == torch.bfloat16, f"{name} dtype must be bfloat16")
+    _C.require(q.dim() == 3 and q.stride(2) == 1 and q.stride(1) == q.size(2), "q must be [total_seq, Hq, D] row-major")
+    dim_qk, dim_v = q.size(2), vcache.size(3)
+    _C.require(dim_qk == 128 and dim_v == 128,
+               f"attention_with_kvcache_prefill_bf16: expected dim_qk=128 and dim_v=128, got dim_qk={dim_qk} dim_v={dim_v}")
+    _C.require(kcache.stride(3) == 1 and vcache.stride(3) == 1, "kv cache head dim must be contiguous")
+    for t, name in ((cu_seqlens_q, "cu_seqlens_q"), (block_ids, "block_ids"), (num_seq_kvcache, "seqlens_kvcache")):
+        _C.require(t.dtype == torch.int32 and t.is_contiguous(), f"{name} must be contiguous int32")
+    y = _prefill_output(q, output, dim_v)
+    if q.size(0) == 0:
+        return y
+    rc = _C.lib.hpc_attention_with_kvcache_prefill_bf16_async(
+        _C.ptr(y), _C.ptr(q), _C.ptr(kcache), _C.ptr(vcache), _C.ptr(cu_seqlens_q), _C.ptr(block_ids),
+        _C.ptr(num_seq_kvcache), cu_seqlens_q.size(0) - 1, int(max_seqlens_q), dim_qk, dim_v, q.size(1), kcache.size(2),
+        kcache.size(1), block_ids.size(1), y.stride(0), q.stride(0), kcache.stride(0), kcache.stride(1),
+        kcache.stride(2), vcache.stride(0), vcache.stride(1), vcache.stride(2), _C.stream_of(q))
+    _C.check(rc, "attention_with_kvcache_prefill_bf16")
+    return y
+
+
+_T.impl("attention_prefill_bf16", _attention_prefill_bf16_entry, "CUDA")
+_T.impl("attention_with_kvcache_prefill_bf16", _attention_kvcache_prefill_bf16_entry, "CUDA")

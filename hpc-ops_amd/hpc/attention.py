@@ -254,3 +254,36 @@ def _attention_blocksparse_prefill_fp8_fake(q, kcache, vcache, qscale, kscale, v
     if output is not None:
         return output
     return torch.empty((q.shape[0], q.shape[1], vcache.shape[-1]), dtype=torch.bfloat16, device=q.device)
+
+
+def attention_prefill_bf16(q: Tensor, k: Tensor, v: Tensor, seqlens_q: Tensor, cu_seqlens_q: Tensor,
+                           max_seqlens_q: int, output: Tensor = None) -> Tensor:
+    """Causal varlen prefill attention in bf16 over contiguous K/V (reference hpc/attention.py:15-68).
+    q [total_seq, Hq, 128], k / v [total_seq, Hkv, 128] bf16; seqlens_q int32 [B]; cu_seqlens_q int32 [B+1];
+    token s of a request attends tokens 0..s of the same request.  Returns bf16 [total_seq, Hq, 128]."""
+    return torch.ops.hpc.attention_prefill_bf16(q, k, v, seqlens_q, cu_seqlens_q, int(max_seqlens_q), output)
+
+
+def attention_with_kvcache_prefill_bf16(q: Tensor, kcache: Tensor, vcache: Tensor, cu_seqlens_q: Tensor,
+                                        block_ids: Tensor, seqlens_kvcache: Tensor, max_seqlens_q: int,
+                                        output: Tensor = None) -> Tensor:
+    """Causal prefill attention in bf16 over the paged KV cache (reference hpc/attention.py:70-146).
+    q [total_seq, Hq, 128]; kcache / vcache logical [num_blocks, block_size, Hkv, 128] (NHD or HND-backed
+    strides); cu_seqlens_q int32 [B+1]; block_ids int32 [B, max_blocks]; seqlens_kvcache int32 [B] = cached
+    tokens of each request, its q tokens being the last ones (q row s attends keys j <= L - Sq + s).
+    Returns bf16 [total_seq, Hq, 128]."""
+    return torch.ops.hpc.attention_with_kvcache_prefill_bf16(q, kcache, vcache, cu_seqlens_q, block_ids,
+                                                             seqlens_kvcache, int(max_seqlens_q), output)
+
+
+@torch.library.register_fake("hpc::attention_prefill_bf16")
+def _attention_prefill_bf16_fake(q, k, v, seqlens_q, cu_seqlens_q, max_seqlens_q, output=None):
+    return output if output is not None else torch.empty((q.shape[0], q.shape[1], v.shape[-1]), dtype=q.dtype,
+                                                         device=q.device)
+
+
+@torch.library.register_fake("hpc::attention_with_kvcache_prefill_bf16")
+def _attention_with_kvcache_prefill_bf16_fake(q, kcache, vcache, cu_seqlens_q, block_ids, num_seq_kvcache,
+                                              max_seqlens_q, output=None):
+    return output if output is not None else torch.empty((q.shape[0], q.shape[1], vcache.shape[-1]), dtype=q.dtype,
+                                                         device=q.device)

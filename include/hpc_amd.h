@@ -262,6 +262,20 @@ int hpc_gemm_bf16xfp32_async(void* y, void* splitk_y, void* split_flag, const vo
                              const void* w_low, int m, int n, int k, float scale, int use_fp32_output,
                              int splits, int flag_ld, hpc_stream_t stream);
 
+/* bf16 causal prefill: paged KV cache, and contiguous varlen K/V [total_seq, Hkv, 128] (row strides ldK / ldV
+ * elements; every q token attends the keys of its request up to itself).
+ * reference: attention_with_kvcache_prefill_bf16_async / attention_prefill_bf16_async (src/attention/prefill/prefill.h,
+ * entries src/attention/entry.cc:83-150 and :15-81).  seqlens_kvcache counts the request's q tokens too. */
+int hpc_attention_with_kvcache_prefill_bf16_async(
+    void* y, const void* q, const void* kcache, const void* vcache, const void* cu_seqlens_q, const void* block_ids,
+    const void* seqlens_kvcache, int num_batch, int max_seqlens_q, int num_dim_qk, int num_dim_v, int num_head_q,
+    int num_head_kv, int block_size, int num_seq_max_blocks, int ldY, int ldQ, int64_t kcache_block_stride,
+    int64_t kcache_token_stride, int64_t kcache_head_stride, int64_t vcache_block_stride,
+    int64_t vcache_token_stride, int64_t vcache_head_stride, hpc_stream_t stream);
+int hpc_attention_prefill_bf16_async(void* y, const void* q, const void* k, const void* v, const void* cu_seqlens_q,
+                                     int num_batch, int max_seqlens_q, int num_dim_qk, int num_dim_v, int num_head_q,
+                                     int num_head_kv, int ldY, int ldQ, int ldK, int ldV, hpc_stream_t stream);
+
 /* Block-sparse form (reference attention_with_kvcache_blocksparse_prefill_fp8, src/attention/entry.cc:264-409):
  * block_mask uint8 [B, Hq, ceil(max_seqlens_q/128) = mask_tiles_m, mask_tiles_kv] over 128 (q positions of the
  * request) x 128 (kv tokens) tiles, non-zero = attend; null = dense.  128 % block_size == 0. */

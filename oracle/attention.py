@@ -196,3 +196,34 @@ def ref_prefill_fp8(q8, kcache8, vcache8, qscale, kscale, vscale, cu_seqlens_q, 
             o = o * (vscale[0] / 256.0)
         out[a0:a1] = o.transpose(0, 1).to(torch.bfloat16)
     return out
+
+
+def ref_prefill_bf16(q, kcache, vcache, cu_seqlens_q, block_ids, seqlens_kv):
+    """bf16 causal prefill oracle: naive_attn_with_kvcache_func of reference
+    tests/test_attention_with_kvcache_prefill_bf16.py:19-63 (fp32 softmax over bf16 inputs), per-request
+    lengths.  block_ids None: contiguous K/V [total, Hkv, D] sharing cu_seqlens_q
+    (tests/test_attention_prefill_bf16.py:54-110, causal)."""
+    total_q, hq, d = q.shape
+    hkv = kcache.shape[-2]
+    group = hq // hkv
+    out = torch.empty(total_q, hq, vcache.shape[-1], dtype=torch.bfloat16)
+    for b in range(cu_seqlens_q.numel() - 1):
+        a0, a1 = int(cu_seqlens_q[b]), int(cu_seqlens_q[b + 1])
+        sq = a1 - a0
+        if sq == 0:
+            continue
+        if block_ids is None:
+            L = sq
+            K, V = kcache[a0:a1], vcache[a0:a1]
+        else:
+            L, P = int(seqlens_kv[b]), kcache.shape[1]
+            ids = block_ids[b, : (L + P - 1) // P].long()
+            K, V = kcache[ids].reshape(-1, hkv, d)[:L], vcache[ids].reshape(-1, hkv, vcache.shape[-1])[:L]
+        BQ = q[a0:a1].float().transpose(0, 1)
+        BK = K.float().transpose(0, 1).repeat_interleave(group, dim=0)
+        BV = V.float().transpose(0, 1).repeat_interleave(group, dim=0)
+        scores = torch.matmul(BQ, BK.transpose(-2, -1)) / math.sqrt(d)
+        mask = torch.tril(torch.ones(L, L, dtype=torch.bool))[L - sq :, :]
+        scores = scores.masked_fill(~mask, float("-inf"))
+        out[a0:a1] = torch.matmul(F.softmax(scores, dim=-1), BV).transpose(0, 1).to(torch.bfloat16)
+    return out
