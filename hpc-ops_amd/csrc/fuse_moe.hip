@@ -159,10 +159,13 @@ __global__ __launch_bounds__(kThreads) void gather_kernel(
 __global__ __launch_bounds__(kThreads) void act_mul_blockwise_quant_kernel(
     const uint16_t* __restrict__ gate_up, const int* __restrict__ num_rows_ptr, int max_rows,
     int inter, uint8_t* __restrict__ out, float* __restrict__ out_scale, long os_row_stride,
-    long os_blk_stride, const int* __restrict__ row_to_col) {
+    long os_blk_stride, const int* __restrict__ row_to_col, const int* __restrict__ num_per_expert,
+    int rows_per_expert) {
   const int row = blockIdx.y;
   const int rows = num_rows_ptr ? min(*num_rows_ptr, max_rows) : max_rows;
   if (row >= rows) return;
+  // masked (DeepEP-layout) form: expert e owns rows [e * rows_per_expert, ...), the first num_per_expert[e] valid
+  if (num_per_expert && row % rows_per_expert >= num_per_expert[row / rows_per_expert]) return;
   const int c8 = blockIdx.x * kThreads + threadIdx.x;  // chunk of 8 columns
   const bool ok = c8 * 8 < inter;
   const uint16_t* gp = gate_up + static_cast<long>(row) * 2 * inter;
@@ -199,10 +202,11 @@ __global__ __launch_bounds__(kThreads) void act_mul_blockwise_quant_kernel(
 __global__ __launch_bounds__(kThreads) void act_mul_quant_kernel(
     const uint16_t* __restrict__ gate_up, const float* __restrict__ scale,
     const int* __restrict__ num_rows_ptr, int max_rows, int inter, int use_bf16_mul,
-    uint8_t* __restrict__ out) {
+    uint8_t* __restrict__ out, const int* __restrict__ num_per_expert, int rows_per_expert) {
   const int row = blockIdx.y;
   const int rows = num_rows_ptr ? min(*num_rows_ptr, max_rows) : max_rows;
   if (row >= rows) return;
+  if (num_per_expert && row % rows_per_expert >= num_per_expert[row / rows_per_expert]) return;
   const int c8 = blockIdx.x * kThreads + threadIdx.x;
   if (c8 * 8 >= inter) return;
   const float sc = scale[0];
@@ -410,7 +414,43 @@ extern "C" int hpc_act_mul_and_blockwise_quant_async(void* out_ptr, void* out_sc
   act_mul_blockwise_quant_kernel<<<grid, kThreads, 0, stream>>>(
       static_cast<const uint16_t*>(gate_up_ptr), static_cast<const int*>(num_rows_ptr), max_rows,
       intermediate_size, static_cast<uint8_t*>(out_ptr), static_cast<float*>(out_scale_ptr),
-      scale_row_stride, scale_block_stride, static_cast<const int*>(row_to_col_ptr));
+      scale_row_stride, scale_block_stride, static_cast<const int*>(row_to_col_ptr), nullptr, 1);
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}
+
+// Masked (DeepEP-layout) forms: gate_up [num_expert * rows_per_expert, 2 I]; only the first num_per_expert[e]
+// rows of every expert are computed, the others are left untouched.
+// reference: masked_act_mul_and_quant_async / masked_act_mul_and_blockwise_quant_async
+// (src/activation/activation.h, entry src/activation/entry.cc:50-110).
+extern "C" int hpc_masked_act_mul_and_blockwise_quant_async(void* out_ptr, void* out_scale_ptr,
+                                                            const void* gate_up_ptr, const void* num_per_expert_ptr,
+                                                            int num_total_tokens, int intermediate_size,
+                                                            int num_tokens_per_expert, hipStream_t stream) {
+  if (!out_ptr || !out_scale_ptr || !gate_up_ptr || !num_per_expert_ptr) return HPC_ERR_INVALID;
+  if (intermediate_size <= 0 || (intermediate_size & 127) || num_tokens_per_expert <= 0) return HPC_ERR_UNSUPPORTED;
+  if (num_total_tokens <= 0) return HPC_OK;
+  dim3 grid((intermediate_size / 8 + kThreads - 1) / kThreads, num_total_tokens);
+  act_mul_blockwise_quant_kernel<<<grid, kThreads, 0, stream>>>(
+      static_cast<const uint16_t*>(gate_up_ptr), nullptr, num_total_tokens, intermediate_size,
+      static_cast<uint8_t*>(out_ptr), static_cast<float*>(out_scale_ptr), intermediate_size / 128, 1, nullptr,
+      static_cast<const int*>(num_per_expert_ptr), num_tokens_per_expert);
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}
+
+extern "C" int hpc_masked_act_mul_and_quant_async(void* out_ptr, const void* gate_up_ptr, const void* scale_ptr,
+                                                  const void* num_per_expert_ptr, int num_total_tokens,
+                                                  int intermediate_size, int num_tokens_per_expert,
+                                                  hipStream_t stream) {
+  if (!out_ptr || !gate_up_ptr || !scale_ptr || !num_per_expert_ptr) return HPC_ERR_INVALID;
+  if (intermediate_size <= 0 || (intermediate_size & 7) || num_tokens_per_expert <= 0) return HPC_ERR_UNSUPPORTED;
+  if (num_total_tokens <= 0) return HPC_OK;
+  dim3 grid((intermediate_size / 8 + kThreads - 1) / kThreads, num_total_tokens);
+  act_mul_quant_kernel<<<grid, kThreads, 0, stream>>>(
+      static_cast<const uint16_t*>(gate_up_ptr), static_cast<const float*>(scale_ptr), nullptr, num_total_tokens,
+      intermediate_size, 0, static_cast<uint8_t*>(out_ptr), static_cast<const int*>(num_per_expert_ptr),
+      num_tokens_per_expert);
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }
@@ -425,7 +465,7 @@ extern "C" int hpc_act_mul_and_quant_async(void* out_ptr, const void* gate_up_pt
   act_mul_quant_kernel<<<grid, kThreads, 0, stream>>>(
       static_cast<const uint16_t*>(gate_up_ptr), static_cast<const float*>(scale_ptr),
       static_cast<const int*>(num_rows_ptr), max_rows, intermediate_size, use_bf16_mul ? 1 : 0,
-      static_cast<uint8_t*>(out_ptr));
+      static_cast<uint8_t*>(out_ptr), nullptr, 1);
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }

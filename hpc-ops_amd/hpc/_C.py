@@ -81,6 +81,8 @@ _sig("hpc_attention_with_kvcache_blocksparse_prefill_fp8_async", I, P, P, P, P, 
 _sig("hpc_attention_with_kvcache_prefill_bf16_async", I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I,
      L, L, L, L, L, L, P)
 _sig("hpc_attention_prefill_bf16_async", I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P)
+_sig("hpc_masked_act_mul_and_quant_async", I, P, P, P, P, I, I, I, P)
+_sig("hpc_masked_act_mul_and_blockwise_quant_async", I, P, P, P, P, I, I, I, P)
 _sig("hpc_reformat_x_scale_async", I, P, P, P, P, I, I, I, I, P)
 _sig("hpc_sampler_segments", I, I)
 _sig("hpc_fused_sampler_workspace_bytes", L, I, I, I)

@@ -406,3 +406,51 @@ def _group_gemm_fp8_scatter_cp_async_entry(x, weight, y_scale, row_indices, seql
 _T.impl("reformat_x_scale", _reformat_x_scale_entry, "CUDA")
 _T.impl("group_gemm_fp8_cp_async", _group_gemm_fp8_cp_async_entry, "CUDA")
 _T.impl("group_gemm_fp8_scatter_cp_async", _group_gemm_fp8_scatter_cp_async_entry, "CUDA")
+
+
+# ---- masked (DeepEP-layout) activation variants (reference src/activation/entry.cc:50-110) ---------------------
+_T.define("masked_act_mul_and_quant(Tensor input, Tensor scale, Tensor num_per_expert, Tensor? output) -> (Tensor)")
+_T.define("masked_act_mul_and_blockwise_quant(Tensor input, Tensor num_per_expert, Tensor? output, "
+          "Tensor? output_scale) -> (Tensor, Tensor)")
+
+
+def _masked_common(input, num_per_expert):
+    _C.require(input.is_contiguous(), "input tensor must be contiguous")
+    _C.require(num_per_expert.is_contiguous(), "num_per_expert tensor must be contiguous")
+    _C.require(input.is_cuda, "input tensor's device must be cuda")
+    _C.require(num_per_expert.is_cuda, "num_per_expert tensor's device must be cuda")
+    _C.require(input.dtype == torch.bfloat16 and input.dim() == 2, "input must be bfloat16 [N, 2*C]")
+    _C.require(num_per_expert.dtype == torch.int32, "num_per_expert must be int32")
+    num_experts, total = num_per_expert.size(0), input.size(0)
+    _C.require(num_experts > 0 and total % num_experts == 0, "rows must be num_expert * num_token_padded_per_expert")
+    return total, input.size(1) // 2, total // num_experts
+
+
+def _masked_act_mul_and_quant_entry(input, scale, num_per_expert, output=None):
+    total, inter, per = _masked_common(input, num_per_expert)
+    _C.require(scale.is_contiguous() and scale.is_cuda, "scale tensor must be contiguous, on cuda")
+    _C.require(inter % 8 == 0, "hidden dim must be divided by 8")
+    _C.require(scale.numel() == 1 and scale.dtype == torch.float32, "only support per tensor qunat")
+    out = output if output is not None else torch.empty((total, inter), dtype=_F8, device=input.device)
+    _C.check(_C.lib.hpc_masked_act_mul_and_quant_async(_C.ptr(out), _C.ptr(input), _C.ptr(scale), _C.ptr(num_per_expert),
+                                                       total, inter, per, _C.stream_of(input)),
+             "masked_act_mul_and_quant_async")
+    return out
+
+
+def _masked_act_mul_and_blockwise_quant_entry(input, num_per_expert, output=None, output_scale=None):
+    total, inter, per = _masked_common(input, num_per_expert)
+    _C.require(inter % 128 == 0, "hidden dim must be divided by 128")
+    out = output if output is not None else torch.empty((total, inter), dtype=_F8, device=input.device)
+    osc = output_scale if output_scale is not None else torch.empty((total, inter // 128), dtype=torch.float32,
+                                                                    device=input.device)
+    _C.require(osc.is_contiguous() and osc.dtype == torch.float32, "output_scale must be contiguous float32")
+    _C.check(_C.lib.hpc_masked_act_mul_and_blockwise_quant_async(_C.ptr(out), _C.ptr(osc), _C.ptr(input),
+                                                                 _C.ptr(num_per_expert), total, inter, per,
+                                                                 _C.stream_of(input)),
+             "masked_act_mul_and_blockwise_quant_async")
+    return out, osc
+
+
+_T.impl("masked_act_mul_and_quant", _masked_act_mul_and_quant_entry, "CUDA")
+_T.impl("masked_act_mul_and_blockwise_quant", _masked_act_mul_and_blockwise_quant_entry, "CUDA")

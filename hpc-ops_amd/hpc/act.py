@@ -1,5 +1,7 @@
-"""hpc.act — activation + quant surface used by the fused MoE (reference hpc/act.py:7-34, :108-114).
-The masked (DeepEP-layout) variants of the reference are outside this hot path."""
+"""hpc.act — activation + quant surface used by the fused MoE (reference hpc/act.py:7-114), including the
+masked (DeepEP-layout) variants."""
+from typing import Optional, Tuple
+
 import torch
 from torch import Tensor
 
@@ -16,3 +18,34 @@ def act_mul_and_quant(gate_up: Tensor, scale: Tensor, use_bf16_mul: bool = True,
 def scaled_fp8_quant(input: Tensor, scale: Tensor = None, output: Tensor = None) -> Tensor:
     """e4m3(input * scale[0]) for a bf16 tensor (scale defaults to 1)."""
     return torch.ops.hpc.scaled_fp8_quant(input, scale, output)
+
+
+def masked_act_mul_and_quant(gate_up: Tensor, scale: Tensor, num_per_expert: Tensor,
+                             output: Optional[Tensor] = None) -> Tensor:
+    """DeepEP layout: gate_up bf16 [num_expert * padded_tokens, 2C], only the first num_per_expert[e] rows of
+    expert e are valid: e4m3(silu(gate) * up * scale[0]) for those rows, the others are left untouched
+    (reference hpc/act.py:37-67)."""
+    return torch.ops.hpc.masked_act_mul_and_quant(gate_up, scale, num_per_expert, output)
+
+
+def masked_act_mul_and_blockwise_quant(gate_up: Tensor, num_per_expert: Tensor, output: Optional[Tensor] = None,
+                                       output_scale: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """DeepEP layout, 128-block quantisation: a = silu(gate) * up, scale = amax_128(|a|) / 448 -> float32
+    [N, C/128], q = e4m3(a / (scale + 1e-8)) -> [N, C]; valid rows only (reference hpc/act.py:70-105)."""
+    return torch.ops.hpc.masked_act_mul_and_blockwise_quant(gate_up, num_per_expert, output, output_scale)
+
+
+@torch.library.register_fake("hpc::masked_act_mul_and_quant")
+def _masked_act_mul_and_quant_fake(input, scale, num_per_expert, output=None):
+    if output is not None:
+        return output
+    return torch.empty((input.shape[0], input.shape[1] // 2), dtype=torch.float8_e4m3fn, device=input.device)
+
+
+@torch.library.register_fake("hpc::masked_act_mul_and_blockwise_quant")
+def _masked_act_mul_and_blockwise_quant_fake(input, num_per_expert, output=None, output_scale=None):
+    n, c = input.shape[0], input.shape[1] // 2
+    out = output if output is not None else torch.empty((n, c), dtype=torch.float8_e4m3fn, device=input.device)
+    osc = output_scale if output_scale is not None else torch.empty((n, c // 128), dtype=torch.float32,
+                                                                    device=input.device)
+    return out, osc

@@ -289,6 +289,19 @@ int hpc_attention_with_kvcache_blocksparse_prefill_fp8_async(
     int64_t vcache_head_stride, int64_t kscale_block_stride_bytes, int64_t kscale_row_stride_bytes,
     int64_t kscale_head_stride_bytes, hpc_stream_t stream);
 
+/* Masked (DeepEP-layout) activation + quant: gate_up bf16 [num_expert * rows_per_expert, 2 I]; only the first
+ * num_per_expert[e] rows of every expert are computed (others untouched).  Per-tensor form: e4m3(silu(g) u scale[0]);
+ * blockwise form: per-128 scale = amax / 448 to out_scale [rows, I/128], q = e4m3(a / (scale + 1e-8)).
+ * reference: masked_act_mul_and_quant_async / masked_act_mul_and_blockwise_quant_async (src/activation/activation.h,
+ * entry src/activation/entry.cc:50-110). */
+int hpc_masked_act_mul_and_quant_async(void* out, const void* gate_up, const void* scale, const void* num_per_expert,
+                                       int num_total_tokens, int intermediate_size, int num_tokens_per_expert,
+                                       hpc_stream_t stream);
+int hpc_masked_act_mul_and_blockwise_quant_async(void* out, void* out_scale, const void* gate_up,
+                                                 const void* num_per_expert, int num_total_tokens,
+                                                 int intermediate_size, int num_tokens_per_expert,
+                                                 hpc_stream_t stream);
+
 /* x_scale [rows, n = K/128] -> transposed, tile-padded, compact [n, m] layout that
  * hpc_group_gemm_blockwise_fp8_async reads (DeepEP-format inputs).
  * reference: reformat_x_scale_async, src/group_gemm/group_gemm.h:27-29 (entry src/group_gemm/entry.cc:170-222). */

@@ -161,3 +161,33 @@ def test_group_gemm_cp_async_ops(num_group, actual_m, n, k, scatter):
         my = torch.ops.hpc.group_gemm_fp8_cp_async(d(x_compact), d(w), d(scale), d(seqlens), d(cu), d(tiles),
                                                    d(cu_tiles), True)
     assert allclose(gt.float(), my.cpu().float(), rtol=0.08, atol=1)
+
+
+@pytest.mark.gpu
+def test_masked_act_variants():
+    """masked_act_mul_and_quant / masked_act_mul_and_blockwise_quant (reference tests/test_act.py:62-160):
+    valid rows match the oracle, rows past num_per_expert[e] keep whatever the output held."""
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    g = torch.Generator().manual_seed(41)
+    E, per, inter = 32, 48, 2048
+    total = E * per
+    gate_up = torch.randn((total, 2 * inter), generator=g).bfloat16()
+    scale = torch.randn(1, generator=g)
+    cnt = torch.randint(0, per, (E,), generator=g).to(torch.int32)
+    keep = (torch.arange(total) % per) < cnt[torch.arange(total) // per]
+    sentinel = torch.full((total, inter), 3.0).to(F8)
+    out = sentinel.clone().cuda()
+    my = hpc.masked_act_mul_and_quant(gate_up.cuda(), scale.cuda(), cnt.cuda(), output=out)
+    gt = omoe.act_mul_and_quant(gate_up, scale, use_bf16_mul=False)
+    assert my.data_ptr() == out.data_ptr()
+    assert allclose(gt.float()[keep], my.cpu().float()[keep], atol=0.15, rtol=0.13)
+    assert torch.equal(my.cpu().view(torch.uint8)[~keep], sentinel.view(torch.uint8)[~keep])
+    qb, sb = hpc.masked_act_mul_and_blockwise_quant(gate_up.cuda(), cnt.cuda())
+    gq, gs = omoe.act_mul_and_blockwise_quant(gate_up)
+    assert qb.dtype == F8 and sb.shape == (total, inter // 128)
+    assert allclose(gs[keep], sb.cpu()[keep], rtol=1e-3, atol=1e-6)
+    deq_my = qb.cpu().float()[keep] * sb.cpu()[keep].repeat_interleave(128, dim=1)
+    deq_gt = gq.float()[keep] * gs[keep].repeat_interleave(128, dim=1)
+    assert allclose(deq_gt, deq_my, rtol=0.13, atol=2e-3)
