@@ -23,9 +23,7 @@ namespace {
 
 constexpr int kThreads = 512;
 constexpr int kBN = 256, kBM = 128, kBK = 128;
-constexpr int kStages = 3;
-constexpr int kWBytes = kBN * kBK, kXBytes = kBM * kBK, kXsBytes = 8 * 256;
-constexpr int kStageBytes = kWBytes + kXBytes + kXsBytes;
+constexpr int kWBytes = kBN * kBK, kXsBytes = 8 * 256;
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -33,11 +31,32 @@ __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
   return static_cast<long>(static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32));
 }
 
-template <bool kHasXs>
+// Per-token-tile-size constants (namespace scope on purpose: the kernel's lambdas use them, and hipcc's
+// host pass drops the kernel stub when a lambda in a templated __global__ refers to function-local
+// constexpr values derived from the template arguments).
+template <int kTok>
+struct TileCfg {
+  static constexpr int kSub = kBM / kTok;            // token tiles per 128-token tile of the scan
+  static constexpr int kWM = kTok == 128 ? 2 : 1;    // waves along tokens
+  static constexpr int kWN = 8 / kWM;                // waves along weight rows
+  static constexpr int kIN = kBN / kWN / 16;         // 16-row blocks per wave
+  static constexpr int kJN = kTok / kWM / 16;        // 16-token blocks per wave
+  static constexpr int kXBytes = kTok * kBK;
+  static constexpr int kStages = kTok == 128 ? 3 : 4;
+  static constexpr int kStageBytes = kWBytes + kXBytes + kXsBytes;
+  static constexpr int kXQ = kTok == 128 ? 2 : 1;    // activation DMA pieces per wave (8 rows each)
+  static constexpr int kXPieces = kTok / 8;
+};
+
+// kTok = tokens per tile: 128 (the form in use: 4 x 2 waves of 64 x 64, 3-slab ring) or 32 (experimental:
+// 8 x 1 waves of 32 x 32, a 4 KB activation slab and FOUR slabs in the ring; extra token tiles of a group
+// re-read the weight tile from the XCD's L2 - measured slower, see the launcher).
+template <bool kHasXs, int kTok>
 __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Args a, const int* __restrict__ cu_tiles,
                                                                         int num_group) {
-  __shared__ __attribute__((aligned(1024))) uint8_t s_ring[kStages * kStageBytes];
-  constexpr int kDmaPerStage = 4 + 2 + (kHasXs ? 1 : 0);  // per wave
+  using C = TileCfg<kTok>;
+  __shared__ __attribute__((aligned(1024))) uint8_t s_ring[C::kStages * C::kStageBytes];
+  constexpr int kDmaPerStage = 4 + C::kXQ + (kHasXs ? 1 : 0);  // per wave
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -49,7 +68,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
   // tiles of a weight tile (and the group's activation tiles) meet in ONE L2 instead of eight.
   const cint_ptr cut = as_const(cu_tiles);
   const int nt = a.N / kBN;
-  const int total = cut[num_group] * nt;
+  const int total = cut[num_group] * nt * C::kSub;
   const int chunk = (total + 7) >> 3;
   const int lin = blockIdx.x;
   const int item = (lin & 7) * chunk + (lin >> 3);
@@ -57,29 +76,30 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
   int lo = 0, hi = num_group;  // first e with cu_tiles[e + 1] * nt > item
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
-    if (cut[mid + 1] * nt <= item) lo = mid + 1; else hi = mid;
+    if (cut[mid + 1] * nt * C::kSub <= item) lo = mid + 1; else hi = mid;
   }
   const int e = lo;
-  const int mtiles = cut[e + 1] - cut[e];
-  const int rem = item - cut[e] * nt;
+  const int mtiles = (cut[e + 1] - cut[e]) * C::kSub;
+  const int rem = item - cut[e] * nt * C::kSub;
   const int m_cnt = as_const(a.seqlens)[e];
   const int m0 = as_const(a.cu_seqlens)[e];
-  const int mt0 = (rem % mtiles) * kBM;
+  const int mt0 = (rem % mtiles) * kTok;
+  if (mt0 >= m_cnt) return;  // empty token sub-tile of the last 128-token tile (workgroup-uniform)
   const int n0 = (rem / mtiles) * kBN;
   const int K = a.K, KB = a.KB;
-  const int wn = wave >> 1, wm = wave & 1;
+  const int wn = wave / C::kWM, wm = wave % C::kWM;
 
   // ---- DMA roles ----------------------------------------------------------------------------------------
   // 8-row pieces (1 KB): lane -> row piece*8 + lane/8, LDS position lane%8 <- global chunk (lane%8) ^ (lane/8)
   const int p_row = lane >> 3, p_chunk = (lane & 7) ^ (lane >> 3);
   const uint8_t* wsrc = a.w + (static_cast<long>(e) * a.N + n0) * K;
   const unsigned w_bytes = static_cast<unsigned>(kBN) * static_cast<unsigned>(K);
-  unsigned w_voff[4], x_voff[2];
+  unsigned w_voff[4], x_voff[2] = {0u, 0u};
 #pragma unroll
   for (int q = 0; q < 4; ++q) w_voff[q] = static_cast<unsigned>((wave * 4 + q) * 8 + p_row) * K + p_chunk * 16;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int slot = mt0 + (wave * 2 + q) * 8 + p_row;
+  for (int q = 0; q < C::kXQ; ++q) {
+    const int slot = mt0 + ((wave * C::kXQ + q) % C::kXPieces) * 8 + p_row;
     const int sc = slot < m_cnt ? slot : m_cnt - 1;
     const int xrow = a.row_index ? a.row_index[m0 + sc] : m0 + sc;
     x_voff[q] = static_cast<unsigned>(xrow) * static_cast<unsigned>(K) + p_chunk * 16;
@@ -94,12 +114,11 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
   }
   const int xs_kb_bytes = static_cast<int>(a.xs_kb_stride * 4);
 
-  auto issue = [&](int st) {  // k-slab st -> ring slot st % kStages; past the end: empty descriptors (zeros)
+  auto issue = [&](int st) {  // k-slab st -> ring slot st % C::kStages; past the end: empty descriptors (zeros)
     const bool on = st < KB;
     const int koff = st * kBK;
-    uint8_t* base = s_ring + (st % kStages) * kStageBytes;
+    uint8_t* base = s_ring + (st % C::kStages) * C::kStageBytes;
     const auto rw = make_rsrc(wsrc, on ? w_bytes : 0u);
-    const auto rx = make_rsrc(a.x, on ? a.x_bytes : 0u);
     // K % 128 == 64 (per-tensor scales): chunks past K get an out-of-range offset and land as zeros
     const bool k_ok = koff + p_chunk * 16 < K;
 #pragma unroll
@@ -107,101 +126,118 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + (wave * 4 + q) * 1024), 16,
                                            k_ok ? w_voff[q] : 0xffffff00u, koff, 0, 0);
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(base + kWBytes + (wave * 2 + q) * 1024), 16,
-                                           k_ok ? x_voff[q] : 0xffffff00u, koff, 0, 0);
+    for (int q = 0; q < 2; ++q) {
+      if (q >= C::kXQ) break;
+      // every wave issues the same number of DMAs (the vmcnt arithmetic needs that); waves without an
+      // activation piece (kTok = 32: waves 4..7) fetch nothing into the unused half of the scale slots
+      const int piece = wave * C::kXQ + q;
+      const bool real = piece < C::kXPieces;
+      const auto rxq = make_rsrc(a.x, on && real ? a.x_bytes : 0u);
+      const int dst_off = real ? kWBytes + piece * 1024 : kWBytes + C::kXBytes + 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rxq, (lds_void*)(base + dst_off), 16, k_ok ? x_voff[q] : 0xffffff00u,
+                                               koff, 0, 0);
+    }
     if constexpr (kHasXs) {
-      const auto rs = make_rsrc(a.xs, on && wave < 2 ? 0xffffffffu : 0u);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(base + kWBytes + kXBytes + wave * 256), 4, xs_voff,
+      const auto rs = make_rsrc(a.xs, on && wave < 2 && wave * 64 < kTok ? 0xffffffffu : 0u);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(base + kWBytes + C::kXBytes + wave * 256), 4, xs_voff,
                                            st * xs_kb_bytes, 0, 0);
     }
   };
 
   const cint_ptr ws_row = as_const(reinterpret_cast<const int*>(a.ws)) + static_cast<long>(e) * a.ws_group_stride +
-                          ((n0 + wn * 64) >> 7) * a.ws_ntile_stride;
+                          ((n0 + wn * 16 * C::kIN) >> 7) * a.ws_ntile_stride;
 
-  f32x4 tot[4][4];
+  f32x4 tot[C::kIN][C::kJN];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < C::kIN; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < C::kJN; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // operand read offsets inside a slab (swizzled): row r, chunk c -> r*128 + ((c ^ (r & 7)) << 4)
-  int a_off[4][2], b_off[4][2];
+  int a_off[C::kIN][2], b_off[C::kJN][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int c = 0; c < 2; ++c) {
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int ra = wn * 64 + i * 16 + r16, rb = wm * 64 + i * 16 + r16;
+    for (int i = 0; i < C::kIN; ++i) {
+      const int ra = wn * 16 * C::kIN + i * 16 + r16;
       a_off[i][c] = ra * kBK + (((g4 + 4 * c) ^ (ra & 7)) << 4);
-      b_off[i][c] = kWBytes + rb * kBK + (((g4 + 4 * c) ^ (rb & 7)) << 4);
     }
+#pragma unroll
+    for (int j = 0; j < C::kJN; ++j) {
+      const int rb = wm * 16 * C::kJN + j * 16 + r16;
+      b_off[j][c] = kWBytes + rb * kBK + (((g4 + 4 * c) ^ (rb & 7)) << 4);
+    }
+  }
 
   // ---- software pipeline --------------------------------------------------------------------------------
-  // The ring holds slabs kb (being consumed), kb+1 (landed by mid-step) and kb+2 (in flight).  Operand
-  // fragments are read one MFMA group ahead - the second half of slab kb before the first half's MFMAs,
-  // the first half of slab kb+1 before the second half's - so LDS latency hides behind 32 MFMAs, and the
-  // single barrier of a k-step sits between the two MFMA groups: past it every wave has finished reading
-  // slab kb (its slot is refilled with slab kb+3) and slab kb+1 is visible.
-  auto read_frags = [&](const uint8_t* slab, int c, u32x4 (&af)[4], u32x4 (&bf)[4]) {
+  // The ring holds slab kb (being consumed), kb+1 (landed by mid-step) and C::kStages-2 more in flight.
+  // Operand fragments are read one MFMA group ahead - the second half of slab kb before the first half's
+  // MFMAs, the first half of slab kb+1 before the second half's - so LDS latency hides behind an MFMA
+  // group, and the single barrier of a k-step sits between the two groups: past it every wave has
+  // finished reading slab kb (its slot is refilled with slab kb+C::kStages) and slab kb+1 is visible.
+  auto read_frags = [&](const uint8_t* slab, int c, u32x4 (&af)[C::kIN], u32x4 (&bf)[C::kJN]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const u32x4*>(slab + a_off[i][c]);
+    for (int i = 0; i < C::kIN; ++i) af[i] = *reinterpret_cast<const u32x4*>(slab + a_off[i][c]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const u32x4*>(slab + b_off[j][c]);
+    for (int j = 0; j < C::kJN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(slab + b_off[j][c]);
   };
-  auto mma_group = [&](f32x4 (&acc)[4][4], const u32x4 (&af)[4], const u32x4 (&bf)[4]) {
+  auto mma_group = [&](f32x4 (&acc)[C::kIN][C::kJN], const u32x4 (&af)[C::kIN], const u32x4 (&bf)[C::kJN]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < C::kIN; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < C::kJN; ++j) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(af[i][0], af[i][1]), pack64(bf[j][0], bf[j][1]),
                                                               acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(af[i][2], af[i][3]), pack64(bf[j][2], bf[j][3]),
                                                               acc[i][j], 0, 0, 0);
       }
   };
+  // s_waitcnt immediates: vmcnt = n (split 4 + 2 bits), expcnt untouched, lgkmcnt untouched (0xF) or 0
+  constexpr int kVmFirst = kDmaPerStage * (C::kStages - 1), kVmLoop = kDmaPerStage * (C::kStages - 2);
+  constexpr int kWaitFirst = 0x0F70 | (kVmFirst & 15) | ((kVmFirst >> 4) << 14);
+  constexpr int kWaitLoop = 0x0070 | (kVmLoop & 15) | ((kVmLoop >> 4) << 14);
 
 #pragma unroll
-  for (int st = 0; st < kStages; ++st) issue(st);
-  __builtin_amdgcn_s_waitcnt(0x0F70 | (kDmaPerStage * (kStages - 1)));  // slab 0 has landed
+  for (int st = 0; st < C::kStages; ++st) issue(st);
+  __builtin_amdgcn_s_waitcnt(kWaitFirst);  // slab 0 has landed
   __builtin_amdgcn_s_barrier();
-  u32x4 a0[4], b0[4], a1[4], b1[4];
+  u32x4 a0[C::kIN], b0[C::kJN], a1[C::kIN], b1[C::kJN];
   read_frags(s_ring, 0, a0, b0);
 
   for (int kb = 0; kb < KB; ++kb) {
-    const uint8_t* slab = s_ring + (kb % kStages) * kStageBytes;
-    const uint8_t* next = s_ring + ((kb + 1) % kStages) * kStageBytes;
+    const uint8_t* slab = s_ring + (kb % C::kStages) * C::kStageBytes;
+    const uint8_t* next = s_ring + ((kb + 1) % C::kStages) * C::kStageBytes;
     read_frags(slab, 1, a1, b1);
-    float f[4] = {0.f, 0.f, 0.f, 0.f};
+    float f[C::kJN];
     if constexpr (kHasXs) {
       const float wsk = __int_as_float(ws_row[kb * a.ws_kb_stride]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        f[j] = wsk * *reinterpret_cast<const float*>(slab + kWBytes + kXBytes + wm * 256 + (j * 16 + r16) * 4);
+      for (int j = 0; j < C::kJN; ++j)
+        f[j] = wsk * *reinterpret_cast<const float*>(slab + kWBytes + C::kXBytes + (wm * 16 * C::kJN + j * 16 + r16) * 4);
     }
-    f32x4 part[kHasXs ? 4 : 1][kHasXs ? 4 : 1];
+    f32x4 part[kHasXs ? C::kIN : 1][kHasXs ? C::kJN : 1];
     if constexpr (kHasXs) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < C::kIN; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) part[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < C::kJN; ++j) part[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       mma_group(part, a0, b0);
     } else {
       // one scale per group: accumulate straight into the running sum, scale once in the epilogue
       // (the reference scales every k-tile, kernels.cuh:473-476: same value up to fp32 rounding)
       mma_group(tot, a0, b0);
     }
-    // slab kb+1 has landed when only slab kb+2 is outstanding; lgkmcnt(0): my reads of slab kb are done
-    __builtin_amdgcn_s_waitcnt(0x0070 | kDmaPerStage);
+    // slab kb+1 has landed when only the younger slabs are outstanding; lgkmcnt(0): my reads of slab kb are done
+    __builtin_amdgcn_s_waitcnt(kWaitLoop);
     __builtin_amdgcn_s_barrier();
-    issue(kb + kStages);
+    issue(kb + C::kStages);
     read_frags(next, 0, a0, b0);
     if constexpr (kHasXs) {
       mma_group(part, a1, b1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < C::kIN; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < C::kJN; ++j)
 #pragma unroll
           for (int r = 0; r < 4; ++r) tot[i][j][r] = fmaf(part[i][j][r], f[j], tot[i][j][r]);
     } else {
@@ -213,21 +249,21 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
   if constexpr (!kHasXs) {
     const float gs = __int_as_float(ws_row[0]);  // per-tensor form: strides are zero, one scale per group
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < C::kIN; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) tot[i][j] *= gs;
+      for (int j = 0; j < C::kJN; ++j) tot[i][j] *= gs;
   }
-  // ---- epilogue: lane holds rows n = wn*64 + i*16 + g4*4 + r of token column wm*64 + j*16 + r16 --------------
+  // ---- epilogue: lane holds rows n = wn*16*C::kIN + i*16 + g4*4 + r of token column wm*16*C::kJN + j*16 + r16 --------
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int slot = mt0 + wm * 64 + j * 16 + r16;
+  for (int j = 0; j < C::kJN; ++j) {
+    const int slot = mt0 + wm * 16 * C::kJN + j * 16 + r16;
     if (slot < m_cnt) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < C::kIN; ++i) {
         u32x2 pk;
         pk[0] = pack_bf16x2(tot[i][j][0], tot[i][j][1]);
         pk[1] = pack_bf16x2(tot[i][j][2], tot[i][j][3]);
-        *reinterpret_cast<u32x2*>(a.y + static_cast<long>(m0 + slot) * a.N + n0 + wn * 64 + i * 16 + g4 * 4) = pk;
+        *reinterpret_cast<u32x2*>(a.y + static_cast<long>(m0 + slot) * a.N + n0 + wn * 16 * C::kIN + i * 16 + g4 * 4) = pk;
       }
     }
   }
@@ -241,15 +277,21 @@ int hpc_ggemm_launch_tiled256(const hpc::ggemm::Args& a, const int* cu_tiles, in
                               hipStream_t stream) {
   using namespace hpc::ggemm;
   if (n % kBN || a.K < kBK) return HPC_ERR_UNSUPPORTED;
+  // The 32-token-tile form (4-slab ring: three weight slabs in flight) was meant for 40-128 tokens per
+  // group; measured it is SLOWER (E64: 3.6 ms vs 2.2 ms at T = 256 .. 768) - its extra token tiles re-read
+  // the weight tile through L2 and do a quarter of the MFMA work per slab - so it only runs on request.
+  const bool narrow = hpc_tuning_get(6) == 2;
   const long max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 128)
-  const long items = max_tiles * (n / kBN) + 8;  // + 8: the per-XCD chunks round up
+  const long items = max_tiles * (n / kBN) * (narrow ? 4 : 1) + 8;  // + 8: the per-XCD chunks round up
   if (items > 0x7fffffffl) return HPC_ERR_UNSUPPORTED;
   dim3 grid(static_cast<unsigned>(items));
-  // (a non-temporal policy on the weight DMA for single-token-tile groups measured no difference)
-  if (a.has_xs)
-    gemm_fp8_tiled256_kernel<true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
-  else
-    gemm_fp8_tiled256_kernel<false><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  if (a.has_xs) {
+    if (narrow) gemm_fp8_tiled256_kernel<true, 32><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+    else gemm_fp8_tiled256_kernel<true, 128><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  } else {
+    if (narrow) gemm_fp8_tiled256_kernel<false, 32><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+    else gemm_fp8_tiled256_kernel<false, 128><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  }
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }
