@@ -135,3 +135,26 @@ def test_device_scheduler_matches_host_bytes(case):
     got = ws_gpu.view(torch.int32).cpu().numpy()[: ora.size].reshape(ora.shape).copy()
     got[0, 2:5] = 0  # allocator-owned header ints
     assert np.array_equal(got, ora)
+
+
+def test_product_host_scheduler_matches_oracle_on_random_batches():
+    """hypothesis: random batch shapes / lengths / bin counts / mtp / min_process_len - the closed-form planner
+    of the product (host build of csrc/assign_task.hip's planner) equals the C restatement of the reference's
+    greedy walk byte for byte (ints 9-11 of a record are padding the reference leaves uninitialised)."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    from oracle import sched
+
+    @settings(max_examples=150, deadline=None)
+    @given(lens=st.lists(st.integers(0, 40000), min_size=1, max_size=48),
+           bins=st.sampled_from([1, 2, 7, 64, 256, 512, 1024]), hkv=st.sampled_from([1, 2, 4, 8]),
+           sq=st.integers(1, 5), nkv=st.booleans(), minlen=st.sampled_from([64, 128, 512, 1024, 4096]))
+    def check(lens, bins, hkv, sq, nkv, minlen):
+        lens = np.asarray(lens, dtype=np.int32)
+        if nkv:  # lengths include the new tokens: they cannot be shorter than the new tokens
+            lens = np.maximum(lens, sq)
+        got = sched.mask_pad(_product_host_map(lens, bins, hkv, sq, nkv, minlen), bins)
+        assert np.array_equal(got, sched.task_map_oracle(lens, bins, hkv, sq, nkv, minlen))
+
+    check()
