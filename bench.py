@@ -368,7 +368,7 @@ def extra_allreduce(rank, world, local_rank):
     p = ctx.Process(target=_ar_child, args=(rank, world, local_rank, name, q))
     p.start()
     try:
-        _, res = q.get(timeout=240)
+        _, res = q.get(timeout=150)
     except Exception:  # noqa: BLE001
         res = {"error": "timeout"}
     p.join(timeout=20)
