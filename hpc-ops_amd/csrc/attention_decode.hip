@@ -23,7 +23,9 @@
 //  * A workgroup (= one scheduler bin) is 4 independent waves that take tiles t = w, w+4, ... of
 //    the current task, each with its own online softmax; they merge once per task through LDS.
 //    Requests that fit one bin are written straight to y; split requests leave fp32 partials
-//    (2 slots per bin) that the combine kernel merges with base-2 LSE weights.
+//    (2 slots per bin) that the combine kernel merges with base-2 LSE weights.  A bin packed with
+//    short tasks (<= 4 tiles each, mixed-length batches) instead gives every wave a whole task
+//    ("solo": no workgroup barrier, 4 tasks side by side) - see run_task below.
 //  * fp8 numerics follow the reference kernels: scores scaled by
 //    qscale[row]*kscale/sqrt(d) in the exp2 domain, P~ = e4m3(256 * 2^(s - running max)),
 //    O = sum(P~ V) / sum(p) * vscale / 256.

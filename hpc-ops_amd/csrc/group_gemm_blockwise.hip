@@ -7,14 +7,15 @@
 //
 // MI355X design: at decode batch sizes every expert sees a handful of tokens, so the op is a
 // stream of the weights (HBM-bound).  Same swap as the reference - weights on the
-// MFMA M axis, tokens on N (v_mfma_f32_16x16x32_fp8_fp8, 16 tokens per pass) - but no TMA /
-// warp specialisation: each WAVE owns 32 weight rows of one expert and streams them HBM -> VGPR
-// with 16-byte non-temporal buffer loads (4 stages of 256 B per row = 32 KB in flight per wave).
-// The activation tile (16/32/64 tokens) of the expert is shared by the 4 waves of a workgroup
-// through a small double-buffered LDS tile, fetched at the same prefetch depth as the weights
-// (vmcnt retires in order, so a shallower activation pipeline would drain the weight stream).
-// Per 128-wide k block the fp32 partial is rescaled by xs*ws and accumulated (reference
-// kernels.cuh:806-836).
+// MFMA M axis, tokens on N (v_mfma_f32_16x16x32_fp8_fp8, 16 / 32 / 48 tokens per pass) - but no TMA /
+// warp specialisation: each WAVE owns 16 weight rows of one expert and streams them HBM -> VGPR
+// with 16-byte non-temporal full-row buffer loads (3-4 stages of 256 B per row = 12-16 KB in flight
+// per wave, 8 waves per CU).  The activation tile of the expert is shared by the waves of a
+// workgroup through a small double-buffered LDS tile, fetched at the same prefetch depth as the
+// weights (vmcnt retires in order, so a shallower activation pipeline would drain the weight
+// stream).  Per 128-wide k block the fp32 partial is rescaled by xs*ws and accumulated (reference
+// kernels.cuh:806-836).  Groups above ~40 rows go to the tiled kernels (group_gemm_tiled256.hip,
+// group_gemm_tiled.hip) - see launch_stream_gemm at the end of this file.
 #include "hpc_common.h"
 #include "../../include/hpc_amd.h"
 #include "group_gemm.h"
