@@ -26,6 +26,7 @@ constexpr int kBN = 256, kBM = 128, kBK = 128;
 constexpr int kWBytes = kBN * kBK, kXsBytes = 8 * 256;
 
 typedef __attribute__((address_space(3))) void lds_void;
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
   return static_cast<long>(static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32));
@@ -138,7 +139,8 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
                                                koff, 0, 0);
     }
     if constexpr (kHasXs) {
-      const auto rs = make_rsrc(a.xs, on && wave < 2 && wave * 64 < kTok ? 0xffffffffu : 0u);
+      // readfirstlane: hipcc otherwise treats the record count as divergent and wraps the DMA in a waterfall loop
+      const auto rs = make_rsrc(a.xs, __builtin_amdgcn_readfirstlane(on && wave < 2 && wave * 64 < kTok ? 0xffffffffu : 0u));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)(base + kWBytes + C::kXBytes + wave * 256), 4, xs_voff,
                                            st * xs_kb_bytes, 0, 0);
     }
@@ -170,26 +172,50 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
   }
 
   // ---- software pipeline --------------------------------------------------------------------------------
-  // The ring holds slab kb (being consumed), kb+1 (landed by mid-step) and C::kStages-2 more in flight.
-  // Operand fragments are read one MFMA group ahead - the second half of slab kb before the first half's
-  // MFMAs, the first half of slab kb+1 before the second half's - so LDS latency hides behind an MFMA
-  // group, and the single barrier of a k-step sits between the two groups: past it every wave has
-  // finished reading slab kb (its slot is refilled with slab kb+C::kStages) and slab kb+1 is visible.
-  auto read_frags = [&](const uint8_t* slab, int c, u32x4 (&af)[C::kIN], u32x4 (&bf)[C::kJN]) {
+  // One v_mfma_f32_16x16x128_f8f6f4 (plain fp8 x fp8, no MX scales) covers the whole 128-byte k-slab of a
+  // 16 x 16 output block at TWICE the rate of four 16x16x32 fp8 MFMAs.  A lane supplies 32 bytes of its
+  // row: the two 16-byte chunks g4 and g4 + 4 (any assignment of k-bytes to lane slots is fine as long as
+  // both operands use the same one - a dot product does not care about the order of its terms).
+  // A k-step is split over the wave's weight-row blocks: the first half multiplies blocks [0, kIN/2) while
+  // the second half's weight fragments are read; the single barrier sits between the halves - past it
+  // every wave has finished reading slab kb (its slot is refilled with slab kb+C::kStages) and slab kb+1
+  // is visible, so the second half runs under the reads of the next slab's token fragments (double
+  // buffered: the current ones are still in use) and first-half weight fragments.
+  constexpr int kH = C::kIN / 2;
+  auto read_a = [&](const uint8_t* slab, int i0, u32x4 (&af)[kH][2]) {
 #pragma unroll
-    for (int i = 0; i < C::kIN; ++i) af[i] = *reinterpret_cast<const u32x4*>(slab + a_off[i][c]);
+    for (int i = 0; i < kH; ++i)
 #pragma unroll
-    for (int j = 0; j < C::kJN; ++j) bf[j] = *reinterpret_cast<const u32x4*>(slab + b_off[j][c]);
+      for (int c = 0; c < 2; ++c) af[i][c] = *reinterpret_cast<const u32x4*>(slab + a_off[i0 + i][c]);
   };
-  auto mma_group = [&](f32x4 (&acc)[C::kIN][C::kJN], const u32x4 (&af)[C::kIN], const u32x4 (&bf)[C::kJN]) {
+  auto read_b = [&](const uint8_t* slab, u32x4 (&bf)[C::kJN][2]) {
 #pragma unroll
-    for (int i = 0; i < C::kIN; ++i)
+    for (int j = 0; j < C::kJN; ++j)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) bf[j][c] = *reinterpret_cast<const u32x4*>(slab + b_off[j][c]);
+  };
+  auto mma_half = [&](int i0, const u32x4 (&af)[kH][2], const u32x4 (&bf)[C::kJN][2], const float (&f)[C::kJN]) {
+#pragma unroll
+    for (int i = 0; i < kH; ++i)
 #pragma unroll
       for (int j = 0; j < C::kJN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(af[i][0], af[i][1]), pack64(bf[j][0], bf[j][1]),
-                                                              acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(af[i][2], af[i][3]), pack64(bf[j][2], bf[j][3]),
-                                                              acc[i][j], 0, 0, 0);
+        const i32x8 av = {static_cast<int>(af[i][0][0]), static_cast<int>(af[i][0][1]), static_cast<int>(af[i][0][2]),
+                          static_cast<int>(af[i][0][3]), static_cast<int>(af[i][1][0]), static_cast<int>(af[i][1][1]),
+                          static_cast<int>(af[i][1][2]), static_cast<int>(af[i][1][3])};
+        const i32x8 bv = {static_cast<int>(bf[j][0][0]), static_cast<int>(bf[j][0][1]), static_cast<int>(bf[j][0][2]),
+                          static_cast<int>(bf[j][0][3]), static_cast<int>(bf[j][1][0]), static_cast<int>(bf[j][1][1]),
+                          static_cast<int>(bf[j][1][2]), static_cast<int>(bf[j][1][3])};
+        if constexpr (kHasXs) {
+          // fp32 partial of the 128-k block, rescaled into the running sum (reference kernels.cuh:473-476)
+          const f32x4 part = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0,
+                                                                              0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tot[i0 + i][j][r] = fmaf(part[r], f[j], tot[i0 + i][j][r]);
+        } else {
+          // one scale per group: accumulate straight into the running sum, scale once in the epilogue
+          // (the reference scales every k-tile: same value up to fp32 rounding)
+          tot[i0 + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, tot[i0 + i][j], 0, 0, 0, 0, 0, 0);
+        }
       }
   };
   // s_waitcnt immediates: vmcnt = n (split 4 + 2 bits), expcnt untouched, lgkmcnt untouched (0xF) or 0
@@ -201,48 +227,35 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
   for (int st = 0; st < C::kStages; ++st) issue(st);
   __builtin_amdgcn_s_waitcnt(kWaitFirst);  // slab 0 has landed
   __builtin_amdgcn_s_barrier();
-  u32x4 a0[C::kIN], b0[C::kJN], a1[C::kIN], b1[C::kJN];
-  read_frags(s_ring, 0, a0, b0);
+  u32x4 a_lo[kH][2], a_hi[kH][2], b_even[C::kJN][2], b_odd[C::kJN][2];
+  read_a(s_ring, 0, a_lo);
+  read_b(s_ring, b_even);
 
-  for (int kb = 0; kb < KB; ++kb) {
+  auto k_step = [&](int kb, const u32x4 (&b_cur)[C::kJN][2], u32x4 (&b_nxt)[C::kJN][2]) {
     const uint8_t* slab = s_ring + (kb % C::kStages) * C::kStageBytes;
     const uint8_t* next = s_ring + ((kb + 1) % C::kStages) * C::kStageBytes;
-    read_frags(slab, 1, a1, b1);
+    read_a(slab, kH, a_hi);
     float f[C::kJN];
+#pragma unroll
+    for (int j = 0; j < C::kJN; ++j) f[j] = 1.f;
     if constexpr (kHasXs) {
       const float wsk = __int_as_float(ws_row[kb * a.ws_kb_stride]);
 #pragma unroll
       for (int j = 0; j < C::kJN; ++j)
         f[j] = wsk * *reinterpret_cast<const float*>(slab + kWBytes + C::kXBytes + (wm * 16 * C::kJN + j * 16 + r16) * 4);
     }
-    f32x4 part[kHasXs ? C::kIN : 1][kHasXs ? C::kJN : 1];
-    if constexpr (kHasXs) {
-#pragma unroll
-      for (int i = 0; i < C::kIN; ++i)
-#pragma unroll
-        for (int j = 0; j < C::kJN; ++j) part[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      mma_group(part, a0, b0);
-    } else {
-      // one scale per group: accumulate straight into the running sum, scale once in the epilogue
-      // (the reference scales every k-tile, kernels.cuh:473-476: same value up to fp32 rounding)
-      mma_group(tot, a0, b0);
-    }
+    mma_half(0, a_lo, b_cur, f);
     // slab kb+1 has landed when only the younger slabs are outstanding; lgkmcnt(0): my reads of slab kb are done
     __builtin_amdgcn_s_waitcnt(kWaitLoop);
     __builtin_amdgcn_s_barrier();
     issue(kb + C::kStages);
-    read_frags(next, 0, a0, b0);
-    if constexpr (kHasXs) {
-      mma_group(part, a1, b1);
-#pragma unroll
-      for (int i = 0; i < C::kIN; ++i)
-#pragma unroll
-        for (int j = 0; j < C::kJN; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) tot[i][j][r] = fmaf(part[i][j][r], f[j], tot[i][j][r]);
-    } else {
-      mma_group(tot, a1, b1);
-    }
+    read_a(next, 0, a_lo);
+    read_b(next, b_nxt);
+    mma_half(kH, a_hi, b_cur, f);
+  };
+  for (int kb = 0; kb < KB; kb += 2) {
+    k_step(kb, b_even, b_odd);
+    if (kb + 1 < KB) k_step(kb + 1, b_odd, b_even);
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the (empty) tail DMAs before the workgroup's LDS is released
 
