@@ -115,17 +115,23 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
   }
   const int xs_kb_bytes = static_cast<int>(a.xs_kb_stride * 4);
 
-  auto issue = [&](int st) {  // k-slab st -> ring slot st % C::kStages; past the end: empty descriptors (zeros)
+  // k-slab st -> ring slot st % C::kStages; past the end: empty descriptors (zeros).  The weight and the
+  // activation DMAs of a slab are issued half a k-step apart (see the pipeline below).
+  auto issue_w = [&](int st, int q) {  // piece q (of 4) of this wave's share of the weight slab
     const bool on = st < KB;
     const int koff = st * kBK;
     uint8_t* base = s_ring + (st % C::kStages) * C::kStageBytes;
     const auto rw = make_rsrc(wsrc, on ? w_bytes : 0u);
     // K % 128 == 64 (per-tensor scales): chunks past K get an out-of-range offset and land as zeros
     const bool k_ok = koff + p_chunk * 16 < K;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + (wave * 4 + q) * 1024), 16,
-                                           k_ok ? w_voff[q] : 0xffffff00u, koff, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + (wave * 4 + q) * 1024), 16,
+                                             k_ok ? w_voff[q] : 0xffffff00u, koff, 0, 0);
+  };
+  auto issue_x = [&](int st) {
+    const bool on = st < KB;
+    const int koff = st * kBK;
+    uint8_t* base = s_ring + (st % C::kStages) * C::kStageBytes;
+    const bool k_ok = koff + p_chunk * 16 < K;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       if (q >= C::kXQ) break;
@@ -218,13 +224,22 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
         }
       }
   };
+  // DMA issue is spread over the k-step - eight waves firing all their slab DMAs right behind the barrier
+  // queue up in the texture path, and the MFMAs behind them in program order starve: the weight DMAs of
+  // slab kb+kStages go out between the second half's MFMAs (their slot is free past the barrier), its
+  // activation (+ scale) DMAs between the first half's MFMAs of the next k-step.
   // s_waitcnt immediates: vmcnt = n (split 4 + 2 bits), expcnt untouched, lgkmcnt untouched (0xF) or 0
-  constexpr int kVmFirst = kDmaPerStage * (C::kStages - 1), kVmLoop = kDmaPerStage * (C::kStages - 2);
+  constexpr int kDmaX = C::kXQ + (kHasXs ? 1 : 0);
+  constexpr int kVmFirst = kDmaPerStage * (C::kStages - 1) - kDmaX, kVmLoop = kDmaPerStage * (C::kStages - 2);
   constexpr int kWaitFirst = 0x0F70 | (kVmFirst & 15) | ((kVmFirst >> 4) << 14);
   constexpr int kWaitLoop = 0x0070 | (kVmLoop & 15) | ((kVmLoop >> 4) << 14);
 
 #pragma unroll
-  for (int st = 0; st < C::kStages; ++st) issue(st);
+  for (int st = 0; st < C::kStages; ++st) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) issue_w(st, q);
+    if (st + 1 < C::kStages) issue_x(st);  // the last slab's activation part goes out in the first k-step
+  }
   __builtin_amdgcn_s_waitcnt(kWaitFirst);  // slab 0 has landed
   __builtin_amdgcn_s_barrier();
   u32x4 a_lo[kH][2], a_hi[kH][2], b_even[C::kJN][2], b_odd[C::kJN][2];
@@ -244,14 +259,39 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
       for (int j = 0; j < C::kJN; ++j)
         f[j] = wsk * *reinterpret_cast<const float*>(slab + kWBytes + C::kXBytes + (wm * 16 * C::kJN + j * 16 + r16) * 4);
     }
+    issue_x(kb + C::kStages - 1);
     mma_half(0, a_lo, b_cur, f);
+    // order: the LDS reads, then MFMAs with one DMA between every two of them
+    __builtin_amdgcn_sched_group_barrier(0x100, kH * 2 + C::kJN, 0);
+#pragma unroll
+    for (int q = 0; q < kDmaX; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     // slab kb+1 has landed when only the younger slabs are outstanding; lgkmcnt(0): my reads of slab kb are done
     __builtin_amdgcn_s_waitcnt(kWaitLoop);
     __builtin_amdgcn_s_barrier();
-    issue(kb + C::kStages);
-    read_a(next, 0, a_lo);
-    read_b(next, b_nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    // program order = wanted order (a DMA writes LDS, so hipcc keeps it in place relative to the LDS reads):
+    // four rounds of one weight DMA + a quarter of the next slab's fragment reads, an MFMA between rounds
+    constexpr int kBPer = C::kJN * 2 / 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      issue_w(kb + C::kStages, q);
+      if (q < kH * 2) a_lo[q >> 1][q & 1] = *reinterpret_cast<const u32x4*>(next + a_off[q >> 1][q & 1]);
+#pragma unroll
+      for (int t = q * kBPer; t < (q + 1) * kBPer; ++t)
+        b_nxt[t >> 1][t & 1] = *reinterpret_cast<const u32x4*>(next + b_off[t >> 1][t & 1]);
+    }
     mma_half(kH, a_hi, b_cur, f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, (kH * 2 + C::kJN * 2 + 3) / 4, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
   };
   for (int kb = 0; kb < KB; kb += 2) {
     k_step(kb, b_even, b_odd);
