@@ -25,6 +25,16 @@ constexpr int kThreads = 512;
 constexpr int kBN = 256, kBM = 128, kBK = 128;
 constexpr int kWBytes = kBN * kBK, kXsBytes = 8 * 256;
 
+#ifdef HPC_TILED256_PROFILE
+// development build only (tools/prof_tiled256.sh): per-segment s_memtime sums of waves 0 and 7
+__device__ unsigned long long g_t256_prof[16];
+#define T256_STAMP(x) const unsigned long long x = __builtin_readcyclecounter()
+#define T256_ACC(i, v) prof[i] += (v)
+#else
+#define T256_STAMP(x)
+#define T256_ACC(i, v)
+#endif
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
@@ -246,7 +256,11 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
   read_a(s_ring, 0, a_lo);
   read_b(s_ring, b_even);
 
+#ifdef HPC_TILED256_PROFILE
+  unsigned long long prof[5] = {0, 0, 0, 0, 0};
+#endif
   auto k_step = [&](int kb, const u32x4 (&b_cur)[C::kJN][2], u32x4 (&b_nxt)[C::kJN][2]) {
+    T256_STAMP(t0);
     const uint8_t* slab = s_ring + (kb % C::kStages) * C::kStageBytes;
     const uint8_t* next = s_ring + ((kb + 1) % C::kStages) * C::kStageBytes;
     read_a(slab, kH, a_hi);
@@ -270,8 +284,11 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
     }
     __builtin_amdgcn_sched_barrier(0);
     // slab kb+1 has landed when only the younger slabs are outstanding; lgkmcnt(0): my reads of slab kb are done
+    T256_STAMP(t1);
     __builtin_amdgcn_s_waitcnt(kWaitLoop);
+    T256_STAMP(t2);
     __builtin_amdgcn_s_barrier();
+    T256_STAMP(t3);
     __builtin_amdgcn_sched_barrier(0);
     // program order = wanted order (a DMA writes LDS, so hipcc keeps it in place relative to the LDS reads):
     // four rounds of one weight DMA + a quarter of the next slab's fragment reads, an MFMA between rounds
@@ -292,11 +309,17 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
       __builtin_amdgcn_sched_group_barrier(0x100, (kH * 2 + C::kJN * 2 + 3) / 4, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    T256_STAMP(t4);
+    T256_ACC(0, t1 - t0); T256_ACC(1, t2 - t1); T256_ACC(2, t3 - t2); T256_ACC(3, t4 - t3); T256_ACC(4, 1);
   };
   for (int kb = 0; kb < KB; kb += 2) {
     k_step(kb, b_even, b_odd);
     if (kb + 1 < KB) k_step(kb + 1, b_odd, b_even);
   }
+#ifdef HPC_TILED256_PROFILE
+  if (lane == 0 && (wave == 0 || wave == 7))
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_t256_prof[(wave ? 8 : 0) + i], prof[i]);
+#endif
   __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the (empty) tail DMAs before the workgroup's LDS is released
 
   if constexpr (!kHasXs) {
@@ -325,6 +348,19 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_tiled256_kernel(const Ar
 }  // namespace
 }  // namespace ggemm
 }  // namespace hpc
+
+#ifdef HPC_TILED256_PROFILE
+extern "C" int hpc_debug_tiled256_prof(unsigned long long* out16, int reset) {
+  using namespace hpc::ggemm;
+  if (hipDeviceSynchronize() != hipSuccess) return HPC_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_t256_prof), sizeof(unsigned long long) * 16) != hipSuccess) return HPC_ERR_LAUNCH;
+  if (reset) {
+    unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_t256_prof), z, sizeof(z)) != hipSuccess) return HPC_ERR_LAUNCH;
+  }
+  return HPC_OK;
+}
+#endif
 
 int hpc_ggemm_launch_tiled256(const hpc::ggemm::Args& a, const int* cu_tiles, int num_group, int m, int n,
                               hipStream_t stream) {

@@ -10,11 +10,14 @@ dev = torch.device("cuda", 0)
 F8 = torch.float8_e4m3fn
 toks = [int(t) for t in sys.argv[1].split(",")] if len(sys.argv) > 1 else [4096]
 E, k, H, I = 64, 8, 4096, 11008
+import os
 torch.manual_seed(41)
 guw = torch.randint(-80, 80, (E, 2 * I, H), dtype=torch.int8, device=dev).view(F8)
 dw = torch.randint(-80, 80, (E, H, I), dtype=torch.int8, device=dev).view(F8)
 guws = torch.rand(E, 2 * I // 128, (H // 128 + 3) // 4 * 4, device=dev) * 0.02
 dws = torch.rand(E, H // 128, (I // 128 + 3) // 4 * 4, device=dev) * 0.02
+if os.environ.get('HPC_AB_ZERO'):
+    guw.view(torch.int8).zero_(); dw.view(torch.int8).zero_()
 gus, ds, ams = torch.rand(E, device=dev) * 0.01, torch.rand(E, device=dev) * 0.01, torch.ones(1, device=dev)
 key, vals = (int(sys.argv[2].split(':')[0]), [int(v) for v in sys.argv[2].split(':')[1].split(',')]) if len(sys.argv) > 2 else (15, [0])
 for T in toks:
