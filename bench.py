@@ -251,7 +251,7 @@ def extra_prefill(dev, hpc):
                iters=10, warm=2, graph=True)
     flops = 4.0 * D * Hq * B * (S * (S + 1) / 2)
     res = {"us": round(us, 1), "TFLOPS": round(flops / us / 1e6, 1),
-           "mfma_frac_of_2.5PF": round(flops / us / 1e6 / 2500, 4)}
+           "mfma_frac_of_5PF_fp8": round(flops / us / 1e6 / 5000, 4)}
     # block-sparse form: random 128 x 128 tile mask per q head, half of the causal tiles dropped
     nt = S // 128
     bm = torch.rand(B, Hq, nt, nt, device=dev) >= 0.5
@@ -270,7 +270,7 @@ def extra_prefill(dev, hpc):
                  iters=10, warm=2, graph=True)
     return {"attention_prefill_fp8_4x4096_h64_8": res,
             "attention_prefill_bf16_4x4096_h64_8": {"us": round(us16, 1), "TFLOPS": round(flops / us16 / 1e6, 1),
-                                                     "mfma_frac_of_2.5PF": round(flops / us16 / 1e6 / 2500, 4)}}
+                                                     "mfma_frac_of_2.5PF_bf16": round(flops / us16 / 1e6 / 2500, 4)}}
 
 
 def extra_moe(dev, hpc, tokens=(16, 64, 256, 4096)):
@@ -298,7 +298,7 @@ def extra_moe(dev, hpc, tokens=(16, 64, 256, 4096)):
         wbytes = hit * (2 * I * H + H * I)
         flops = 2.0 * T * k * (2 * I * H + H * I)
         res[f"T{T}"] = {"us": round(us, 1), "TFLOPS": round(flops / us / 1e6, 2),
-                        "mfma_frac_of_2.5PF": round(flops / us / 1e6 / 2500.0, 4),
+                        "mfma_frac_of_5PF_fp8": round(flops / us / 1e6 / 5000.0, 4),
                         "weight_GBps": round(wbytes / us / 1e3, 1),
                         "hbm_frac_of_8TBps": round(wbytes / us / 1e3 / HBM_PEAK_GBPS, 4), "experts_hit": hit}
     return {"fuse_moe_blockwise_fp8_E64_top8_H4096_I11008": res}

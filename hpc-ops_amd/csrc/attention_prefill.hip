@@ -257,13 +257,17 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
       for (int nb = 0; nb < kNB; ++nb) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
         if (nb_on[nb]) {
-#pragma unroll
-          for (int c = 0; c < 2; ++c) {
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(ka[c][0], ka[c][1]),
-                                                            pack64(qf[nb][c][0], qf[nb][c][1]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(ka[c][2], ka[c][3]),
-                                                            pack64(qf[nb][c][2], qf[nb][c][3]), acc, 0, 0, 0);
-          }
+          // the whole head dim in ONE v_mfma_f32_16x16x128_f8f6f4 (plain fp8 x fp8, twice the rate of four
+          // 16x16x32 fp8 MFMAs); lane (n, g) supplies chunks g and g + 4 of its row on both sides - a dot
+          // product does not care which lane slot a dim sits in as long as K and Q agree
+          const i32x8 kv8 = {static_cast<int>(ka[0][0]), static_cast<int>(ka[0][1]), static_cast<int>(ka[0][2]),
+                             static_cast<int>(ka[0][3]), static_cast<int>(ka[1][0]), static_cast<int>(ka[1][1]),
+                             static_cast<int>(ka[1][2]), static_cast<int>(ka[1][3])};
+          const i32x8 qv8 = {static_cast<int>(qf[nb][0][0]), static_cast<int>(qf[nb][0][1]),
+                             static_cast<int>(qf[nb][0][2]), static_cast<int>(qf[nb][0][3]),
+                             static_cast<int>(qf[nb][1][0]), static_cast<int>(qf[nb][1][1]),
+                             static_cast<int>(qf[nb][1][2]), static_cast<int>(qf[nb][1][3])};
+          acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(kv8, qv8, acc, 0, 0, 0, 0, 0, 0);
         }
         s[nb][tb] = acc;
       }

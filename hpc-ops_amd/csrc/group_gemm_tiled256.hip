@@ -11,8 +11,11 @@
 //     (l % 8) ^ (l / 8) of row l / 8, and a reader asks for position chunk ^ (row & 7);
 //   * two slabs stay in flight across the single barrier of a k-step: counted `s_waitcnt vmcnt(N)` and a
 //     raw `s_barrier` (a __syncthreads() would drain the DMA queue);
+//   * a 16 x 16 output block takes ONE v_mfma_f32_16x16x128_f8f6f4 per slab (plain fp8 x fp8: the only
+//     fp8 MFMA form that runs at the 5 PFLOP/s rate; 16x16x32_fp8_fp8 runs at the bf16 rate);
 //   * the per-token activation scales of the slab ride in the same ring (4-byte DMA), the weight-block
-//     scale is a scalar load; fp32 partial of a 128-k block is rescaled into the running sum as before.
+//     scale is a scalar load; fp32 partial of a 128-k block is rescaled into the running sum as before;
+//   * DMA issue is spread over the k-step and the instruction order pinned (see the pipeline comment).
 #include "hpc_common.h"
 #include "../../include/hpc_amd.h"
 #include "group_gemm.h"
@@ -36,7 +39,6 @@ __device__ unsigned long long g_t256_prof[16];
 #endif
 
 typedef __attribute__((address_space(3))) void lds_void;
-typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
   return static_cast<long>(static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32));
