@@ -21,6 +21,7 @@
 //    No workgroup ever waits on another workgroup of the same GPU, so the protocol cannot
 //    deadlock on residency; every spin is bounded.
 #include "hpc_common.h"
+#include "hpc_dev.h"
 #include "../../include/hpc_amd.h"
 
 namespace hpc {
@@ -32,22 +33,25 @@ constexpr int kMaxVec = 8;  // 16-byte vectors per thread per row: hidden <= 8 *
 constexpr uint32_t kSentinel = 0x80000000u;
 constexpr long kSpinLimit = 1L << 22;  // ~seconds; a dead peer yields a counted timeout, not a hang
 
-__device__ int g_timeouts = 0;
+// Peer-visible timeout counter: a word of pinned host memory every GPU of the process can bump with
+// a system-scope atomic and the host can read WITHOUT synchronising a stream.  The C entries refuse
+// to launch once it is non-zero (HPC_ERR_TIMEOUT): after a spin gave up the Lamport slots / signal
+// pads hold leftovers and every later result would be silently wrong.
+__device__ __forceinline__ void note_timeout(int* counter) {
+  __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // system-scope (sc0 sc1) accesses: the load bypasses L1/L2 so a peer's store is observed without a
-// kernel boundary; the store is written through to its home memory at once (a write-back store
-// would sit in this GPU's L2 until the kernel ends while the peer spins on it).
-__device__ __forceinline__ u32x4 ld16_sys(const void* p) {
-  u32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-  return v;
-}
+// kernel boundary (and a line of a peer's buffer cached by an EARLIER call is never served again);
+// the store is written through to its home memory at once (a write-back store would sit in this
+// GPU's L2 until the kernel ends while the peer spins on it).
+// Loads go through buffer descriptors with the cache-policy bits in `aux`, so hipcc tracks them in
+// vmcnt like any other load: a thread issues ALL the loads of a phase (every peer, every vector)
+// before it waits for the first one - with a hand-written `global_load ... ; s_waitcnt vmcnt(0)`
+// pair there was exactly one remote request in flight per thread.
+constexpr int kAuxSys = 17;  // sc0 | sc1
 __device__ __forceinline__ void st16_sys(void* p, u32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-}
-// bulk read of peer data that was complete before this kernel's barrier (first touch -> L1 miss)
-__device__ __forceinline__ u32x4 ld16_peer(const void* p) {
-  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
 }
 __device__ __forceinline__ u32x4 sanitize(u32x4 v) {
 #pragma unroll
@@ -56,19 +60,6 @@ __device__ __forceinline__ u32x4 sanitize(u32x4 v) {
 }
 __device__ __forceinline__ bool arrived(u32x4 v) {
   return v[0] != kSentinel && v[1] != kSentinel && v[2] != kSentinel && v[3] != kSentinel;
-}
-__device__ __forceinline__ u32x4 poll16(const void* p) {
-  u32x4 v = ld16_sys(p);
-  long spins = 0;
-  while (!arrived(v)) {
-    __builtin_amdgcn_s_sleep(2);
-    v = ld16_sys(p);
-    if (++spins > kSpinLimit) {
-      atomicAdd(&g_timeouts, 1);
-      break;
-    }
-  }
-  return v;
 }
 
 __device__ __forceinline__ float block_sum(float v, float* red) {
@@ -82,13 +73,14 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // r = bf16(sum + residual) -> residual_out; y = bf16(float(r) * rsqrt(mean(r^2) + eps) * w)
 // acc[i][0..7] hold the all-reduced row (fp32, already rounded to bf16 precision by the caller if
 // the mode requires it); returns the normalised row packed in `out`.
-__device__ __forceinline__ void residual_rmsnorm(float (&acc)[kMaxVec][8], int nvec, int hidden,
+template <int kVec>
+__device__ __forceinline__ void residual_rmsnorm(float (&acc)[kVec][8], int nvec, int hidden,
                                                  const uint16_t* res_row, uint16_t* res_out_row,
-                                                 const uint16_t* w, float eps, u32x4 (&out)[kMaxVec],
+                                                 const uint16_t* w, float eps, u32x4 (&out)[kVec],
                                                  float* red) {
   float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < kMaxVec; ++i) {
+  for (int i = 0; i < kVec; ++i) {
     const int v = threadIdx.x + i * kThreads;
     if (v < nvec) {
       const u32x4 rv = ld16(res_row + v * 8);
@@ -109,7 +101,7 @@ __device__ __forceinline__ void residual_rmsnorm(float (&acc)[kMaxVec][8], int n
   ss = block_sum(ss, red);
   const float rms = rsqrtf(ss / static_cast<float>(hidden) + eps);
 #pragma unroll
-  for (int i = 0; i < kMaxVec; ++i) {
+  for (int i = 0; i < kVec; ++i) {
     const int v = threadIdx.x + i * kThreads;
     if (v < nvec) {
       const u32x4 wv = ld16(w + v * 8);
@@ -131,6 +123,8 @@ struct HtArgs {
   const uint16_t* residual;
   uint16_t* out_residual;
   const uint16_t* w;
+  int* timeouts;                // host-pinned counter (see note_timeout)
+  long spin_limit;
   float eps;
   int rows, hidden, rank, ws;
 };
@@ -147,8 +141,8 @@ __device__ __forceinline__ void signal_barrier(const HtArgs& a) {
                                                  __HIP_MEMORY_SCOPE_SYSTEM)) {
       expect = 0u;
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > kSpinLimit) {
-        atomicAdd(&g_timeouts, 1);
+      if (++spins > a.spin_limit) {
+        note_timeout(a.timeouts);
         break;
       }
     }
@@ -159,8 +153,8 @@ __device__ __forceinline__ void signal_barrier(const HtArgs& a) {
                                                  __HIP_MEMORY_SCOPE_SYSTEM)) {
       expect = 1u;
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > kSpinLimit) {
-        atomicAdd(&g_timeouts, 1);
+      if (++spins > a.spin_limit) {
+        note_timeout(a.timeouts);
         break;
       }
     }
@@ -168,36 +162,73 @@ __device__ __forceinline__ void signal_barrier(const HtArgs& a) {
   __syncthreads();
 }
 
+// kWs > 0: world size known at compile time - the peer loops are fully unrolled and a thread has
+// 4 vectors x kWs peers = up to 32 remote 16-byte reads in flight before the first add (the row of
+// a peer is only 2 * hidden bytes, so the reduce-scatter phase is a latency problem: one read in
+// flight per thread moves ~0.25 of what the links can carry).  kWs == 0: any world size <= 8,
+// runtime loop over the peers (still all vectors of a peer in flight).
+// Loads are bounded buffer loads: lanes past the end of the row read 0 without a branch.
+// kVec = 16-byte vectors per thread and row: 4 for hidden <= 8192 (x[4][8] + acc: ~200 VGPRs, two
+// workgroups per CU), 8 up to 16384 (two passes of 4).
+template <int kWs, int kVec>
 __global__ __launch_bounds__(kThreads) void ht_kernel(const HtArgs a) {
   __shared__ float red[4];
   const int nvec = a.hidden >> 3;
+  const unsigned row_bytes = static_cast<unsigned>(a.hidden) * 2u;
   signal_barrier(a);  // every rank's input is in place
   for (int row = blockIdx.x; row < a.rows; row += gridDim.x) {
     const long roff = static_cast<long>(row) * a.hidden;
-    float acc[kMaxVec][8];
+    float acc[kVec][8];
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
-      const int v = threadIdx.x + i * kThreads;
+    for (int i = 0; i < kVec; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
-      if (v < nvec) {
-        for (int p = 0; p < a.ws; ++p) {
-          const u32x4 x = ld16_peer(a.in[p] + roff + v * 8);
+    // the whole byte offset goes into the VGPR offset: the descriptor's range check covers
+    // voffset + immediate only, an SGPR offset would slip lanes past the row end through
+    const int voff = threadIdx.x * 16;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc[i][2 * j] += bf16lo_to_f32(x[j]);
-            acc[i][2 * j + 1] += bf16hi_to_f32(x[j]);
-          }
+    for (int half = 0; half < kVec / 4; ++half) {
+      if constexpr (kWs > 0) {
+        u32x4 x[4][kWs];
+#pragma unroll
+        for (int p = 0; p < kWs; ++p) {
+          const auto rs = make_rsrc(uniform_ptr(a.in[p] + roff), row_bytes);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) x[i][p] = buf_ld16<kAuxSys>(rs, voff + (half * 4 + i) * kThreads * 16, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int p = 0; p < kWs; ++p)  // fixed rank order: deterministic sums
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              acc[half * 4 + i][2 * j] += bf16lo_to_f32(x[i][p][j]);
+              acc[half * 4 + i][2 * j + 1] += bf16hi_to_f32(x[i][p][j]);
+            }
+      } else {
+        for (int p = 0; p < a.ws; ++p) {
+          const auto rs = make_rsrc(uniform_ptr(a.in[p] + roff), row_bytes);
+          u32x4 x[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) x[i] = buf_ld16<kAuxSys>(rs, voff + (half * 4 + i) * kThreads * 16, 0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              acc[half * 4 + i][2 * j] += bf16lo_to_f32(x[i][j]);
+              acc[half * 4 + i][2 * j + 1] += bf16hi_to_f32(x[i][j]);
+            }
         }
       }
     }
-    u32x4 y[kMaxVec];
+    u32x4 y[kVec];
     residual_rmsnorm(acc, nvec, a.hidden, a.residual + roff, a.out_residual + roff, a.w, a.eps, y, red);
+    const int nws = kWs > 0 ? kWs : a.ws;
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
+    for (int i = 0; i < kVec; ++i) {
       const int v = threadIdx.x + i * kThreads;
       if (v < nvec)
-        for (int p = 0; p < a.ws; ++p) st16_sys(a.out[p] + roff + v * 8, y[i]);
+        for (int p = 0; p < nws; ++p) st16_sys(a.out[p] + roff + v * 8, y[i]);
     }
   }
   __threadfence_system();  // my rows are visible in every peer before I signal
@@ -216,6 +247,8 @@ struct LlArgs {
   uint16_t* residual_out;
   uint16_t* y;
   const uint16_t* w;
+  int* timeouts;
+  long spin_limit;
   float eps;
   int rows, hidden, rank, ws;
 };
@@ -245,6 +278,39 @@ __global__ __launch_bounds__(kThreads) void ll_scatter_kernel(const LlArgs a) {
   }
 }
 
+// Poll `kN` x `nper` 16-byte vectors of this thread until none carries the sentinel: every poll round
+// issues ALL the loads before it looks at the first one (local memory, system scope), instead of one
+// load -> wait -> check per vector.  Out-of-row lanes read 0 (bounded descriptor) = "arrived".
+template <int kVec, int kN>
+__device__ __forceinline__ void poll_vectors(u32x4 (&v)[kVec][kN], const uint8_t* base, long stride,
+                                             unsigned row_bytes, int nper, int* timeouts, long spin_limit) {
+  long spins = 0;
+  while (true) {
+    bool ok = true;
+#pragma unroll
+    for (int p = 0; p < kN; ++p) {
+      if (p >= nper) break;
+      const auto rs = make_rsrc(uniform_ptr(base + p * stride), row_bytes);
+#pragma unroll
+      for (int i = 0; i < kVec; ++i) v[i][p] = buf_ld16<kAuxSys>(rs, (threadIdx.x + i * kThreads) * 16, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < kN; ++p) {
+      if (p >= nper) break;
+#pragma unroll
+      for (int i = 0; i < kVec; ++i) ok = ok && arrived(v[i][p]);
+    }
+    if (ok) break;
+    __builtin_amdgcn_s_sleep(2);
+    asm volatile("" ::: "memory");  // the next round must really re-load
+    if (++spins > spin_limit) {
+      note_timeout(timeouts);
+      break;
+    }
+  }
+}
+
+template <int kVec>
 __global__ __launch_bounds__(kThreads) void ll_reduce_norm_kernel(const LlArgs a) {
   __shared__ float red[4];
   const uint32_t cur = a.flags[0] % 3u;
@@ -268,25 +334,35 @@ __global__ __launch_bounds__(kThreads) void ll_reduce_norm_kernel(const LlArgs a
   }
 
   for (int t = blockIdx.x; t < a.rows; t += gridDim.x) {
-    float acc[kMaxVec][8];
+    float acc[kVec][8];
+#pragma unroll
+    for (int i = 0; i < kVec; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
     if (t % a.ws == a.rank) {
-      // owner: wait for every rank's copy of row t, reduce, broadcast
+      // owner: wait for every rank's copy of row t (they land in MY memory), reduce, broadcast
       const uint8_t* src = a.local_ws + static_cast<long>(cur) * slot_bytes +
                            static_cast<long>(t / a.ws) * a.ws * row_bytes;
+      for (int p0 = 0; p0 < a.ws; p0 += 4) {  // 4 peers x all vectors in flight per round
+        u32x4 xv[kVec][4];
+        const int nper = a.ws - p0 < 4 ? a.ws - p0 : 4;
+        poll_vectors<kVec, 4>(xv, src + p0 * row_bytes, row_bytes, static_cast<unsigned>(row_bytes), nper, a.timeouts, a.spin_limit);
 #pragma unroll
-      for (int i = 0; i < kMaxVec; ++i) {
-        const int v = threadIdx.x + i * kThreads;
+        for (int p = 0; p < 4; ++p) {
+          if (p >= nper) break;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
-        if (v < nvec) {
-          for (int p = 0; p < a.ws; ++p) {
-            const u32x4 xv = poll16(src + p * row_bytes + v * 16);
+          for (int i = 0; i < kVec; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              acc[i][2 * j] += bf16lo_to_f32(xv[j]);
-              acc[i][2 * j + 1] += bf16hi_to_f32(xv[j]);
+              acc[i][2 * j] += bf16lo_to_f32(xv[i][p][j]);
+              acc[i][2 * j + 1] += bf16hi_to_f32(xv[i][p][j]);
             }
-          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < kVec; ++i) {
+        const int v = threadIdx.x + i * kThreads;
+        if (v < nvec) {
           u32x4 sum;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
@@ -301,27 +377,21 @@ __global__ __launch_bounds__(kThreads) void ll_reduce_norm_kernel(const LlArgs a
         }
       }
     } else {
-      const uint8_t* src = a.local_ws + bcast_off + t * row_bytes;
+      u32x4 xv[kVec][1];
+      poll_vectors<kVec, 1>(xv, a.local_ws + bcast_off + t * row_bytes, 0, static_cast<unsigned>(row_bytes), 1, a.timeouts, a.spin_limit);
 #pragma unroll
-      for (int i = 0; i < kMaxVec; ++i) {
-        const int v = threadIdx.x + i * kThreads;
+      for (int i = 0; i < kVec; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
-        if (v < nvec) {
-          const u32x4 xv = poll16(src + v * 16);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            acc[i][2 * j] = bf16lo_to_f32(xv[j]);
-            acc[i][2 * j + 1] = bf16hi_to_f32(xv[j]);
-          }
+        for (int j = 0; j < 4; ++j) {
+          acc[i][2 * j] = bf16lo_to_f32(xv[i][0][j]);
+          acc[i][2 * j + 1] = bf16hi_to_f32(xv[i][0][j]);
         }
-      }
     }
-    u32x4 y[kMaxVec];
+    u32x4 y[kVec];
     const long roff = static_cast<long>(t) * a.hidden;
     residual_rmsnorm(acc, nvec, a.hidden, a.residual + roff, a.residual_out + roff, a.w, a.eps, y, red);
 #pragma unroll
-    for (int i = 0; i < kMaxVec; ++i) {
+    for (int i = 0; i < kVec; ++i) {
       const int v = threadIdx.x + i * kThreads;
       if (v < nvec) st16(a.y + roff + v * 8, y[i]);
     }
@@ -334,22 +404,69 @@ __global__ __launch_bounds__(kThreads) void ll_reduce_norm_kernel(const LlArgs a
 
 using namespace hpc::ar;
 
+namespace {
+// development key 10 = n: bounded spins give up after 2^n rounds (tests of the lost-peer path)
+long spin_limit() {
+  const int n = hpc_dev_tuning_get(10);
+  return n > 0 && n < 40 ? 1L << n : kSpinLimit;
+}
+// one word of pinned, device-mapped host memory shared by every device of the process
+int* timeout_word() {
+  static int* host = [] {
+    int* p = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&p), 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess)
+      return static_cast<int*>(nullptr);
+    *p = 0;
+    return p;
+  }();
+  return host;
+}
+}  // namespace
+
 extern "C" int hpc_allreduce_timeouts(void) {
-  int v = 0;
-  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_timeouts), sizeof(int)) != hipSuccess) return -1;
-  return v;
+  int* p = timeout_word();
+  return p ? *reinterpret_cast<volatile int*>(p) : -1;
+}
+
+extern "C" int hpc_allreduce_reset_timeouts(void) {
+  int* p = timeout_word();
+  if (!p) return HPC_ERR_LAUNCH;
+  *reinterpret_cast<volatile int*>(p) = 0;
+  return HPC_OK;
+}
+
+extern "C" int hpc_fuse_allreduce_rmsnorm_high_throughput_grid(int world_size, int num_max_blocks,
+                                                               int signal_pad_words) {
+  if (world_size < 1 || world_size > kMaxWs || num_max_blocks <= 0 || signal_pad_words <= 0)
+    return HPC_ERR_INVALID;
+  // The barriers pair block b of this rank with block b of every peer, so the grid must be the same
+  // on every rank whatever slice each of them was handed: it is a function of rank-invariant inputs
+  // only (num_max_blocks, world size, pad capacity) - never of this rank's row count (the reference
+  // launches num_max_blocks blocks for the same reason, high_throughput.cu:135-150).  One row is
+  // only 2 * hidden bytes per peer, so the reference's SM-count-sized default is latency-bound on
+  // MI355X: at least 2 workgroups per CU; block b posts into words [b * ws, (b + 1) * ws) of a pad.
+  int grid = num_max_blocks > 512 ? num_max_blocks : 512;
+  if (grid > signal_pad_words / world_size) grid = signal_pad_words / world_size;
+  return grid > 0 ? grid : HPC_ERR_INVALID;
 }
 
 extern "C" int hpc_fuse_allreduce_rmsnorm_high_throughput_async(
     const void* const* peer_x_ptrs, void* const* peer_out_ptrs, void* const* peer_signal_ptrs,
     const void* residual_ptr, void* out_residual_ptr, const void* weight_ptr, float rms_norm_eps,
-    int num_rows, int hidden_size, int rank, int world_size, int num_max_blocks, hipStream_t stream) {
+    int num_rows, int hidden_size, int rank, int world_size, int num_max_blocks, int signal_pad_words,
+    hipStream_t stream) {
   if (!peer_x_ptrs || !peer_out_ptrs || !peer_signal_ptrs || !residual_ptr || !out_residual_ptr || !weight_ptr)
     return HPC_ERR_INVALID;
   if (world_size < 1 || world_size > kMaxWs || rank < 0 || rank >= world_size) return HPC_ERR_UNSUPPORTED;
   if ((hidden_size & 7) || hidden_size <= 0 || hidden_size > kMaxVec * kThreads * 8) return HPC_ERR_UNSUPPORTED;
-  if (num_max_blocks <= 0) return HPC_ERR_INVALID;
+  if (num_max_blocks <= 0 || num_rows < 0) return HPC_ERR_INVALID;
+  const int grid = hpc_fuse_allreduce_rmsnorm_high_throughput_grid(world_size, num_max_blocks, signal_pad_words);
+  if (grid <= 0) return HPC_ERR_INVALID;  // pad too small for even one block
   HtArgs a;
+  a.timeouts = timeout_word();
+  a.spin_limit = spin_limit();
+  if (!a.timeouts) return HPC_ERR_LAUNCH;
+  if (*reinterpret_cast<volatile int*>(a.timeouts) != 0) return HPC_ERR_TIMEOUT;
   for (int p = 0; p < kMaxWs; ++p) {
     a.in[p] = p < world_size ? static_cast<const uint16_t*>(peer_x_ptrs[p]) : nullptr;
     a.out[p] = p < world_size ? static_cast<uint16_t*>(peer_out_ptrs[p]) : nullptr;
@@ -363,14 +480,19 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_high_throughput_async(
   a.hidden = hidden_size;
   a.rank = rank;
   a.ws = world_size;
-  // Every rank must launch the same grid: the barriers pair block b with block b of each peer, so
-  // the grid is a pure function of (rows, num_max_blocks).  One row is only 2*hidden bytes per
-  // peer, so a 78-block grid (the reference's SM-count-sized default) is latency-bound on MI355X:
-  // use at least 2 workgroups per CU worth of rows; the signal pad (72 * CUs words) bounds it.
-  int grid = num_max_blocks > 512 ? num_max_blocks : 512;
-  if (grid > num_rows) grid = num_rows > 0 ? num_rows : 1;
-  if (grid * world_size > 72 * 256) grid = 72 * 256 / world_size;
-  ht_kernel<<<grid, kThreads, 0, stream>>>(a);
+#define HPC_HT_LAUNCH(WS)                                          \
+  if (hidden_size <= 4 * kThreads * 8)                              \
+    ht_kernel<WS, 4><<<grid, kThreads, 0, stream>>>(a);             \
+  else                                                              \
+    ht_kernel<WS, 8><<<grid, kThreads, 0, stream>>>(a)
+  switch (hpc_dev_tuning_get(9) == 1 ? 0 : world_size) {  // key 9 = 1: runtime-world-size kernel
+    case 1: HPC_HT_LAUNCH(1); break;
+    case 2: HPC_HT_LAUNCH(2); break;
+    case 4: HPC_HT_LAUNCH(4); break;
+    case 8: HPC_HT_LAUNCH(8); break;
+    default: HPC_HT_LAUNCH(0); break;
+  }
+#undef HPC_HT_LAUNCH
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }
@@ -390,6 +512,10 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_low_latency_async(
   const int64_t need = 3 * 2 * n_pad * hidden_size * 2;
   if (workspace_bytes < need) return HPC_ERR_INVALID;
   LlArgs a;
+  a.timeouts = timeout_word();
+  a.spin_limit = spin_limit();
+  if (!a.timeouts) return HPC_ERR_LAUNCH;
+  if (*reinterpret_cast<volatile int*>(a.timeouts) != 0) return HPC_ERR_TIMEOUT;
   a.x = static_cast<const uint16_t*>(input_ptr);
   a.peers = static_cast<const long*>(data_buffer_ptrs_dev);
   a.local_ws = static_cast<uint8_t*>(local_workspace_ptr);
@@ -406,7 +532,10 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_low_latency_async(
   const int grid = num_tokens < 2048 ? num_tokens : 2048;
   ll_scatter_kernel<<<grid, kThreads, 0, stream>>>(a);
   HPC_CHECK_LAUNCH();
-  ll_reduce_norm_kernel<<<grid, kThreads, 0, stream>>>(a);
+  if (hidden_size <= 4 * kThreads * 8)
+    ll_reduce_norm_kernel<4><<<grid, kThreads, 0, stream>>>(a);
+  else
+    ll_reduce_norm_kernel<8><<<grid, kThreads, 0, stream>>>(a);
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }

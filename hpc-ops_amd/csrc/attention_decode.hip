@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "hpc_common.h"
+#include "hpc_dev.h"
 #include "../../include/hpc_amd.h"
 #include "sched_task_info.h"
 
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(kThreads) void decode_combine_kernel(const Args a, 
 
 template <bool kFp8, int kQuant>
 int launch(const Args& a, int num_bins, int num_nb, hipStream_t stream) {
-  const bool temporal = hpc_tuning_get(0) == 1;
+  const bool temporal = hpc_dev_tuning_get(0) == 1;
 #define HPC_DECODE_LAUNCH(NB)                                                                   \
   if (temporal)                                                                                 \
     decode_kernel<kFp8, kQuant, NB, 0><<<num_bins, kThreads, 0, stream>>>(a);                   \
@@ -672,7 +673,7 @@ inline Common fill_common(Args& a, void* y_ptr, void* workspace, const int* task
   a.g_shift = group == 8 ? 3 : 2;
   a.page_shift = block_size == 64 ? 6 : (block_size == 32 ? 5 : 4);
   a.max_blocks = num_seq_max_blocks;
-  a.solo_ok = hpc_tuning_get(5) != 1;
+  a.solo_ok = hpc_dev_tuning_get(5) != 1;
   a.ldq = ldQ;
   a.ldy = ldY;
   a.qscale_stride = 0;

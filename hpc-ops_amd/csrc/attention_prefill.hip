@@ -14,6 +14,7 @@
 // that walk the KV tiles together (causal: each wave masks what its rows cannot see) and share every
 // K/V tile through a double-buffered LDS stage filled one tile ahead.
 #include "hpc_common.h"
+#include "hpc_dev.h"
 #include "../../include/hpc_amd.h"
 
 namespace hpc {
@@ -460,7 +461,7 @@ static int prefill_fp8_launch(const void* block_mask_ptr, int mask_tiles_m, int 
   a.block_mask = static_cast<const uint8_t*>(block_mask_ptr);
   // head-major 16-row blocks let a block skip masked-out tiles (block-sparse); dense attention measured ~8 %
   // faster with every wave holding all G heads of a few positions (key 7 overrides: 1 = by head, 2 = by position)
-  a.by_head = group <= 8 && (hpc_tuning_get(7) ? hpc_tuning_get(7) == 1 : block_mask_ptr != nullptr);
+  a.by_head = group <= 8 && (hpc_dev_tuning_get(7) ? hpc_dev_tuning_get(7) == 1 : block_mask_ptr != nullptr);
   a.mask_tiles_m = mask_tiles_m;
   a.mask_tiles_kv = mask_tiles_kv;
   if (block_mask_ptr && (mask_tiles_m <= 0 || mask_tiles_kv <= 0)) return HPC_ERR_INVALID;

@@ -329,3 +329,13 @@ extern "C" int hpc_comm_lookup_peers(const void* ptr, void** peer_ptrs, int* ran
   if (rank_out) *rank_out = it->second.rank;
   return it->second.world;
 }
+
+extern "C" int64_t hpc_comm_region_bytes_left(const void* ptr) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  const uintptr_t p = reinterpret_cast<uintptr_t>(ptr);
+  auto it = g_regions.upper_bound(p);
+  if (it == g_regions.begin()) return -1;
+  --it;
+  if (p >= it->first + it->second.bytes) return -1;
+  return static_cast<int64_t>(it->first + it->second.bytes - p);
+}

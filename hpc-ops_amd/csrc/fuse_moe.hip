@@ -188,8 +188,8 @@ __global__ __launch_bounds__(kThreads) void act_mul_blockwise_quant_kernel(
   const float scale = amax / 448.0f;
   const float inv = 1.0f / (scale + 1e-8f);
   u32x2 q;
-  q[0] = cvt_4xe4m3(a[0] * inv, a[1] * inv, a[2] * inv, a[3] * inv);
-  q[1] = cvt_4xe4m3(a[4] * inv, a[5] * inv, a[6] * inv, a[7] * inv);
+  q[0] = quant_4xe4m3(a[0] * inv, a[1] * inv, a[2] * inv, a[3] * inv);
+  q[1] = quant_4xe4m3(a[4] * inv, a[5] * inv, a[6] * inv, a[7] * inv);
   *reinterpret_cast<u32x2*>(out + static_cast<long>(row) * inter + c8 * 8) = q;
   if ((threadIdx.x & 15) == 0) {
     const long r = row_to_col ? row_to_col[row] : row;
@@ -229,8 +229,8 @@ __global__ __launch_bounds__(kThreads) void act_mul_quant_kernel(
     a[2 * j + 1] = s1 * sc;
   }
   u32x2 q;
-  q[0] = cvt_4xe4m3(a[0], a[1], a[2], a[3]);
-  q[1] = cvt_4xe4m3(a[4], a[5], a[6], a[7]);
+  q[0] = quant_4xe4m3(a[0], a[1], a[2], a[3]);
+  q[1] = quant_4xe4m3(a[4], a[5], a[6], a[7]);
   *reinterpret_cast<u32x2*>(out + static_cast<long>(row) * inter + c8 * 8) = q;
 }
 
@@ -243,9 +243,9 @@ __global__ __launch_bounds__(kThreads) void scaled_fp8_quant_kernel(const uint16
        i += static_cast<long>(gridDim.x) * kThreads) {
     const u32x4 v = ld16(in + i * 8);
     u32x2 q;
-    q[0] = cvt_4xe4m3(bf16lo_to_f32(v[0]) * sc, bf16hi_to_f32(v[0]) * sc, bf16lo_to_f32(v[1]) * sc,
+    q[0] = quant_4xe4m3(bf16lo_to_f32(v[0]) * sc, bf16hi_to_f32(v[0]) * sc, bf16lo_to_f32(v[1]) * sc,
                       bf16hi_to_f32(v[1]) * sc);
-    q[1] = cvt_4xe4m3(bf16lo_to_f32(v[2]) * sc, bf16hi_to_f32(v[2]) * sc, bf16lo_to_f32(v[3]) * sc,
+    q[1] = quant_4xe4m3(bf16lo_to_f32(v[2]) * sc, bf16hi_to_f32(v[2]) * sc, bf16lo_to_f32(v[3]) * sc,
                       bf16hi_to_f32(v[3]) * sc);
     *reinterpret_cast<u32x2*>(out + i * 8) = q;
   }

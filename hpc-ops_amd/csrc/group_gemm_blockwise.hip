@@ -17,6 +17,7 @@
 // kernels.cuh:806-836).  Groups above ~40 rows go to the tiled kernels (group_gemm_tiled256.hip,
 // group_gemm_tiled.hip) - see launch_stream_gemm at the end of this file.
 #include "hpc_common.h"
+#include "hpc_dev.h"
 #include "../../include/hpc_amd.h"
 #include "group_gemm.h"
 
@@ -247,7 +248,7 @@ int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const v
   // groups above ~40 tokens: tiled kernels (need the scan of ceil(seqlens/128)): the 256 x 128 LDS-DMA ring
   // kernel when n allows (one pass over the weights for up to 128 tokens; measured faster than the
   // streaming form from ~40 tokens per group on), else the 128 x 128 register-staged one
-  const int tiled_mode = hpc_tuning_get(3);  // 0 auto, 1 never, 2 always (when possible), 3 always, 128x128 only
+  const int tiled_mode = hpc_dev_tuning_get(3);  // 0 auto, 1 never, 2 always (when possible), 3 always, 128x128 only
   if (cu_tiles128 && n % 128 == 0 && tiled_mode != 1 && (tiled_mode >= 2 || m / num_group > 40)) {
     if (n % 256 == 0 && a.K >= 128 && tiled_mode != 3)
       return hpc_ggemm_launch_tiled256(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);
@@ -256,7 +257,7 @@ int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const v
   // tokens served per pass over the weights, from the average group size (the reference picks its
   // tileM the same way, fuse_moe/entry.cc:525-543); larger groups take several passes
   const int avg = m / num_group;
-  const int forced = hpc_tuning_get(1);
+  const int forced = hpc_dev_tuning_get(1);
   // forced: 1 / 2 / 3 / 4 = tokens-per-pass 16 / 32 / 48 / 64 with 16 rows per wave; 8 = 64 tokens, 32 rows per
   // wave; 16 / 32 = 64 / 32 tokens with 8 waves per workgroup
   // measured on E64 / top-8: 16 tokens per pass up to ~10 per group, 32 up to ~22, then 48 (one pass still

@@ -17,6 +17,7 @@
 //     scale is a scalar load; fp32 partial of a 128-k block is rescaled into the running sum as before;
 //   * DMA issue is spread over the k-step and the instruction order pinned (see the pipeline comment).
 #include "hpc_common.h"
+#include "hpc_dev.h"
 #include "../../include/hpc_amd.h"
 #include "group_gemm.h"
 
@@ -371,7 +372,7 @@ int hpc_ggemm_launch_tiled256(const hpc::ggemm::Args& a, const int* cu_tiles, in
   // The 32-token-tile form (4-slab ring: three weight slabs in flight) was meant for 40-128 tokens per
   // group; measured it is SLOWER (E64: 3.6 ms vs 2.2 ms at T = 256 .. 768) - its extra token tiles re-read
   // the weight tile through L2 and do a quarter of the MFMA work per slab - so it only runs on request.
-  const bool narrow = hpc_tuning_get(6) == 2;
+  const bool narrow = hpc_dev_tuning_get(6) == 2;
   const long max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 128)
   const long items = max_tiles * (n / kBN) * (narrow ? 4 : 1) + 8;  // + 8: the per-XCD chunks round up
   if (items > 0x7fffffffl) return HPC_ERR_UNSUPPORTED;

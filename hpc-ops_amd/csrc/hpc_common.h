@@ -44,19 +44,33 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 
 // ---- OCP e4m3fn conversions (gfx950 hardware cvt; saturating to +-448 like the reference's
 // __nv_fp8 casts, SURVEY 7 "hard parts") ------------------------------------------------
+// Two clamps.  clamp_e4m3: for values that cannot be NaN by construction (softmax probabilities):
+// fmaxf(NaN, -448) returns -448, so a NaN would come out as -448.  clamp_e4m3_nan: for quantisers of
+// caller data (activations, q/k/v, RMSNorm output) - NaN stays NaN (e.g. 0 * inf when a row's amax is
+// 0) like the reference's saturating __nv_fp8_e4m3 cast and torch's .to(float8_e4m3fn).
 __device__ __forceinline__ float clamp_e4m3(float x) {
-  // v_med3_f32: NaN-propagating is not needed; NaN inputs stay NaN through fminf/fmaxf order.
   return __builtin_fminf(__builtin_fmaxf(x, -448.0f), 448.0f);
+}
+__device__ __forceinline__ float clamp_e4m3_nan(float x) {
+  const float c = __builtin_fminf(__builtin_fmaxf(x, -448.0f), 448.0f);
+  return x != x ? x : c;
 }
 // packs (a, b) into the low 16 bits of the result.
 __device__ __forceinline__ uint32_t cvt_pk_e4m3(float a, float b) {
   return static_cast<uint32_t>(
-             __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(a), clamp_e4m3(b), 0, false)) &
+             __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3_nan(a), clamp_e4m3_nan(b), 0, false)) &
          0xffffu;
 }
+// probabilities (never NaN): the cheap clamp
 __device__ __forceinline__ uint32_t cvt_4xe4m3(float a, float b, float c, float d) {
   int r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(a), clamp_e4m3(b), 0, false);
   r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3(c), clamp_e4m3(d), r, true);
+  return static_cast<uint32_t>(r);
+}
+// caller data: NaN-preserving
+__device__ __forceinline__ uint32_t quant_4xe4m3(float a, float b, float c, float d) {
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3_nan(a), clamp_e4m3_nan(b), 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3_nan(c), clamp_e4m3_nan(d), r, true);
   return static_cast<uint32_t>(r);
 }
 // byte `sel` (0..3) of w -> f32
@@ -101,6 +115,14 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned num_records = 0xffffffffu) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, num_records, 0x00020000);
 }
+// Pin a pointer that IS wave-uniform (but that hipcc's divergence analysis cannot prove uniform) into
+// SGPRs; without it a descriptor built from the pointer costs a waterfall loop per access.
+__device__ __forceinline__ const uint8_t* uniform_ptr(const void* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+  return reinterpret_cast<const uint8_t*>(static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32));
+}
 // voff: per-lane byte offset (may carry a compile-time constant), soff: wave-uniform byte offset
 // kAux: cache policy bits of the buffer instruction (0 = default, 2 = nt "streaming, read once")
 template <int kAux = 0>
@@ -119,6 +141,7 @@ __device__ __forceinline__ u32x2 buf_ld8(rsrc_t rs, int voff, int soff) {
 #define HPC_ERR_UNSUPPORTED (-1)
 #define HPC_ERR_INVALID (-2)
 #define HPC_ERR_LAUNCH (-3)
+#define HPC_ERR_TIMEOUT (-4)
 
 #define HPC_CHECK_LAUNCH()                               \
   do {                                                   \

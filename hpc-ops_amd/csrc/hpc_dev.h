@@ -1,0 +1,21 @@
+// Development tuning registers - INTERNAL, not part of the C-ABI of include/hpc_amd.h.
+//
+// 16 small integers that select kernel variants inside the launchers for A/B measurements and for
+// the parity tests that pin one variant (tests/, tools/).  All zero = the shipped configuration.
+// Storage is a set of relaxed atomics (any host thread may read them while another one writes);
+// the environment variable HPC_AMD_TUNING="key=value,key=value" seeds them once at library load,
+// so a deployment never needs to call the setter.  The symbols are exported from libhpc_amd.so
+// for the in-tree tools only; they are deliberately absent from the public header.
+//   key 0  decode KV load cache policy (1 = temporal instead of nt)
+//   key 1  streaming grouped GEMM: forced tokens-per-pass / waves variant
+//   key 3  grouped GEMM tiled mode (0 auto, 1 never, 2 always when possible, 3 always 128x128)
+//   key 5  decode: 1 = never run one task per wave ("solo")
+//   key 6  256x128 tiled GEMM: 2 = 32-token narrow form
+//   key 7  block-sparse prefill row mapping (1 head-major, 2 position-major)
+//   key 9  fused all-reduce (high throughput): 1 = runtime-world-size kernel at any world size
+//   key 10 fused all-reduce: bounded spins give up after 2^value rounds (default 2^22)
+//   others: see the launchers that read them
+#pragma once
+
+extern "C" int hpc_dev_tuning_set(int key, int value);
+extern "C" int hpc_dev_tuning_get(int key);

@@ -57,12 +57,43 @@ extern "C" int hpc_get_cu_count(int device_id) {
   return cache[device_id];
 }
 
-// Tuning knobs (development hook, not part of the reference surface): small integer registers
-// read by the launchers.  key 0: decode KV load cache policy (0 = nt/default choice, 1 = temporal).
-static int g_tuning[16];
-extern "C" int hpc_tuning_set(int key, int value) {
+// Development tuning registers: see csrc/hpc_dev.h (internal; not in include/hpc_amd.h).
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+
+#include "hpc_dev.h"
+
+namespace {
+struct Tuning {
+  std::atomic<int> v[16];
+  Tuning() {
+    for (auto& x : v) x.store(0, std::memory_order_relaxed);
+    const char* env = std::getenv("HPC_AMD_TUNING");  // "key=value,key=value"
+    while (env && *env) {
+      char* end = nullptr;
+      const long k = std::strtol(env, &end, 10);
+      if (end == env || *end != '=') break;
+      env = end + 1;
+      const long val = std::strtol(env, &end, 10);
+      if (end == env) break;
+      if (k >= 0 && k < 16) v[k].store(static_cast<int>(val), std::memory_order_relaxed);
+      env = (*end == ',') ? end + 1 : end;
+      if (*end != ',') break;
+    }
+  }
+};
+Tuning& tuning() {
+  static Tuning t;
+  return t;
+}
+}  // namespace
+
+extern "C" int hpc_dev_tuning_set(int key, int value) {
   if (key < 0 || key >= 16) return -2;
-  g_tuning[key] = value;
+  tuning().v[key].store(value, std::memory_order_relaxed);
   return 0;
 }
-extern "C" int hpc_tuning_get(int key) { return (key < 0 || key >= 16) ? 0 : g_tuning[key]; }
+extern "C" int hpc_dev_tuning_get(int key) {
+  return (key < 0 || key >= 16) ? 0 : tuning().v[key].load(std::memory_order_relaxed);
+}

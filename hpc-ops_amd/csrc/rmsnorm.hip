@@ -69,14 +69,14 @@ __global__ __launch_bounds__(256) void rmsnorm_scale_kernel(
     }
     const int64_t o = row * hidden + v * 8;
     u32x2 q;
-    q[0] = cvt_4xe4m3(y[0] * inv0, y[1] * inv0, y[2] * inv0, y[3] * inv0);
-    q[1] = cvt_4xe4m3(y[4] * inv0, y[5] * inv0, y[6] * inv0, y[7] * inv0);
+    q[0] = quant_4xe4m3(y[0] * inv0, y[1] * inv0, y[2] * inv0, y[3] * inv0);
+    q[1] = quant_4xe4m3(y[4] * inv0, y[5] * inv0, y[6] * inv0, y[7] * inv0);
     *reinterpret_cast<u32x2*>(out_fp8 + o) = q;
     if constexpr (kMoe) {
       *reinterpret_cast<f32x4*>(out_f32 + o) = f32x4{y[0], y[1], y[2], y[3]};
       *reinterpret_cast<f32x4*>(out_f32 + o + 4) = f32x4{y[4], y[5], y[6], y[7]};
-      q[0] = cvt_4xe4m3(y[0] * inv1, y[1] * inv1, y[2] * inv1, y[3] * inv1);
-      q[1] = cvt_4xe4m3(y[4] * inv1, y[5] * inv1, y[6] * inv1, y[7] * inv1);
+      q[0] = quant_4xe4m3(y[0] * inv1, y[1] * inv1, y[2] * inv1, y[3] * inv1);
+      q[1] = quant_4xe4m3(y[4] * inv1, y[5] * inv1, y[6] * inv1, y[7] * inv1);
       *reinterpret_cast<u32x2*>(out_fp8_2 + o) = q;
     }
   }

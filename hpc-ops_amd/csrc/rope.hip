@@ -209,8 +209,8 @@ __global__ __launch_bounds__(kThreads) void rope_kernel(const Args a) {
       u32x2 o1, o2;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        o1[i] = cvt_4xe4m3(x1[4 * i] * mult, x1[4 * i + 1] * mult, x1[4 * i + 2] * mult, x1[4 * i + 3] * mult);
-        o2[i] = cvt_4xe4m3(x2[4 * i] * mult, x2[4 * i + 1] * mult, x2[4 * i + 2] * mult, x2[4 * i + 3] * mult);
+        o1[i] = quant_4xe4m3(x1[4 * i] * mult, x1[4 * i + 1] * mult, x1[4 * i + 2] * mult, x1[4 * i + 3] * mult);
+        o2[i] = quant_4xe4m3(x2[4 * i] * mult, x2[4 * i + 1] * mult, x2[4 * i + 2] * mult, x2[4 * i + 3] * mult);
       }
       *reinterpret_cast<u32x2*>(dst + 8 * j) = o1;
       *reinterpret_cast<u32x2*>(dst + 64 + 8 * j) = o2;

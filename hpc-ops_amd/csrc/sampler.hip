@@ -190,10 +190,13 @@ __global__ __launch_bounds__(kThreads) void sampler_segment_kernel(const Args a)
     if (lane == 0) s_red[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    // a segment whose logits are all -inf (grammar / vocabulary masks) must contribute (max = -inf,
+    // sum = 0), not exp(-inf - (-inf)) = NaN: subtract 0 instead of the -inf maximum
+    const float m_sub = m == kNegInf ? 0.f : m;
     float e = 0.f;
 #pragma unroll
     for (int j = 0; j < kElems; ++j)
-      if (key[j]) e += expf(val_of(key[j]) - m);
+      if (key[j]) e += expf(val_of(key[j]) - m_sub);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
     if (lane == 0) s_red[4 + wave] = e;

@@ -40,8 +40,8 @@ def _sig(name, restype, *argtypes):
 _sig("hpc_version", c_char_p)
 _sig("hpc_built_json", c_char_p)
 _sig("hpc_get_cu_count", I, I)
-_sig("hpc_tuning_set", I, I, I)
-_sig("hpc_tuning_get", I, I)
+_sig("hpc_dev_tuning_set", I, I, I)
+_sig("hpc_dev_tuning_get", I, I)
 _sig("hpc_fused_rmsnorm_with_scale_async", I, P, P, P, P, P, P, F, I, I, I, P)
 IP = ctypes.POINTER(c_int)
 _sig("hpc_attention_decode_num_bins", I, I, I)
@@ -96,14 +96,19 @@ _sig("hpc_comm_allgather", I, I, P, L, P)
 _sig("hpc_comm_info", I, I, IP, IP, IP)
 _sig("hpc_comm_create_tensor_sync", I, I, L, PP)
 _sig("hpc_comm_lookup_peers", I, P, PP, IP)
-_sig("hpc_fuse_allreduce_rmsnorm_high_throughput_async", I, PP, PP, PP, P, P, P, F, I, I, I, I, I, P)
+_sig("hpc_comm_region_bytes_left", L, P)
+_sig("hpc_fuse_allreduce_rmsnorm_high_throughput_grid", I, I, I, I)
+_sig("hpc_fuse_allreduce_rmsnorm_high_throughput_async", I, PP, PP, PP, P, P, P, F, I, I, I, I, I, I, P)
 _sig("hpc_fuse_allreduce_rmsnorm_low_latency_async", I, P, P, P, P, P, P, P, P, F, I, I, I, I, L, P)
 _sig("hpc_allreduce_timeouts", I)
+_sig("hpc_allreduce_reset_timeouts", I)
 
 # torch op namespace `hpc` (reference: TORCH_LIBRARY(hpc, m), src/C/C.cc:5)
 torch_lib = torch.library.Library("hpc", "DEF")
 
-_ERR = {-1: "unsupported configuration", -2: "invalid argument", -3: "HIP launch error"}
+_ERR = {-1: "unsupported configuration", -2: "invalid argument", -3: "HIP launch error",
+        -4: "an earlier fused all-reduce timed out waiting for a peer: results since then are undefined, "
+            "re-create the communicator handles (hpc_allreduce_reset_timeouts re-arms the entries)"}
 
 
 def check(code: int, what: str) -> None:
@@ -118,7 +123,14 @@ def ptr(t):
 
 
 def stream_of(t: torch.Tensor):
-    """Current HIP stream of t's device (reference: at::cuda::getCurrentCUDAStream(device))."""
+    """Current HIP stream of t's device (reference: at::cuda::getCurrentCUDAStream(device)).
+    The kernels are launched with the calling thread's CURRENT device, so a tensor that lives on another
+    device must not get here silently (its stream belongs to that other device): fail loudly instead - one
+    process per GPU is the deployment model, wrap the call in `with torch.cuda.device(t.device)` otherwise."""
+    idx = t.device.index
+    if idx is not None and idx != torch.cuda.current_device():
+        raise RuntimeError(f"hpc: tensor on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "call under torch.cuda.device(tensor.device)")
     return c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 

@@ -30,12 +30,17 @@ def _bf16_contig(t, name):
 _SIGNAL_CACHE = {}
 
 
-def _signal_ptrs(signal, world_size):
-    """Host copy of the device pointer table, read once per table (a per-call .cpu() would
-    synchronise the stream and break graph capture)."""
-    key = (signal.data_ptr(), world_size)
+def _signal_ptrs(signal, world_size, rank):
+    """Host copy of the device pointer table + the capacity (uint32 words) of this rank's signal pad,
+    read once per table (a per-call .cpu() would synchronise the stream and break graph capture).
+    The capacity comes from the communicator's registry: the pad runs to the end of the symmetric
+    buffer it was carved from (MulticastHandle: 72 * CU count words)."""
+    key = (signal.data_ptr(), world_size, rank)
     if key not in _SIGNAL_CACHE:
-        _SIGNAL_CACHE[key] = [int(v) for v in signal.cpu().tolist()[:world_size]]
+        ptrs = [int(v) for v in signal.cpu().tolist()[:world_size]]
+        left = _C.lib.hpc_comm_region_bytes_left(ctypes.c_void_p(ptrs[rank]))
+        _C.require(left >= 4 * world_size, "signal pad is not inside a symmetric buffer of this process (or too small)")
+        _SIGNAL_CACHE[key] = (ptrs, int(min(left // 4, 2 ** 31 - 1)))
     return _SIGNAL_CACHE[key]
 
 
@@ -63,11 +68,11 @@ def _ht_entry(x, multicast_x, residual, weight, signal, rank, world_size, num_ma
     out_ptrs, r_out = lookup_peers(output_multicast_x)
     _C.require(len(in_ptrs) == world_size and len(out_ptrs) == world_size and r_in == rank == r_out,
                "multicast views do not belong to a communicator of this world_size / rank")
-    sig_ptrs = _signal_ptrs(signal, world_size)
+    sig_ptrs, pad_words = _signal_ptrs(signal, world_size, int(rank))
     rc = _C.lib.hpc_fuse_allreduce_rmsnorm_high_throughput_async(
         _ptr_array(in_ptrs), _ptr_array(out_ptrs), _ptr_array(sig_ptrs), _C.ptr(residual),
         _C.ptr(output_residual), _C.ptr(weight), float(rms_norm_eps), rows, hidden, int(rank),
-        int(world_size), int(num_max_blocks), _C.stream_of(x))
+        int(world_size), int(num_max_blocks), pad_words, _C.stream_of(x))
     _C.check(rc, "fuse_allreduce_rmsnorm_high_throughput_async")
 
 

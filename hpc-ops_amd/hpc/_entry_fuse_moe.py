@@ -40,14 +40,16 @@ def aligned_size(avg: int) -> int:
 
 
 def _cu_tiles128(seqlens, m, num_group, stream):
-    """Scan of ceil(seqlens/128) for the tiled (large-group) GEMM kernel; None keeps the streaming one."""
+    """Scan of ceil(seqlens/128) for the tiled (large-group) GEMM kernel; None keeps the streaming one.
+    Returns the TENSOR: the caller keeps it referenced until its GEMM launch has been enqueued (a raw pointer
+    into a tensor that died at return would only be safe by grace of the caching allocator's stream ordering)."""
     if m // max(num_group, 1) <= 40:
         return None
     tiles = torch.empty(num_group, dtype=torch.int32, device=seqlens.device)
     cu = torch.empty(num_group + 1, dtype=torch.int32, device=seqlens.device)
     _C.check(_C.lib.hpc_moe_tiles_async(_C.ptr(seqlens), num_group, 128, _C.ptr(tiles), _C.ptr(cu), stream),
              "group_gemm tiles")
-    return _C.ptr(cu)
+    return cu
 
 
 def _cuda_contig(t, name):
@@ -162,11 +164,13 @@ def _group_gemm_blockwise_fp8_entry(x, weight, seqlens, cu_seqlens, x_scale, w_s
     s = _C.stream_of(x)
     _C.check(_C.lib.hpc_moe_tiles_async(_C.ptr(seqlens), num_group, tile_m, _C.ptr(tiles),
                                         _C.ptr(cu_tiles), s), "group_gemm tiles")
+    cu128 = _cu_tiles128(seqlens, m, num_group, s)
     rc = _C.lib.hpc_group_gemm_blockwise_fp8_async(
         _C.ptr(y), _C.ptr(x), _C.ptr(weight), _C.ptr(seqlens), _C.ptr(cu_seqlens), _C.ptr(x_scale),
         _C.ptr(w_scale), None, _C.ptr(cu_tiles), num_group, m, n, k, w_scale.size(2), tile_m, 1,
-        m_pad, _cu_tiles128(seqlens, m, num_group, s), s)
+        m_pad, _C.ptr(cu128), s)
     _C.check(rc, "group_gemm_blockwise_fp8_async")
+    del cu128  # lived until the launch was enqueued; stream order protects the rest
     return y
 
 
@@ -302,10 +306,12 @@ def _group_gemm_fp8_entry(x, weight, seqlens, cu_seqlens, y_scale, num_seq_per_g
     n, num_group = weight.size(1), seqlens.size(0)
     y = output if output is not None else torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
     s = _C.stream_of(x)
+    cu128 = _cu_tiles128(seqlens, m, num_group, s)
     rc = _C.lib.hpc_group_gemm_pertensor_fp8_async(
         _C.ptr(y), _C.ptr(x), _C.ptr(weight), _C.ptr(seqlens), _C.ptr(cu_seqlens), _C.ptr(y_scale), None,
-        num_group, m, m, n, k, _cu_tiles128(seqlens, m, num_group, s), s)
+        num_group, m, m, n, k, _C.ptr(cu128), s)
     _C.check(rc, "group_gemm_fp8_async")
+    del cu128
     return y
 
 
@@ -384,10 +390,12 @@ def _group_gemm_cp_async(x, weight, y_scale, row_indices, seqlens, cu_seqlens):
     m = row_indices.size(0) if row_indices is not None else x.size(0)
     y = torch.empty((m, n), dtype=torch.bfloat16, device=x.device)
     s = _C.stream_of(x)
+    cu128 = _cu_tiles128(seqlens, m, num_group, s)
     rc = _C.lib.hpc_group_gemm_pertensor_fp8_async(
         _C.ptr(y), _C.ptr(x), _C.ptr(weight), _C.ptr(seqlens), _C.ptr(cu_seqlens), _C.ptr(y_scale),
-        _C.ptr(row_indices), num_group, m, x.size(0), n, k, _cu_tiles128(seqlens, m, num_group, s), s)
+        _C.ptr(row_indices), num_group, m, x.size(0), n, k, _C.ptr(cu128), s)
     _C.check(rc, "group_gemm_fp8_cp_async")
+    del cu128
     return y
 
 

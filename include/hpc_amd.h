@@ -11,6 +11,8 @@
  *   -1  HPC_ERR_UNSUPPORTED  shape / tile configuration not supported
  *   -2  HPC_ERR_INVALID      bad argument (null pointer, inconsistent sizes)
  *   -3  HPC_ERR_LAUNCH       the HIP runtime refused the launch
+ *   -4  HPC_ERR_TIMEOUT      (fused all-reduce only) an earlier call on this process gave up waiting
+ *                            for a peer; the symmetric buffers / signal pads are in an undefined state
  * The Python shim turns every non-zero code into RuntimeError("... launch failed!").
  */
 #ifndef HPC_AMD_H_
@@ -31,11 +33,6 @@ const char* hpc_built_json(void);
 /* Number of compute units of device `device_id` (reference get_sm_count(), src/utils/utils.cc:15-27;
  * here per device, not a device-0 cache). */
 int hpc_get_cu_count(int device_id);
-
-/* Development tuning registers (no reference counterpart): key 0..15 -> small int read by the
- * launchers (see csrc/library.hip).  Defaults (all 0) are the shipped configuration. */
-int hpc_tuning_set(int key, int value);
-int hpc_tuning_get(int key);
 
 /* ---- RMSNorm (+fp8 quant) ------------------------------------------------------------------
  * reference: fused_rmsnorm_with_scale_async, src/normalization/fused_rmsnorm_with_scale.h:19-22
@@ -360,7 +357,8 @@ int hpc_fused_sampler_temperature_async(void* token_ids, void* workspace, const 
  * uncached device memory on every rank, exchanges IPC handles, ptrs_out[r] = rank r's buffer mapped
  * in this process (there is no multicast object on xGMI).  hpc_comm_lookup_peers translates an
  * address inside a local symmetric buffer into the same offset of every rank's buffer (returns the
- * world size or -1). */
+ * world size or -1); hpc_comm_region_bytes_left returns the bytes from `ptr` to the end of the local
+ * symmetric buffer that contains it (-1 if none) - the entries use it to learn a signal pad's capacity. */
 int hpc_comm_create(int rank, int world_size, int device_id, const char* name);
 int hpc_comm_destroy(int handle);
 int hpc_comm_barrier(int handle);
@@ -368,31 +366,42 @@ int hpc_comm_allgather(int handle, const void* in, int64_t nbytes, void* out);
 int hpc_comm_info(int handle, int* rank, int* world_size, int* device_id);
 int hpc_comm_create_tensor_sync(int handle, int64_t nbytes, void** ptrs_out);
 int hpc_comm_lookup_peers(const void* ptr, void** peer_ptrs, int* rank_out);
+int64_t hpc_comm_region_bytes_left(const void* ptr);
 
 /* ---- fused AllReduce + residual + RMSNorm (bf16) over peer memory ------------------------------------
  * reference: fuse_allreduce_rmsnorm_high_throughput_async, src/allreduce/
  *            fuse_allreduce_rmsnorm_high_throughput.h:11-17 (kernel .cu:15-99), and
  *            fuse_allreduce_rmsnorm_low_latency_async, fuse_allreduce_rmsnorm_low_latency.h:29-49,503-504.
  * R = bf16(sum_r x_r + residual); out = bf16(float(R) * rsqrt(mean(R^2) + eps) * w).
- * High throughput: this rank owns `num_rows` token rows; peer_x_ptrs[p] / peer_out_ptrs[p] address
- *   those rows inside rank p's symmetric input / output buffers, peer_signal_ptrs[p] rank p's signal
- *   pad (>= num_max_blocks * world_size uint32, zero-initialised).  All ranks must use the same
- *   num_max_blocks.  hidden <= 16384, world_size <= 8.  (The reference supports H in {4096,5120,7168}.)
+ * High throughput: this rank owns `num_rows` token rows (slices may differ between ranks); peer_x_ptrs[p] /
+ *   peer_out_ptrs[p] address those rows inside rank p's symmetric input / output buffers,
+ *   peer_signal_ptrs[p] rank p's signal pad of `signal_pad_words` zero-initialised uint32 (block b uses
+ *   words [b * world_size, (b + 1) * world_size)).  The barriers pair block b of every rank, so the grid is a
+ *   function of rank-invariant inputs only: hpc_fuse_allreduce_rmsnorm_high_throughput_grid(world_size,
+ *   num_max_blocks, signal_pad_words) = min(max(num_max_blocks, 512), signal_pad_words / world_size); all
+ *   ranks must pass the same num_max_blocks and pad size.  -2 when the pad cannot hold one block.
+ *   hidden <= 16384, world_size <= 8.  (The reference supports H in {4096,5120,7168}.)
  * Low latency (Lamport, token t owned by rank t % world_size): data_buffer_ptrs_dev = device int64
  *   table of the ranks' workspace bases, workspace = 3 slots x 2 stages, pre-filled with 0x80000000
  *   words by the caller, buffer_flags_dev = 9 x uint32 {cur, dirty, bytes per slot, 0, bytes to clear
  *   x4, arrive} advanced on the device.
- * hpc_allreduce_timeouts: number of bounded spins that gave up since load (0 in a healthy run). */
+ * Every spin on a peer is bounded (~seconds).  A spin that gives up bumps a counter in pinned host memory:
+ *   hpc_allreduce_timeouts reads it without synchronising any stream (0 in a healthy run), and from then on
+ *   both entries return HPC_ERR_TIMEOUT instead of launching - after a lost peer the Lamport slots / signal
+ *   pads hold leftovers, so the handles must be re-created; hpc_allreduce_reset_timeouts re-arms the entries. */
+int hpc_fuse_allreduce_rmsnorm_high_throughput_grid(int world_size, int num_max_blocks, int signal_pad_words);
 int hpc_fuse_allreduce_rmsnorm_high_throughput_async(
     const void* const* peer_x_ptrs, void* const* peer_out_ptrs, void* const* peer_signal_ptrs,
     const void* residual_ptr, void* out_residual_ptr, const void* weight_ptr, float rms_norm_eps,
-    int num_rows, int hidden_size, int rank, int world_size, int num_max_blocks, hpc_stream_t stream);
+    int num_rows, int hidden_size, int rank, int world_size, int num_max_blocks, int signal_pad_words,
+    hpc_stream_t stream);
 int hpc_fuse_allreduce_rmsnorm_low_latency_async(
     void* output_ptr, void* residual_out_ptr, const void* input_ptr, const void* data_buffer_ptrs_dev,
     void* local_workspace_ptr, void* buffer_flags_dev, const void* residual_in_ptr,
     const void* weight_ptr, float rms_norm_eps, int num_tokens, int hidden_size, int rank,
     int world_size, int64_t workspace_bytes, hpc_stream_t stream);
 int hpc_allreduce_timeouts(void);
+int hpc_allreduce_reset_timeouts(void);
 
 #ifdef __cplusplus
 }

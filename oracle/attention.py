@@ -149,6 +149,45 @@ def ref_attn_fp8(q, kvcache, block_ids, nblocks, num_seq_q, num_seq_kvcache, q_s
     return out.reshape(-1, num_head_q, head_dim)
 
 
+def ref_attn_fp8_separate(q, k_cache, v_cache, block_ids, kv_lens_total, num_seq_q, q_scale, k_scale,
+                          v_scale, rows=None):
+    """ref_attn_fp8 (per-tensor K/V scales) for separate K / V caches [nblk, P, Hkv, D] and lens that
+    already include the Sq new tokens - the layout of the reference benchmark generator
+    (benchmark/attention_decode/bench_attention_decode_fp8.py:137-180).  `rows` restricts the
+    computation to a subset of requests (graded-shape parity tests and the bounded CPU-baseline
+    sample of bench.py).  Same arithmetic as ref_attn_fp8: global-max softmax, P = e4m3(256 p),
+    y = P V / sum(p) * vscale / 256.  Returns bf16 [len(rows), Sq, Hq, D]."""
+    num_batch = kv_lens_total.shape[0]
+    num_head_q, head_dim = q.shape[1], q.shape[2]
+    P, num_head_kv = k_cache.shape[1], k_cache.shape[2]
+    group = num_head_q // num_head_kv
+    qb = q.reshape(num_batch, num_seq_q, num_head_q, head_dim)
+    qs = q_scale.reshape(num_batch, num_seq_q, num_head_q)
+    rows = range(num_batch) if rows is None else rows
+    outs = []
+    for bi in rows:
+        sq = num_seq_q
+        seqlen = int(kv_lens_total[bi])
+        blk = block_ids[bi, : (seqlen + P - 1) // P].long()
+        q_batch = qb[bi].transpose(0, 1).float()
+        k_batch = (k_cache[blk].reshape(-1, num_head_kv, head_dim).transpose(0, 1)[:, :seqlen]
+                   .repeat_interleave(group, dim=0)).float()
+        v_batch = (v_cache[blk].reshape(-1, num_head_kv, head_dim).transpose(0, 1)[:, :seqlen]
+                   .repeat_interleave(group, dim=0)).float()
+        p = q_batch @ k_batch.transpose(-1, -2) / math.sqrt(head_dim)
+        p = p * qs[bi].transpose(0, 1)[:, :, None] * k_scale
+        causal = torch.cat(
+            [torch.ones(sq, seqlen - sq, dtype=torch.bool),
+             torch.tril(torch.ones(sq, sq, dtype=torch.bool))], dim=-1).unsqueeze(0)
+        p = p.masked_fill(~causal, float("-inf"))
+        w = torch.exp(p - p.max(dim=-1)[0][:, :, None])
+        gsum = w.sum(dim=-1)[:, :, None]
+        w = (w * 256.0).to(torch.float8_e4m3fn).float()
+        y = torch.matmul(w, v_batch) / gsum * (v_scale / 256.0)
+        outs.append(y.transpose(0, 1).to(torch.bfloat16))
+    return torch.stack(outs, 0)
+
+
 def ref_prefill_fp8(q8, kcache8, vcache8, qscale, kscale, vscale, cu_seqlens_q, block_ids, seqlens_kv,
                     k_per_token=False, block_mask=None):
     """FP8 paged causal prefill oracle: restates naive_attn_with_kvcache_func of reference

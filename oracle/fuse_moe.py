@@ -133,3 +133,45 @@ def fuse_moe_pertensor_fp8(x, gate_up_weight, down_weight, gate_up_scale, down_s
     di = act_mul_and_quant(g, act_and_mul_scale, use_bf16_mul)
     d = group_gemm_pertensor(di, down_weight, seqlens, cu, down_scale)
     return reduce(d, topk_pos, topk_scale, shared_output)
+
+
+def fuse_moe_blockwise_fp8_rows(x, x_scale, expert_weights, topk_ids, topk_scale, rows, rank_ep,
+                                num_expert_local, shared_output=None):
+    """fuse_moe_blockwise_fp8 restricted to the token rows `rows` (every stage of the pipeline is
+    row-independent: GEMM rows, per-row 128-block quantisation, per-token reduce), with the expert
+    weights streamed one expert at a time - the full-size configuration (64 experts x 135 MB of
+    e4m3) never has to sit in host memory as fp32.  `expert_weights(e)` returns the CPU tensors
+    (gate_up_weight[e], gate_up_weight_scale[e], down_weight[e], down_weight_scale[e]).
+    Same arithmetic and rounding points as fuse_moe_blockwise_fp8 above (it calls the same stage
+    functions); returns bf16 [len(rows), H]."""
+    rows = [int(r) for r in rows]
+    num_topk = topk_ids.shape[1]
+    start = rank_ep * num_expert_local
+    by_expert = {}
+    for ri, t in enumerate(rows):
+        for j in range(num_topk):
+            e = int(topk_ids[t, j]) - start
+            if 0 <= e < num_expert_local:
+                by_expert.setdefault(e, []).append((ri, j))
+    hidden = x.shape[1]
+    down = torch.zeros(len(rows), num_topk, hidden, dtype=torch.bfloat16)
+    valid = torch.zeros(len(rows), num_topk, dtype=torch.float32)
+    for e in sorted(by_expert):
+        pairs = by_expert[e]
+        guw, guws, dw, dws = expert_weights(e)
+        toks = torch.tensor([rows[ri] for ri, _ in pairs], dtype=torch.long)
+        cnt = len(pairs)
+        one, zero = torch.tensor([cnt], dtype=torch.int32), torch.tensor([0], dtype=torch.int32)
+        g = group_gemm_blockwise(x[toks], guw[None], one, zero, x_scale[toks], guws[None])
+        di, dis = act_mul_and_blockwise_quant(g)
+        d = group_gemm_blockwise(di, dw[None], one, zero, dis, dws[None])
+        for i, (ri, j) in enumerate(pairs):
+            down[ri, j] = d[i]
+            valid[ri, j] = 1.0
+    tr = torch.tensor(rows, dtype=torch.long)
+    acc = torch.zeros(len(rows), hidden, dtype=torch.float32)
+    for j in range(num_topk):  # same accumulation order as reduce()
+        acc += down[:, j].float() * (topk_scale[tr, j].float() * valid[:, j]).unsqueeze(-1)
+    if shared_output is not None:
+        acc += shared_output[tr].float()
+    return acc.to(torch.bfloat16)

@@ -110,7 +110,12 @@ def _ar_task(rank, world_size, cases, name, q, device_index):
                     in_x[:n_it] = inputs[rank][:n_it].to(dev)
                     out_x.fill_(7.0)
                     out_res = torch.empty_like(res_d)
-                    start, end = N_pad // world_size * rank, N_pad // world_size * (rank + 1)
+                    if mode == "ht_uneven":  # slices of different sizes (legal: the grid is rank-invariant)
+                        cuts = [0] + [min(N_pad, (N_pad * (r + 1)) // world_size + (3 if r % 2 == 0 else -2))
+                                      for r in range(world_size - 1)] + [N_pad]
+                        start, end = cuts[rank], cuts[rank + 1]
+                    else:
+                        start, end = N_pad // world_size * rank, N_pad // world_size * (rank + 1)
                     off = start * H * 2
                     torch.cuda.synchronize()
                     comm.Barrier()
@@ -136,15 +141,19 @@ def _ar_task(rank, world_size, cases, name, q, device_index):
         q.put((rank, traceback.format_exc() or repr(e)))
 
 
-CASES = [("ht", 128, 8192, 16, 3), ("ht", 77, 5120, 78, 2), ("ll", 128, 8192, 16, 5), ("ll", 77, 7168, 78, 4),
-         ("ll", 8, 4096, 4, 3)]
+CASES = [("ht", 128, 8192, 16, 3), ("ht", 77, 5120, 78, 2), ("ht_uneven", 77, 8192, 64, 2), ("ht", 24, 16384, 64, 2),
+         ("ll", 128, 8192, 16, 5), ("ll", 77, 7168, 78, 4), ("ll", 8, 4096, 4, 3), ("ll", 16, 16384, 4, 2)]
 
 
-def _spawn(world_size):
+def _spawn(world_size, one_gpu_per_rank=False, tuning=""):
     ctx = multiprocessing.get_context("spawn")
     q = ctx.Queue()
-    name = f"t_ar_{os.getpid()}_{world_size}"
-    ps = [ctx.Process(target=_ar_task, args=(r, world_size, CASES, name, q, 0)) for r in range(world_size)]
+    name = f"t_ar_{os.getpid()}_{world_size}_{len(tuning)}"
+    old = os.environ.get("HPC_AMD_TUNING")
+    if tuning:
+        os.environ["HPC_AMD_TUNING"] = tuning  # inherited by the spawned ranks, read at library load
+    ps = [ctx.Process(target=_ar_task, args=(r, world_size, CASES, name, q, r if one_gpu_per_rank else 0))
+          for r in range(world_size)]
     for p in ps:
         p.start()
     res = []
@@ -152,6 +161,11 @@ def _spawn(world_size):
         res.append(q.get(timeout=600))
     for p in ps:
         p.join(timeout=60)
+    if tuning:
+        if old is None:
+            os.environ.pop("HPC_AMD_TUNING", None)
+        else:
+            os.environ["HPC_AMD_TUNING"] = old
     assert sorted(res) == [(r, "ok") for r in range(world_size)], res
 
 
@@ -165,3 +179,97 @@ def test_allreduce_rmsnorm_world2_shared_gpu():
     """two ranks on the single GPU of the test box: exercises IPC handles, pointer tables, signal
     barriers and the Lamport protocol across processes (the 8-GPU run is the driver's)."""
     _spawn(2)
+
+
+@pytest.mark.gpu
+def test_allreduce_rmsnorm_world2_generic_peer_loop():
+    """same protocol through the runtime-world-size kernel (world sizes other than 1/2/4/8 use it):
+    development tuning key 9 = 1 selects it at world size 2."""
+    _spawn(2, tuning="9=1")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world_size", [4, 8])
+def test_allreduce_rmsnorm_multi_gpu(world_size):
+    """one rank per GPU over xGMI; skipped on boxes with fewer GPUs (the driver's 8-GPU node runs it)."""
+    if torch.cuda.device_count() < world_size:
+        pytest.skip(f"needs {world_size} GPUs, {torch.cuda.device_count()} visible")
+    _spawn(world_size, one_gpu_per_rank=True)
+
+
+@pytest.mark.gpu
+def test_allreduce_rmsnorm_world2_two_gpus():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    _spawn(2, one_gpu_per_rank=True)
+
+
+def _lost_peer_task(q):
+    try:
+        _paths()
+        import hpc
+        from hpc import _C
+
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        comm = hpc.MulticastCommunicator(0, 1, 0, f"t_lost_{os.getpid()}")
+        H, rows = 4096, 8
+        buf, hdl = hpc.empty_multimem(comm, [rows, H], dtype=torch.bfloat16, device=dev)
+        out, ohdl = hpc.empty_multimem(comm, [rows, H], dtype=torch.bfloat16, device=dev)
+        res = torch.zeros(rows, H, dtype=torch.bfloat16, device=dev)
+        w = torch.ones(H, dtype=torch.bfloat16, device=dev)
+        pad = int(hdl.signal_buffer_ptrs[0])
+        arr = lambda vals: (ctypes.c_void_p * 8)(*vals)  # noqa: E731
+        # a 2-rank call whose rank 1 never shows up: rank 0's barrier gives up after its bounded spin
+        args = (arr([buf.data_ptr()] * 2), arr([out.data_ptr()] * 2), arr([pad, pad + 4096 * 8]), _C.ptr(res), _C.ptr(res),
+                _C.ptr(w), 1e-6, rows, H, 0, 2, 64, 2048)
+        assert _C.lib.hpc_allreduce_timeouts() == 0
+        rc = _C.lib.hpc_fuse_allreduce_rmsnorm_high_throughput_async(*args, _C.stream_of(buf))
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        n = _C.lib.hpc_allreduce_timeouts()  # read from pinned host memory: no stream sync involved
+        assert n > 0, "the lost peer was not counted"
+        rc = _C.lib.hpc_fuse_allreduce_rmsnorm_high_throughput_async(*args, _C.stream_of(buf))
+        assert rc == -4, f"entries must refuse to launch after a timeout, got {rc}"
+        try:
+            hpc.fuse_allreduce_rmsnorm_low_latency(buf, buf, hdl.data_buffer_ptrs_dev, buf,
+                                                   torch.zeros(9, dtype=torch.int32, device=dev), 1, 0, res, w, 1e-6, 4)
+            raise AssertionError("low-latency entry launched after a timeout")
+        except RuntimeError as e:
+            assert "timed out" in str(e)
+        assert _C.lib.hpc_allreduce_reset_timeouts() == 0 and _C.lib.hpc_allreduce_timeouts() == 0
+        q.put("ok")
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put(traceback.format_exc())
+
+
+@pytest.mark.gpu
+def test_allreduce_lost_peer_is_reported_and_latches():
+    """a spin that gives up must not pass silently: the counter lives in pinned host memory (readable without
+    a stream sync) and both entries refuse to launch (HPC_ERR_TIMEOUT -> RuntimeError) until it is reset."""
+    ctx = multiprocessing.get_context("spawn")
+    q = ctx.Queue()
+    old = os.environ.get("HPC_AMD_TUNING")
+    os.environ["HPC_AMD_TUNING"] = "10=14"  # give up after 2^14 spin rounds instead of 2^22 (~seconds)
+    try:
+        p = ctx.Process(target=_lost_peer_task, args=(q,))
+        p.start()
+        res = q.get(timeout=300)
+        p.join(timeout=60)
+    finally:
+        if old is None:
+            os.environ.pop("HPC_AMD_TUNING", None)
+        else:
+            os.environ["HPC_AMD_TUNING"] = old
+    assert res == "ok", res
+
+
+def test_high_throughput_grid_is_rank_invariant():
+    """CPU: the grid depends on (world size, num_max_blocks, pad capacity) only - never on a rank's row count -
+    and is clamped to the pad (72 * CUs words from MulticastHandle; fewer CUs on a partitioned device)."""
+    lib = ctypes.CDLL(str(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so"))
+    f = lib.hpc_fuse_allreduce_rmsnorm_high_throughput_grid
+    assert f(8, 64, 72 * 256) == 512 and f(8, 2048, 72 * 256) == 2048
+    assert f(8, 64, 72 * 32) == 72 * 32 // 8  # CPX-sized pad: clamped, not overrun
+    assert f(2, 64, 1) < 0 and f(9, 64, 1024) < 0 and f(2, 0, 1024) < 0

@@ -136,8 +136,8 @@ def test_attn_bf16_bins_of_short_requests(num_seq_q, kvcache_shape, solo):
     import hpc
 
     lens = torch.tensor([3, 64, 65, 128, 200, 250, 17, 1] * 6 + [5000], dtype=torch.int32)
-    hpc._C.lib.hpc_tuning_set(5, 0 if solo else 1)
+    hpc._C.lib.hpc_dev_tuning_set(5, 0 if solo else 1)
     try:
         _run(len(lens), num_seq_q, lens, 64, (2, 16), True, False, True, kvcache_shape, min_process_len=512)
     finally:
-        hpc._C.lib.hpc_tuning_set(5, 0)
+        hpc._C.lib.hpc_dev_tuning_set(5, 0)

@@ -129,8 +129,8 @@ def test_attn_fp8_bins_of_short_requests(k_per_token, num_seq_q, solo):
     import hpc
 
     lens = torch.tensor([3, 64, 65, 128, 200, 250, 17, 1] * 6 + [5000], dtype=torch.int32)
-    hpc._C.lib.hpc_tuning_set(5, 0 if solo else 1)
+    hpc._C.lib.hpc_dev_tuning_set(5, 0 if solo else 1)
     try:
         _run(len(lens), num_seq_q, lens, 64, (2, 16), k_per_token, True, True, "NHD", 0.1 if k_per_token else 0.2)
     finally:
-        hpc._C.lib.hpc_tuning_set(5, 0)
+        hpc._C.lib.hpc_dev_tuning_set(5, 0)

@@ -119,13 +119,13 @@ def test_group_gemm_blockwise(num_group, actual_m, n, k, forced_mt):
     for g in range(num_group):
         c0 = int(cu_tiles[g]) * tile_m
         xs_t[:, c0 : c0 + int(seqlens[g])] = xs_rows[int(cu[g]) : int(cu[g]) + int(seqlens[g])].t()
-    hpc._C.lib.hpc_tuning_set(1, forced_mt)
+    hpc._C.lib.hpc_dev_tuning_set(1, forced_mt)
     try:
         my = hpc.group_gemm_blockwise_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), xs_t.cuda(),
                                           wscale.cuda(), num_seq_per_group_avg=actual_m)
         torch.cuda.synchronize()
     finally:
-        hpc._C.lib.hpc_tuning_set(1, 0)
+        hpc._C.lib.hpc_dev_tuning_set(1, 0)
     assert allclose(gt.float(), my.cpu().float(), rtol=0.01, atol=0.02)
 
 
@@ -173,15 +173,15 @@ def test_group_gemm_blockwise_tiled_kernels(tiled_mode, n, k):
     for g in range(num_group):
         c0 = int(cu_tiles[g]) * tile_m
         xs_t[:, c0 : c0 + int(seqlens[g])] = xs_rows[int(cu[g]) : int(cu[g]) + int(seqlens[g])].t()
-    hpc._C.lib.hpc_tuning_set(3, tiled_mode % 10)
-    hpc._C.lib.hpc_tuning_set(6, 2 if tiled_mode >= 10 else 1)
+    hpc._C.lib.hpc_dev_tuning_set(3, tiled_mode % 10)
+    hpc._C.lib.hpc_dev_tuning_set(6, 2 if tiled_mode >= 10 else 1)
     try:
         my = hpc.group_gemm_blockwise_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), xs_t.cuda(), wscale.cuda(),
                                           num_seq_per_group_avg=avg)
         torch.cuda.synchronize()
     finally:
-        hpc._C.lib.hpc_tuning_set(3, 0)
-        hpc._C.lib.hpc_tuning_set(6, 0)
+        hpc._C.lib.hpc_dev_tuning_set(3, 0)
+        hpc._C.lib.hpc_dev_tuning_set(6, 0)
     assert allclose(gt.float(), my.cpu().float(), rtol=0.01, atol=0.02)
 
 

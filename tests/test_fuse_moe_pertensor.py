@@ -120,15 +120,15 @@ def test_group_gemm_pertensor_tiled_kernels(tiled_mode, k):
     scale = torch.rand(G) + 0.5
     cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
     gt = omoe.group_gemm_pertensor(x, w, seqlens, cu, scale)
-    hpc._C.lib.hpc_tuning_set(3, tiled_mode % 10)
-    hpc._C.lib.hpc_tuning_set(6, 2 if tiled_mode >= 10 else 1)
+    hpc._C.lib.hpc_dev_tuning_set(3, tiled_mode % 10)
+    hpc._C.lib.hpc_dev_tuning_set(6, 2 if tiled_mode >= 10 else 1)
     try:
         my = hpc.group_gemm_pertensor_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), scale.cuda(),
                                           num_seq_per_group_avg=total // G)
         torch.cuda.synchronize()
     finally:
-        hpc._C.lib.hpc_tuning_set(3, 0)
-        hpc._C.lib.hpc_tuning_set(6, 0)
+        hpc._C.lib.hpc_dev_tuning_set(3, 0)
+        hpc._C.lib.hpc_dev_tuning_set(6, 0)
     assert allclose(gt.float(), my.cpu().float(), rtol=0.08, atol=0.5)
 
 

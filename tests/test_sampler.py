@@ -61,6 +61,30 @@ def test_topk_topp_softmax_matrix(batch_size, max_topk, topk_val, softmax_policy
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("softmax_policy", [1, 2])
+def test_fully_masked_segments(softmax_policy):
+    """grammar / vocabulary masks: whole segments of the row are -inf.  With softmax BEFORE top-k a segment's
+    (max, sum) statistics must come out as (-inf, 0) - not exp(-inf - -inf) = NaN, which used to turn the whole
+    row into 'smallest token id of the top-k'."""
+    import hpc
+
+    g = _gen(77)
+    logits = torch.randn(3, V0, generator=g)
+    logits[0, : V0 // 2] = float("-inf")          # leading segments fully masked
+    logits[1, V0 // 3:] = float("-inf")           # trailing segments fully masked
+    logits[2, 1000: V0 - 1000] = float("-inf")    # only the ends survive
+    gumbel = orc.gumbel0_like(logits, g)
+    topk_t = torch.full((3,), 20, dtype=torch.int32)
+    topp_t = torch.full((3,), 0.9)
+    tok = hpc.fused_sampler(logits.cuda(), softmax_policy=hpc.SoftmaxPolicy(softmax_policy), topk=topk_t.cuda(),
+                            topp=topp_t.cuda(), max_topk=32, gumbel_noise=gumbel.cuda())
+    ref, _ = orc.ref_fused_sampler(logits, softmax_policy=softmax_policy, topk=topk_t, topp=topp_t, max_topk=32,
+                                   gumbel_noise=gumbel)
+    assert torch.equal(tok.cpu(), ref)
+    assert bool(torch.isfinite(logits[torch.arange(3), tok.cpu().long().flatten()]).all())  # never samples a masked token
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("batch_size", [1, 4])
 def test_repetition_penalty_and_writeback(batch_size):
     import hpc

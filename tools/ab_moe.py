@@ -26,7 +26,7 @@ for T in toks:
     x = (torch.randn(T, H, device=dev) / 100).to(F8)
     xs = torch.rand(T, H // 128, device=dev)
     for val in vals:
-        _C.lib.hpc_tuning_set(key, val)
+        _C.lib.hpc_dev_tuning_set(key, val)
         bw = bench.timed(lambda: hpc.fuse_moe_blockwise_fp8(x, xs, guw, guws, dw, dws, ids, sc, 0, E), iters=10, warm=2)
         pt = bench.timed(lambda: hpc.fuse_moe_pertensor_fp8(x, guw, dw, gus, ds, ams, ids, sc, 0, E), iters=10, warm=2)
         fl = 2.0 * T * k * 3 * I * H

@@ -55,11 +55,11 @@ def main():
         import itertools
         combos = list(itertools.product(*[vs for _, vs in sweeps])) if sweeps else [()]
         for combo in combos:
-            for (key, _), val in zip(sweeps, combo): _C.lib.hpc_tuning_set(key, val)
+            for (key, _), val in zip(sweeps, combo): _C.lib.hpc_dev_tuning_set(key, val)
             hpc.assign_attention_decode_task(lens, tm, a.hkv, 1, True, 64)
             us = timeit(run)
             print(f"{layout} B{a.batch} S{a.seq} tune={dict(zip([k for k,_ in sweeps], combo))}: {us:8.1f} us  {nbytes/us/1e3:7.1f} GB/s", flush=True)
-        for key, _ in sweeps: _C.lib.hpc_tuning_set(key, 0)
+        for key, _ in sweeps: _C.lib.hpc_dev_tuning_set(key, 0)
 
 if __name__ == "__main__":
     main()

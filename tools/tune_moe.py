@@ -13,7 +13,7 @@ if len(sys.argv) > 2:
     for part in sys.argv[2].split(";"):
         k, vs = part.split(":"); sweeps.append((int(k), [int(v) for v in vs.split(",")]))
 for combo in (itertools.product(*[v for _, v in sweeps]) if sweeps else [()]):
-    for (k, _), v in zip(sweeps, combo): _C.lib.hpc_tuning_set(k, v)
+    for (k, _), v in zip(sweeps, combo): _C.lib.hpc_dev_tuning_set(k, v)
     r = bench.extra_moe(dev, hpc, tokens=toks)
     for t, d in list(r.values())[0].items():
         print("tune", dict(zip([k for k, _ in sweeps], combo)), t, d, flush=True)
