@@ -443,9 +443,13 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_high_throughput_grid(int world_size, i
   // on every rank whatever slice each of them was handed: it is a function of rank-invariant inputs
   // only (num_max_blocks, world size, pad capacity) - never of this rank's row count (the reference
   // launches num_max_blocks blocks for the same reason, high_throughput.cu:135-150).  One row is
-  // only 2 * hidden bytes per peer, so the reference's SM-count-sized default is latency-bound on
-  // MI355X: at least 2 workgroups per CU; block b posts into words [b * ws, (b + 1) * ws) of a pad.
-  int grid = num_max_blocks > 512 ? num_max_blocks : 512;
+  // only 2 * hidden bytes per peer, so the reference's SM-count-sized default leaves most of an
+  // MI355X idle: at least one workgroup per CU (development key 11 = n replaces the floor of 256 -
+  // the tests that run two ranks on ONE GPU need both ranks' grids co-resident).  Block b posts into
+  // words [b * ws, (b + 1) * ws) of a pad.
+  const int floor_dev = hpc_dev_tuning_get(11);
+  const int floor_blocks = floor_dev > 0 ? floor_dev : 256;
+  int grid = num_max_blocks > floor_blocks ? num_max_blocks : floor_blocks;
   if (grid > signal_pad_words / world_size) grid = signal_pad_words / world_size;
   return grid > 0 ? grid : HPC_ERR_INVALID;
 }
@@ -455,6 +459,7 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_high_throughput_async(
     const void* residual_ptr, void* out_residual_ptr, const void* weight_ptr, float rms_norm_eps,
     int num_rows, int hidden_size, int rank, int world_size, int num_max_blocks, int signal_pad_words,
     hipStream_t stream) {
+  if (int* tw = timeout_word(); tw && *reinterpret_cast<volatile int*>(tw) != 0) return HPC_ERR_TIMEOUT;
   if (!peer_x_ptrs || !peer_out_ptrs || !peer_signal_ptrs || !residual_ptr || !out_residual_ptr || !weight_ptr)
     return HPC_ERR_INVALID;
   if (world_size < 1 || world_size > kMaxWs || rank < 0 || rank >= world_size) return HPC_ERR_UNSUPPORTED;
@@ -502,6 +507,7 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_low_latency_async(
     void* local_workspace_ptr, void* buffer_flags_dev, const void* residual_in_ptr,
     const void* weight_ptr, float rms_norm_eps, int num_tokens, int hidden_size, int rank,
     int world_size, int64_t workspace_bytes, hipStream_t stream) {
+  if (int* tw = timeout_word(); tw && *reinterpret_cast<volatile int*>(tw) != 0) return HPC_ERR_TIMEOUT;
   if (!output_ptr || !residual_out_ptr || !input_ptr || !data_buffer_ptrs_dev || !local_workspace_ptr ||
       !buffer_flags_dev || !residual_in_ptr || !weight_ptr)
     return HPC_ERR_INVALID;

@@ -14,6 +14,7 @@
 //   key 7  block-sparse prefill row mapping (1 head-major, 2 position-major)
 //   key 9  fused all-reduce (high throughput): 1 = runtime-world-size kernel at any world size
 //   key 10 fused all-reduce: bounded spins give up after 2^value rounds (default 2^22)
+//   key 11 fused all-reduce (high throughput): minimum grid (default 256 = one workgroup per CU)
 //   others: see the launchers that read them
 #pragma once
 

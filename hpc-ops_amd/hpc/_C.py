@@ -74,6 +74,7 @@ _sig("hpc_rope_norm_store_kv_fp8_async", I, P, P, P, P, P, P, P, P, P, P, P, P, 
      I, I, I, I, I, I, I, I, I, I, I, P)
 _sig("hpc_gemm_bf16xfp32_splits", I, I, I, I, I)
 _sig("hpc_gemm_bf16xfp32_async", I, P, P, P, P, P, P, I, I, I, F, I, I, I, P)
+_sig("hpc_topk_router_async", I, IP, P, P, I, I, L, I, I, P)
 _sig("hpc_attention_with_kvcache_prefill_fp8_async", I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I,
      I, I, L, L, L, L, L, L, L, L, L, P)
 _sig("hpc_attention_with_kvcache_blocksparse_prefill_fp8_async", I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I,

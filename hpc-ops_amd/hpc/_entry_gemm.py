@@ -55,3 +55,35 @@ def _gemm_bf16xfp32_entry(x, w_high, w_low, scale, use_fp32_output=False, use_sp
 
 
 _T.impl("gemm_bf16xfp32", _gemm_bf16xfp32_entry, "CUDA")
+
+
+# ---- fused softmax + top-k router (no reference op: pinned to stable torch semantics, oracle/router.py) ----
+_T.define("topk_router(Tensor logits, int topk, bool renormalize, Tensor? topk_ids, Tensor? topk_scale) -> (Tensor, Tensor)")
+
+
+def _topk_router_entry(logits, topk, renormalize=True, topk_ids=None, topk_scale=None):
+    import ctypes
+
+    _C.require(logits.is_cuda, "logits must be a device tensor")
+    _C.require(logits.dtype == torch.float32, "logits dtype must be float32 (the router GEMM's fp32 output)")
+    _C.require(logits.dim() == 2 and logits.stride(1) == 1, "logits must be [num_tokens, num_expert] with unit expert stride")
+    m, n = logits.shape
+    _C.require(n % 4 == 0 and n <= 1024, "num_expert must be a multiple of 4 and <= 1024")
+    _C.require(1 <= topk <= min(n, 64), "topk must be in 1..min(num_expert, 64)")
+    _C.require(logits.stride(0) % 4 == 0 and logits.data_ptr() % 16 == 0, "logits rows must be 16-byte aligned")
+    if topk_ids is None:
+        topk_ids = torch.empty((m, topk), dtype=torch.int32, device=logits.device)
+    if topk_scale is None:
+        topk_scale = torch.empty((m, topk), dtype=torch.float32, device=logits.device)
+    _C.require(topk_ids.dtype == torch.int32 and topk_ids.is_contiguous() and tuple(topk_ids.shape) == (m, topk),
+               "topk_ids must be a contiguous int32 [num_tokens, topk] tensor")
+    _C.require(topk_scale.dtype == torch.float32 and topk_scale.is_contiguous() and tuple(topk_scale.shape) == (m, topk),
+               "topk_scale must be a contiguous float32 [num_tokens, topk] tensor")
+    rc = _C.lib.hpc_topk_router_async(ctypes.cast(topk_ids.data_ptr(), ctypes.POINTER(ctypes.c_int)), _C.ptr(topk_scale),
+                                      _C.ptr(logits), m, n, logits.stride(0), int(topk), int(bool(renormalize)),
+                                      _C.stream_of(logits))
+    _C.check(rc, "topk_router")
+    return topk_ids, topk_scale
+
+
+_T.impl("topk_router", _topk_router_entry, "CUDA")

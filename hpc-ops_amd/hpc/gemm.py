@@ -33,3 +33,22 @@ def gemm_bf16xfp32(
 def _gemm_bf16xfp32_fake(a, b_high, b_low, scale, use_fp32_output=False, use_splitk=True, split_flag=None):
     return torch.empty((a.shape[0], b_high.shape[0]), dtype=torch.float32 if use_fp32_output else a.dtype,
                        device=a.device)
+
+
+def topk_router(logits: Tensor, topk: int, renormalize: bool = True, topk_ids: Tensor = None,
+                topk_scale: Tensor = None):
+    """Fused softmax + top-k over the router logits (the fp32 output of gemm_bf16xfp32): returns
+    (topk_ids int32 [m, topk], topk_scale float32 [m, topk]) - what fuse_moe / fuse_moe_blockwise_fp8 take.
+
+    No reference counterpart (the reference stops at the GEMM); semantics = stable PyTorch:
+    ids = argsort(logits, descending, stable)[:, :topk] (ties -> smaller expert id, bit-exact),
+    p = softmax(logits.float(), -1), scale = p[ids] (renormalize=False) or p[ids] / p[ids].sum(-1) (True).
+    logits [m, num_expert] float32, num_expert % 4 == 0 and <= 1024, topk <= 64."""
+    return torch.ops.hpc.topk_router(logits, topk, renormalize, topk_ids, topk_scale)
+
+
+@torch.library.register_fake("hpc::topk_router")
+def _topk_router_fake(logits, topk, renormalize=True, topk_ids=None, topk_scale=None):
+    m = logits.shape[0]
+    return (torch.empty((m, topk), dtype=torch.int32, device=logits.device),
+            torch.empty((m, topk), dtype=torch.float32, device=logits.device))

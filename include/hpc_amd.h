@@ -259,6 +259,17 @@ int hpc_gemm_bf16xfp32_async(void* y, void* splitk_y, void* split_flag, const vo
                              const void* w_low, int m, int n, int k, float scale, int use_fp32_output,
                              int splits, int flag_ld, hpc_stream_t stream);
 
+/* ---- fused softmax + top-k router (the step between the router GEMM and fuse_moe*) ---------------------
+ * No reference kernel exists (hpc/gemm.py:16-61 stops at the GEMM; BASELINE north_star names the op); the
+ * semantics are pinned to stable PyTorch: ids = the first `topk` entries of a STABLE descending sort of the
+ * fp32 logits (ties -> smaller expert id; bit-exact), p = softmax(logits) in fp32,
+ * topk_scale = p[ids] (renormalize = 0) or p[ids] / sum(p[ids]) (renormalize = 1), best expert first.
+ * logits f32 [num_tokens, ld_logits >= num_expert], 16-byte aligned rows; num_expert % 4 == 0, <= 1024;
+ * topk <= 64.  topk_ids int32 [num_tokens, topk], topk_scale f32 [num_tokens, topk] - the tensors
+ * hpc_fuse_moe_*_async take. */
+int hpc_topk_router_async(int* topk_ids, float* topk_scale, const float* logits, int num_tokens, int num_expert,
+                          int64_t ld_logits, int topk, int renormalize, hpc_stream_t stream);
+
 /* bf16 causal prefill: paged KV cache, and contiguous varlen K/V [total_seq, Hkv, 128] (row strides ldK / ldV
  * elements; every q token attends the keys of its request up to itself).
  * reference: attention_with_kvcache_prefill_bf16_async / attention_prefill_bf16_async (src/attention/prefill/prefill.h,
@@ -378,7 +389,7 @@ int64_t hpc_comm_region_bytes_left(const void* ptr);
  *   peer_signal_ptrs[p] rank p's signal pad of `signal_pad_words` zero-initialised uint32 (block b uses
  *   words [b * world_size, (b + 1) * world_size)).  The barriers pair block b of every rank, so the grid is a
  *   function of rank-invariant inputs only: hpc_fuse_allreduce_rmsnorm_high_throughput_grid(world_size,
- *   num_max_blocks, signal_pad_words) = min(max(num_max_blocks, 512), signal_pad_words / world_size); all
+ *   num_max_blocks, signal_pad_words) = min(max(num_max_blocks, 256), signal_pad_words / world_size); all
  *   ranks must pass the same num_max_blocks and pad size.  -2 when the pad cannot hold one block.
  *   hidden <= 16384, world_size <= 8.  (The reference supports H in {4096,5120,7168}.)
  * Low latency (Lamport, token t owned by rank t % world_size): data_buffer_ptrs_dev = device int64

@@ -177,15 +177,17 @@ def test_allreduce_rmsnorm_world1():
 @pytest.mark.gpu
 def test_allreduce_rmsnorm_world2_shared_gpu():
     """two ranks on the single GPU of the test box: exercises IPC handles, pointer tables, signal
-    barriers and the Lamport protocol across processes (the 8-GPU run is the driver's)."""
-    _spawn(2)
+    barriers and the Lamport protocol across processes (the 8-GPU run is the driver's).  Both ranks' grids
+    must be co-resident on the one GPU, so the high-throughput grid floor (one workgroup per CU) is lifted:
+    development key 11 = 1 -> grid = num_max_blocks like the reference."""
+    _spawn(2, tuning="11=1")
 
 
 @pytest.mark.gpu
 def test_allreduce_rmsnorm_world2_generic_peer_loop():
     """same protocol through the runtime-world-size kernel (world sizes other than 1/2/4/8 use it):
     development tuning key 9 = 1 selects it at world size 2."""
-    _spawn(2, tuning="9=1")
+    _spawn(2, tuning="9=1,11=1")
 
 
 @pytest.mark.gpu
@@ -270,6 +272,6 @@ def test_high_throughput_grid_is_rank_invariant():
     and is clamped to the pad (72 * CUs words from MulticastHandle; fewer CUs on a partitioned device)."""
     lib = ctypes.CDLL(str(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so"))
     f = lib.hpc_fuse_allreduce_rmsnorm_high_throughput_grid
-    assert f(8, 64, 72 * 256) == 512 and f(8, 2048, 72 * 256) == 2048
-    assert f(8, 64, 72 * 32) == 72 * 32 // 8  # CPX-sized pad: clamped, not overrun
+    assert f(8, 64, 72 * 256) == 256 and f(8, 2048, 72 * 256) == 2048
+    assert f(8, 64, 72 * 16) == 72 * 16 // 8  # small pad (partitioned device): clamped, not overrun
     assert f(2, 64, 1) < 0 and f(9, 64, 1024) < 0 and f(2, 0, 1024) < 0

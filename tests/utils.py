@@ -26,3 +26,26 @@ def allclose(ref_tensor, real_tensor, atol=1e-8, rtol=1e-5):
 
 def to_cpu(*ts):
     return [t.cpu() if t is not None else None for t in ts]
+
+
+def moe_allclose(ref, real, rtol=0.01, atol=0.01, max_literal_outliers=0.005, max_rel_rms=5e-3, max_abs_frac=0.02):
+    """Tolerance of the fused-MoE parity checks at hidden sizes beyond the reference test's (512).
+
+    The reference bar is rtol = atol = 0.01 at hidden 512 / ffn <= 512 (tests/test_fuse_moe_blockwise.py:268,350),
+    where outputs are O(1).  With the same generator at hidden 4096 / ffn 11008 every expert contribution is
+    O(10-30) and is rounded to bf16 (ulp 0.06-0.25) after each GEMM; a bf16 rounding of a gate_up element that
+    flips with the fp32 summation order can move one e4m3 code of the quantised activation (a 6 % step of that
+    element), so a small fraction of the outputs differs by a few bf16 ulps whatever the kernel does.  The bar:
+      * at least 1 - max_literal_outliers (99.5 %) of the elements meet the reference's literal (0.01, 0.01);
+      * the relative RMS error of every row is <= max_rel_rms;
+      * no element is off by more than max_abs_frac of the largest |ref| (a wrong expert / scale / row is O(1))."""
+    a, b = ref.float(), real.float()
+    err = (a - b).abs()
+    literal_miss = float((err > atol + rtol * a.abs()).float().mean())
+    rel_rms = float((err.pow(2).mean(-1).sqrt() / a.pow(2).mean(-1).sqrt().clamp_min(1e-3)).max())
+    worst = float(err.max() / a.abs().max().clamp_min(1e-3))
+    ok = literal_miss <= max_literal_outliers and rel_rms <= max_rel_rms and worst <= max_abs_frac
+    if not ok:
+        print(f"\nmoe_allclose FAILED: max abs err {float(err.max()):.4g} ({worst:.4g} of max |ref|), worst row relative "
+              f"rms {rel_rms:.4g}, fraction outside the literal (0.01, 0.01) bar {literal_miss:.5f}")
+    return ok

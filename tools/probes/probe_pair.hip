@@ -1,0 +1,110 @@
+// Access-pattern probe (development tool): fp8 NHD paged-KV streaming, bytes fetched per token row and
+// instruction.  K and V pools [npages][64 tokens][8 heads][128 B], pages in random order.  A wave-iteration
+// fetches 8 KB of K and 8 KB of V as 16-byte-per-lane loads whose lanes cover rows of W bytes
+// (W = 128: one head = today's kernel, 256: a head PAIR in one instruction, 512, 1024: whole token row);
+// 512 workgroups of 4 waves in every variant, same total bytes.  Reads only.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <algorithm>
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// W = bytes per row piece; V8 = 1: V fetched with 8-byte-per-lane loads (rows of W bytes by W/8 lanes)
+template <int W, int V8, int NT>
+__global__ __launch_bounds__(256, 2) void k(const char* __restrict__ kp, const char* __restrict__ vp,
+                                            const int* __restrict__ pages, int pages_per_req, int nreq, unsigned* out) {
+  constexpr int HEADS = W / 128;          // heads per workgroup
+  constexpr int GROUPS = 8 / HEADS;       // head groups
+  constexpr int TOK = 8192 / W;           // tokens per wave-iteration (8 KB of K)
+  constexpr int LPR = W / 16;             // lanes per row (16-byte loads)
+  constexpr int RPI = 64 / LPR;           // rows per instruction
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // workgroup -> (head group, request, split of the request's tokens): 512 workgroups always
+  const int hg = blockIdx.x % GROUPS, rest = blockIdx.x / GROUPS;
+  const int b = rest % nreq, split = rest / nreq;   // split in [0, HEADS)
+  const int tok_per_req = pages_per_req * 64;
+  const int tok0 = split * (tok_per_req / HEADS), tok1 = tok0 + tok_per_req / HEADS;
+  const int* pg = pages + (long)b * pages_per_req;
+  const int row = lane / LPR, col = lane % LPR;
+  unsigned acc = 0;
+  for (int t = tok0 + wave * TOK; t < tok1; t += 4 * TOK) {
+    u32x4 r[8];
+    u32x4 v16[V8 ? 1 : 8];
+    u32x2 v8[V8 ? 16 : 1];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int tok = t + i * RPI + row;
+      const long off = (long)pg[tok >> 6] * 65536 + (long)(tok & 63) * 1024 + hg * W + col * 16;
+      r[i] = NT ? __builtin_nontemporal_load((const u32x4*)(kp + off)) : *(const u32x4*)(kp + off);
+    }
+    if (V8) {
+      constexpr int LPR8 = W / 8, RPI8 = 64 / LPR8;
+      const int row8 = lane / LPR8, col8 = lane % LPR8;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int tok = t + i * RPI8 + row8;
+        const long off = (long)pg[tok >> 6] * 65536 + (long)(tok & 63) * 1024 + hg * W + col8 * 8;
+        v8[i] = NT ? __builtin_nontemporal_load((const u32x2*)(vp + off)) : *(const u32x2*)(vp + off);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int tok = t + i * RPI + row;
+        const long off = (long)pg[tok >> 6] * 65536 + (long)(tok & 63) * 1024 + hg * W + col * 16;
+        v16[i] = NT ? __builtin_nontemporal_load((const u32x4*)(vp + off)) : *(const u32x4*)(vp + off);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += r[i][0] ^ r[i][3];
+    if (V8) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc += v8[i][0] ^ v8[i][1];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc += v16[i][0] ^ v16[i][3];
+    }
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
+int main() {
+  const int nreq = 64, ppr = 128;  // 8192 tokens per request
+  const int npages = nreq * ppr + 100;
+  char *kp, *vp; int* pages; unsigned* out;
+  hipMalloc(&kp, (long)npages * 65536); hipMalloc(&vp, (long)npages * 65536);
+  hipMalloc(&pages, nreq * ppr * 4); hipMalloc(&out, 64);
+  hipMemset(kp, 1, (long)npages * 65536); hipMemset(vp, 2, (long)npages * 65536);
+  std::vector<int> perm(npages); for (int i = 0; i < npages; ++i) perm[i] = i;
+  srand(1); std::random_shuffle(perm.begin(), perm.end());
+  hipMemcpy(pages, perm.data(), nreq * ppr * 4, hipMemcpyHostToDevice);
+  const double bytes = (double)nreq * ppr * 65536 * 2;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto run = [&](const char* name, auto launch) {
+    for (int i = 0; i < 3; ++i) launch();
+    hipDeviceSynchronize();
+    float best = 1e9;
+    for (int rep = 0; rep < 3; ++rep) {
+      hipEventRecord(e0);
+      for (int i = 0; i < 10; ++i) launch();
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      best = ms < best ? ms : best;
+    }
+    printf("%-46s %8.1f us  %8.1f GB/s  %.3f of 8 TB/s\n", name, best * 100, bytes / (best / 10 * 1e-3) / 1e9,
+           bytes / (best / 10 * 1e-3) / 8e12);
+  };
+#define RUN(W, V8, NT, name) run(name, [&] { k<W, V8, NT><<<512, 256>>>(kp, vp, pages, ppr, nreq, out); })
+  RUN(128, 0, 1, "W=128 (1 head)  16B loads nt");
+  RUN(128, 1, 1, "W=128 (1 head)  V 8B loads nt  [today]");
+  RUN(256, 0, 1, "W=256 (pair)    16B loads nt");
+  RUN(256, 1, 1, "W=256 (pair)    V 8B loads nt");
+  RUN(512, 0, 1, "W=512 (4 heads) 16B loads nt");
+  RUN(1024, 0, 1, "W=1024 (8 heads) 16B loads nt");
+  RUN(128, 0, 0, "W=128 temporal");
+  RUN(256, 0, 0, "W=256 temporal");
+  RUN(1024, 0, 0, "W=1024 temporal");
+  RUN(128, 0, 1, "W=128 again");
+  return 0;
+}
