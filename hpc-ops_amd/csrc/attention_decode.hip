@@ -35,6 +35,7 @@
 #include "hpc_dev.h"
 #include "../../include/hpc_amd.h"
 #include "sched_task_info.h"
+#include "attention_decode_v2.h"
 
 namespace hpc {
 namespace decode {
@@ -691,15 +692,25 @@ inline Common fill_common(Args& a, void* y_ptr, void* workspace, const int* task
 }  // namespace decode
 }  // namespace hpc
 
-extern "C" int64_t hpc_attention_decode_workspace_bytes(int num_bins, int num_batch, int num_head_kv,
-                                                        int num_seq_q, int heads_per_group) {
-  if (num_bins <= 0 || num_batch <= 0 || num_head_kv <= 0 || num_seq_q <= 0 || heads_per_group <= 0)
-    return HPC_ERR_INVALID;
+namespace {
+int64_t v1_workspace_bytes(int num_bins, int num_batch, int num_head_kv, int num_seq_q, int heads_per_group) {
   const int64_t rows = (static_cast<int64_t>(num_seq_q) * heads_per_group + 15) / 16 * 16;
   const int64_t part_o = static_cast<int64_t>(num_bins) * 2 * rows * 128 * 4;
   const int64_t part_lse = static_cast<int64_t>(num_bins) * 2 * rows * 4;
   const int64_t first_bin = static_cast<int64_t>(num_batch) * num_head_kv * 4;
   return part_o + part_lse + ((first_bin + 15) / 16) * 16;
+}
+}  // namespace
+
+// Scratch of one decode call: the first-generation kernel's region (2 partial slots per bin, first-bin table)
+// followed by the second-generation FP8 / NHD kernel's (2 slots per workgroup x 2 heads, chunk table; its grid
+// never exceeds num_bins workgroups).
+extern "C" int64_t hpc_attention_decode_workspace_bytes(int num_bins, int num_batch, int num_head_kv,
+                                                        int num_seq_q, int heads_per_group) {
+  if (num_bins <= 0 || num_batch <= 0 || num_head_kv <= 0 || num_seq_q <= 0 || heads_per_group <= 0)
+    return HPC_ERR_INVALID;
+  return v1_workspace_bytes(num_bins, num_batch, num_head_kv, num_seq_q, heads_per_group) +
+         hpc::decode2::workspace_bytes(num_bins, num_batch, num_head_kv);
 }
 
 extern "C" int hpc_attention_decode_bf16_async(
@@ -723,8 +734,8 @@ extern "C" int hpc_attention_decode_bf16_async(
 
 extern "C" int hpc_attention_decode_fp8_async(
     void* y_ptr, void* workspace, const int* task_map_ptr, const void* q_ptr, const void* kcache_ptr,
-    const void* vcache_ptr, const int* block_ids_ptr, const float* qscale_ptr,
-    const void* kscale_ptr, const float* vscale_ptr, int quant_type, int num_bins, int num_batch,
+    const void* vcache_ptr, const int* block_ids_ptr, const int* num_seq_kvcache_ptr, const float* qscale_ptr,
+    const void* kscale_ptr, const float* vscale_ptr, int new_kv_included, int quant_type, int num_bins, int num_batch,
     int num_seq_q, int num_head_q, int num_head_kv, int num_dim_qk, int num_dim_v, int block_size,
     int num_seq_max_blocks, int qscale_pad_stride, int ldY, int ldQ, int64_t kcache_block_stride,
     int64_t kcache_token_stride, int64_t kcache_head_stride, int64_t vcache_block_stride,
@@ -750,6 +761,55 @@ extern "C" int hpc_attention_decode_fp8_async(
   a.ks_block_stride = kscale_block_stride;
   a.ks_row_stride = kscale_row_stride;
   a.ks_head_stride = kscale_head_stride;
+  // second generation (head pairs per load, deep prefetch, in-kernel plan) when the layout allows it
+  {
+    hpc::decode2::Args b;
+    b.q = q_ptr;
+    b.kcache = kcache_ptr;
+    b.vcache = vcache_ptr;
+    b.block_ids = block_ids_ptr;
+    b.lens = num_seq_kvcache_ptr;
+    b.y = static_cast<uint16_t*>(y_ptr);
+    b.part_o = b.part_lse = nullptr;
+    b.table = nullptr;
+    b.qscale = qscale_ptr;
+    b.kscale = static_cast<const float*>(kscale_ptr);
+    b.vscale = vscale_ptr;
+    b.num_batch = num_batch;
+    b.num_seq_q = num_seq_q;
+    b.num_head_kv = num_head_kv;
+    b.g_shift = a.g_shift;
+    b.page_shift = a.page_shift;
+    b.max_blocks = num_seq_max_blocks;
+    b.ldq = ldQ;
+    b.ldy = ldY;
+    b.qscale_stride = qscale_pad_stride;
+    b.new_kv_included = new_kv_included;
+    b.dev_nomem = hpc_dev_tuning_get(15);
+    b.k_block_stride = kcache_block_stride;
+    b.k_token_stride = kcache_token_stride;
+    b.v_block_stride = vcache_block_stride;
+    b.v_token_stride = vcache_token_stride;
+    b.ks_block_stride = kscale_block_stride;
+    b.ks_row_stride = kscale_row_stride;
+    b.ks_head_stride = kscale_head_stride;
+    b.scale_log2 = a.scale_log2;
+    const int gen = hpc_dev_tuning_get(12);  // 0 auto, 1 first generation only
+    if (gen != 1 && quant_type == 1 &&
+        hpc::decode2::eligible(b, num_head_q, block_size, kcache_head_stride, vcache_head_stride)) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess) return HPC_ERR_LAUNCH;
+      int num_wg = 2 * hpc_get_cu_count(dev);  // two 4-wave workgroups per CU (<= 256 registers, 65 KB of LDS each)
+      const int wg_dev = hpc_dev_tuning_get(14);
+      if (wg_dev > 0) num_wg = wg_dev;
+      if (num_wg > num_bins) num_wg = num_bins;  // the scratch is sized for num_bins workgroups
+      num_wg -= num_wg % (num_head_kv / 2);      // workgroup = (token range, head pair)
+      if (num_wg <= 0) return HPC_ERR_LAUNCH;
+      char* ws2 = static_cast<char*>(workspace) +
+                  v1_workspace_bytes(num_bins, num_batch, num_head_kv, num_seq_q, num_head_q / num_head_kv);
+      return hpc::decode2::launch(b, ws2, num_wg, quant_type, stream);
+    }
+  }
   if (quant_type == 1) return launch<true, 1>(a, num_bins, c.num_nb, stream);
   return launch<true, 0>(a, num_bins, c.num_nb, stream);
 }

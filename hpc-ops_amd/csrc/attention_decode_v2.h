@@ -1,0 +1,38 @@
+// Interface between the decode-attention C entry (attention_decode.hip) and the second-generation
+// FP8 / NHD kernel (attention_decode_v2.hip).  Internal header.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hpc {
+namespace decode2 {
+
+struct Args {
+  const void* q;
+  const void* kcache;
+  const void* vcache;
+  const int* block_ids;
+  const int* lens;       // num_seq_kvcache [B]
+  uint16_t* y;
+  float* part_o;         // [workgroups][2][2 heads][16][128]
+  float* part_lse;       // [workgroups][2][2 heads][16]
+  int* table;            // [pairs * B][2]: chunks of the request, first workgroup
+  const float* qscale;   // [B * Sq, qscale_stride]
+  const float* kscale;   // [1] or the K-scale tail rows of the cache
+  const float* vscale;   // [1] or [Hkv]
+  int num_batch, num_seq_q, num_head_kv, g_shift, page_shift, max_blocks;
+  int ldq, ldy, qscale_stride, new_kv_included;
+  int dev_nomem;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing; results are wrong)
+  long k_block_stride, k_token_stride;  // bytes
+  long v_block_stride, v_token_stride;
+  long ks_block_stride, ks_row_stride, ks_head_stride;  // bytes
+  float scale_log2;
+};
+
+int64_t workspace_bytes(int num_wg, int num_batch, int num_head_kv);
+// NHD pages with adjacent heads 128 B apart, an even head count, <= 16 q rows per kv head, <= 1024 requests
+bool eligible(const Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride);
+int launch(Args a, void* workspace, int num_wg, int quant_type, hipStream_t stream);
+
+}  // namespace decode2
+}  // namespace hpc

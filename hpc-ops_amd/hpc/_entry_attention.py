@@ -195,6 +195,7 @@ def _attention_decode_fp8_entry(q, kcache, vcache, block_ids, num_seq_kvcache, q
                "qscale / vscale must be float32")
     _C.require(quant_type in (0, 1), "quant_type must be QPERTOKEN_PERHEAD_KPERTOKEN_PERHEAD_VPERHEAD "
                "or QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR")
+    _C.require(num_seq_kvcache.is_cuda, "num_seq_kvcache tensor must be cuda")
     block_size = kcache.size(1)
     if quant_type == 0:
         _C.require(block_size in (32, 64), "kvcache paged blocksize must be 32 or 64.")
@@ -218,8 +219,9 @@ def _attention_decode_fp8_entry(q, kcache, vcache, block_ids, num_seq_kvcache, q
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
     rc = _C.lib.hpc_attention_decode_fp8_async(
         _C.ptr(y), _C.ptr(ws), ctypes.cast(task_map.data_ptr(), _INT_P), _C.ptr(q), _C.ptr(kcache),
-        _C.ptr(vcache), ctypes.cast(block_ids.data_ptr(), _INT_P), _C.ptr(qscale), _C.ptr(kscale),
-        _C.ptr(vscale), int(quant_type), bins, num_batch, num_seq_q, num_head_q, num_head_kv,
+        _C.ptr(vcache), ctypes.cast(block_ids.data_ptr(), _INT_P),
+        ctypes.cast(num_seq_kvcache.data_ptr(), _INT_P), _C.ptr(qscale), _C.ptr(kscale),
+        _C.ptr(vscale), int(bool(new_kv_included)), int(quant_type), bins, num_batch, num_seq_q, num_head_q, num_head_kv,
         q.size(2), vcache.size(3), block_size, block_ids.size(1), qscale.stride(0), y.stride(0),
         q.stride(0), kcache.stride(0), kcache.stride(1), kcache.stride(2), vcache.stride(0),
         vcache.stride(1), vcache.stride(2), ks[0], ks[1], ks[2], _C.stream_of(q),

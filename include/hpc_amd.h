@@ -104,12 +104,18 @@ int hpc_attention_decode_bf16_async(void* y_ptr, void* workspace, const int* tas
  * the fp32 scales of tokens 32r..32r+31 as 128 raw bytes; byte strides given explicitly - the
  * reference reads them through a TMA view, sm90/dynamic/...qkpertoken..._dynamic.cu:84-91),
  * vscale f32[Hkv].  Numerics: P~ = e4m3(256 * 2^(s - running max)), O = sum(P~ V)/sum(p) * vscale/256.
- * num_seq_q <= 4.  block_size 16/32/64 for quant_type 1, 32/64 for quant_type 0. */
+ * num_seq_q <= 4.  block_size 16/32/64 for quant_type 1, 32/64 for quant_type 0.
+ * num_seq_kvcache_ptr (device int32 [num_batch]) / new_kv_included as in the reference launcher
+ * (decode.h:27-35): with them, NHD pages (adjacent kv heads 128 bytes apart), an even head count and
+ * <= 16 q rows per kv head take the second-generation kernel (attention_decode_v2.hip: two heads per load,
+ * deep prefetch, the schedule planned in-kernel from the lengths in the closed form of the scheduler above);
+ * num_seq_kvcache_ptr may be NULL, then the task map drives the first-generation kernel as for bf16. */
 int hpc_attention_decode_fp8_async(void* y_ptr, void* workspace, const int* task_map_ptr,
                                    const void* q_ptr, const void* kcache_ptr,
                                    const void* vcache_ptr, const int* block_ids_ptr,
-                                   const float* qscale_ptr, const void* kscale_ptr,
-                                   const float* vscale_ptr, int quant_type, int num_bins,
+                                   const int* num_seq_kvcache_ptr, const float* qscale_ptr,
+                                   const void* kscale_ptr, const float* vscale_ptr,
+                                   int new_kv_included, int quant_type, int num_bins,
                                    int num_batch, int num_seq_q, int num_head_q, int num_head_kv,
                                    int num_dim_qk, int num_dim_v, int block_size,
                                    int num_seq_max_blocks, int qscale_pad_stride, int ldY, int ldQ,

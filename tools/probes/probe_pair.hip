@@ -69,6 +69,59 @@ __global__ __launch_bounds__(256, 2) void k(const char* __restrict__ kp, const c
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+
+// v2-like residency: 256 workgroups x 4 waves (one per SIMD), TWO 16 KB stages per wave in flight
+// (the next stage is requested before the current one is consumed).  W = 256 only.
+template <int NT>
+__global__ __launch_bounds__(256, 1) void k2(const char* __restrict__ kp, const char* __restrict__ vp,
+                                             const int* __restrict__ pages, int pages_per_req, int nreq, unsigned* out,
+                                             int spin) {
+  constexpr int W = 256, GROUPS = 4, TOK = 32, LPR = 16, RPI = 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // 256 workgroups: (head group, request) with the request's tokens in one piece
+  const int hg = blockIdx.x % GROUPS, b = blockIdx.x / GROUPS;
+  const int tok1 = pages_per_req * 64;
+  const int* pg = pages + (long)b * pages_per_req;
+  const int row = lane / LPR, col = lane % LPR;
+  const int row8 = lane / 32, col8 = lane % 32;
+  unsigned acc = 0;
+  u32x4 r[2][8];
+  u32x2 v8[2][16];
+  auto load = [&](int st, int t) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int tok = t + i * RPI + row;
+      const long off = (long)pg[tok >> 6] * 65536 + (long)(tok & 63) * 1024 + hg * W + col * 16;
+      r[st][i] = NT ? __builtin_nontemporal_load((const u32x4*)(kp + off)) : *(const u32x4*)(kp + off);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int tok = t + i * 2 + row8;
+      const long off = (long)pg[tok >> 6] * 65536 + (long)(tok & 63) * 1024 + hg * W + col8 * 8;
+      v8[st][i] = NT ? __builtin_nontemporal_load((const u32x2*)(vp + off)) : *(const u32x2*)(vp + off);
+    }
+  };
+  auto consume = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += r[st][i][0] ^ r[st][i][3];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += v8[st][i][0] ^ v8[st][i][1];
+    for (int i = 0; i < spin; ++i) acc = acc * 1664525u + 1013904223u;  // stand-in for the per-stage compute
+  };
+  int t = wave * TOK;
+  load(0, t);
+  if (t + 4 * TOK < tok1) load(1, t + 4 * TOK);
+  for (; t < tok1; t += 8 * TOK) {
+    consume(0);
+    if (t + 8 * TOK < tok1) load(0, t + 8 * TOK);
+    if (t + 4 * TOK < tok1) {
+      consume(1);
+      if (t + 12 * TOK < tok1) load(1, t + 12 * TOK);
+    }
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
 int main() {
   const int nreq = 64, ppr = 128;  // 8192 tokens per request
   const int npages = nreq * ppr + 100;
@@ -106,5 +159,9 @@ int main() {
   RUN(256, 0, 0, "W=256 temporal");
   RUN(1024, 0, 0, "W=1024 temporal");
   RUN(128, 0, 1, "W=128 again");
+  run("k2: 256 WG x 4 waves, 2 stages in flight, W=256", [&] { k2<1><<<256, 256>>>(kp, vp, pages, ppr, nreq, out, 0); });
+  run("k2 + 200 dependent ops per stage", [&] { k2<1><<<256, 256>>>(kp, vp, pages, ppr, nreq, out, 200); });
+  run("k2 + 400 dependent ops per stage", [&] { k2<1><<<256, 256>>>(kp, vp, pages, ppr, nreq, out, 400); });
+  run("k2 + 800 dependent ops per stage", [&] { k2<1><<<256, 256>>>(kp, vp, pages, ppr, nreq, out, 800); });
   return 0;
 }

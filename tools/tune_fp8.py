@@ -1,40 +1,33 @@
-"""Development tool: FP8 decode timing, uniform vs mixed lengths, NHD vs HND pages."""
+"""Development tool: FP8 decode timing (uniform 8k / the C3 mix; NHD pages), sweeping development tuning keys.
+usage: python tools/tune_fp8.py ["k=v,k=v" ...]   each argument is one configuration of tuning registers"""
 import math, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT / "hpc-ops_amd")); sys.path.insert(0, str(ROOT))
 import torch, bench, hpc
+from hpc import _C
 dev = torch.device("cuda", 0)
-B, Hkv, Hq, D, P = 64, 8, 64, 128, 64
-def run(lens_c, layout, minlen, quant=1):
-    nbl = (lens_c + P - 1) // P
-    nblk = int(int(nbl.sum()) * 1.2) + B + 8
-    q8 = torch.randn(B, Hq, D, device=dev).to(torch.float8_e4m3fn)
-    qs = torch.rand(B, Hq, device=dev) * 0.01 + 0.005
-    if layout == "NHD":
-        k8 = torch.randn(nblk, P, Hkv, D, device=dev).to(torch.float8_e4m3fn)
-        v8 = torch.randn(nblk, P, Hkv, D, device=dev).to(torch.float8_e4m3fn)
-    else:
-        k8 = torch.randn(nblk, Hkv, P, D, device=dev).to(torch.float8_e4m3fn).permute(0, 2, 1, 3)
-        v8 = torch.randn(nblk, Hkv, P, D, device=dev).to(torch.float8_e4m3fn).permute(0, 2, 1, 3)
-    bid = torch.zeros(B, int(nbl.max()), dtype=torch.int32, device=dev)
-    perm = torch.randperm(nblk, device=dev).to(torch.int32)
-    off = 0
-    for i, n in enumerate(nbl.tolist()):
-        bid[i, :n] = perm[off:off + n]; off += n
-    lens = lens_c.to(dev)
-    ks = torch.tensor([0.02], device=dev); vs = torch.tensor([0.03], device=dev)
-    tm = hpc.get_attention_decode_task_workspace(B, int(lens_c.max()), Hkv, minlen)
-    hpc.assign_attention_decode_task(lens, tm, Hkv, 1, True, minlen)
-    o = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=dev)
-    us = bench.timed(lambda: hpc.attention_decode_fp8(q8, k8, v8, bid, lens, qs, ks, vs, 0, True,
-                     hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, True, tm, None, o))
-    kvb = int(lens_c.sum()) * Hkv * 256
+B, D, P = 64, 128, 64
+def run(lens_c, heads=(8, 64), graph=True):
+    w = dict(bench.C3, num_head_kv=heads[0], num_head_q=heads[1])
+    inp = bench.c3_inputs(dev, w, lens=lens_c)
+    tm = hpc.get_attention_decode_task_workspace(B, int(lens_c.max()), heads[0], 64)
+    hpc.assign_attention_decode_task(inp["kv_lens"], tm, heads[0], 1, True, 64)
+    o = torch.empty(B, heads[1], D, dtype=torch.bfloat16, device=dev)
+    us = bench.timed(lambda: hpc.attention_decode_fp8(inp["q"], inp["k_cache"], inp["v_cache"], inp["block_ids"], inp["kv_lens"],
+                     inp["q_scale"], inp["k_scale"], inp["v_scale"], 0, True,
+                     hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, True, tm, None, o), graph=graph, iters=40)
+    kvb = int(lens_c.sum()) * heads[0] * 256
     return us, kvb / us / 1e3
-g = torch.Generator().manual_seed(41)
-mixed = torch.exp(torch.rand(B, generator=g) * (math.log(32768) - math.log(128)) + math.log(128)).to(torch.int32)
-for name, lens in (("uniform8k", torch.full((B,), 8192, dtype=torch.int32)), ("mixed", mixed)):
-    for layout in ("NHD", "HND"):
-        for minlen in (64, 512):
-            us, gb = run(lens, layout, minlen)
-            print(f"fp8 {name} {layout} minlen{minlen}: {us:8.1f} us {gb:8.1f} GB/s", flush=True)
+mixed = bench.c3_lens()
+cases = (("uniform8k", torch.full((B,), 8192, dtype=torch.int32)), ("mixed", mixed),
+         ("skewed_mix", torch.tensor([128] * 32 + [4096] * 32, dtype=torch.int32)),
+         ("uniform512", torch.full((B,), 512, dtype=torch.int32)))
+configs = sys.argv[1:] or ["12=1", ""]
+for cfg in configs:
+    pairs = [tuple(int(x) for x in kv.split("=")) for kv in cfg.split(",") if kv]
+    for k, v in pairs: _C.lib.hpc_dev_tuning_set(k, v)
+    for name, lens in cases:
+        us, gb = run(lens)
+        print(f"[{cfg or 'default':>14}] fp8 {name:<11} 8/64: {us:8.1f} us {gb:8.1f} GB/s {gb/8000:.3f}", flush=True)
+    for k, v in pairs: _C.lib.hpc_dev_tuning_set(k, 0)
