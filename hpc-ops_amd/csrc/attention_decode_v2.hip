@@ -182,20 +182,27 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   const uint8_t* qbase = static_cast<const uint8_t*>(a.q);
   const uint8_t* kbase = static_cast<const uint8_t*>(a.kcache);
   const uint8_t* vbase = static_cast<const uint8_t*>(a.vcache);
-  auto ltot_of = [&](int b) { const int l = lens[b] + add_new; return l > 0 ? l : 0; };
-  auto tiles_of = [&](int b) { return (ltot_of(b) + 63) >> 6; };
+  auto ltot_of = [&](int b) __attribute__((always_inline)) { const int l = lens[b] + add_new; return l > 0 ? l : 0; };
+  auto tiles_of = [&](int b) __attribute__((always_inline)) { return (ltot_of(b) + 63) >> 6; };
 
-  // ---- plan: tiles per head pair, this workgroup's range, its first (pair, request, tile) ---------
-  // lane l sums the tiles of requests [l * kpl, (l + 1) * kpl); an inclusive wave scan gives the
-  // prefix at every chunk start; the request that holds tile u is found with one ballot + a walk
+  // ---- plan: this workgroup's range, its first (request, tile) ------------------------------------------------
+  // Requests are laid end to end on a COST axis: tiles_b tiles of 64 tokens preceded by kOvh units of overhead
+  // per non-empty request (a task boundary costs a merge through LDS, two barriers, idle pipeline slots and up to
+  // three phantom WIs: about kOvh tiles' worth of time), so a range that holds many short requests gets fewer
+  // tiles.  Range r owns the cost positions [r * per, (r + 1) * per); tile t of request b sits at position
+  // cost_start(b) + kOvh + t.  lane l sums the costs of requests [l * kpl, (l + 1) * kpl); an inclusive wave scan
+  // gives the prefix at every chunk start; the request that holds a position is found with one ballot + a walk
   // over at most kpl requests.
+  constexpr int kOvh = 2;  // measured: 1..8 within noise on the mixed workload, 0 (no balancing) 3 % slower
+  auto cost_of = [&](int b) __attribute__((always_inline)) { const int t = tiles_of(b); return t > 0 ? t + kOvh : 0; };
   const int kpl = (B + 63) >> 6;
   int chunk_sum = 0;
   for (int i = 0; i < kpl; ++i) {
     const int b = lane * kpl + i;
     if (b < B) {
       const int l = a.lens[b] + add_new;
-      chunk_sum += ((l > 0 ? l : 0) + 63) >> 6;
+      const int t = ((l > 0 ? l : 0) + 63) >> 6;
+      chunk_sum += t > 0 ? t + kOvh : 0;
     }
   }
   int incl = chunk_sum;
@@ -205,14 +212,12 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     if (lane >= o) incl += t;
   }
   const int chunk_start = incl - chunk_sum;
-  const int Th = sgpr(__shfl(incl, 63, 64));       // tiles per head (pair)
+  const int Th = sgpr(__shfl(incl, 63, 64));       // total cost per head pair
   const int npair = a.num_head_kv / kHP;
   if (Th == 0) return;
   // Workgroup -> (range r, pair p) with the pair index MINOR: workgroups r * npair .. r * npair + npair - 1 stream
-  // the npair 256-byte slices of the SAME token rows at the same time (identical work, started together), so a
-  // DRAM row that was opened for one pair's slice is hit again by the others while it is open - the probe's
-  // 0.82-0.84 was measured with exactly this block order; with the pair index major the same kernel ran at 0.68.
-  // The grid is a multiple of npair (launcher); range r owns tiles [r * per, (r + 1) * per) of the per-pair axis.
+  // the npair 256-byte slices of the same token rows at about the same time (identical work, started together).
+  // The grid is a multiple of npair (launcher).
   const int nrange = nwg / npair;
   const int rng = wg / npair;
   const int per = (Th + nrange - 1) / nrange;
@@ -221,78 +226,82 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   if (g_begin >= g_end) return;
 
   // ---- load cursor (SGPRs) ---------------------------------------------------------------------------
-  int c_p, c_b, c_t0, c_n, c_wi, c_nwi, c_ltot, c_tiles, c_valid = 1;
-  long c_g, c_req0;
-  auto open_task = [&]() {  // c_p, c_b, c_t0, c_g, c_req0 set: derive the rest
-    c_ltot = ltot_of(c_b);
-    c_tiles = (c_ltot + 63) >> 6;
-    const long room = g_end - c_g;
-    c_n = c_tiles - c_t0 < room ? c_tiles - c_t0 : static_cast<int>(room);
-    const int tok_end = (c_t0 + c_n) * 64 < c_ltot ? (c_t0 + c_n) * 64 : c_ltot;
-    c_nwi = (tok_end - c_t0 * 64 + kTok - 1) / kTok;
-    c_wi = wave;
-  };
-  {
-    c_p = wg % npair;
-    const int u = static_cast<int>(g_begin);
-    const uint64_t le = __ballot(chunk_start <= u);
-    const int cl = 63 - __builtin_clzll(le);  // last lane whose chunk starts at or before u
+  // The range is converted to real tiles once: it starts at tile c_rt0 of request c_b and ends in front of tile
+  // e_rt of request e_b (a boundary inside a request's overhead units is a boundary at that request's first tile).
+  auto locate = [&](int x, int& b_out, int& rt_out, int& cc_out) __attribute__((always_inline)) {
+    if (x >= Th) {
+      b_out = B;
+      rt_out = 0;
+      cc_out = Th;
+      return;
+    }
+    const uint64_t le = __ballot(chunk_start <= x);
+    const int cl = 63 - __builtin_clzll(le);  // last lane whose chunk starts at or before x
     int pos = sgpr(__shfl(chunk_start, cl, 64));
     int b = cl * kpl;
-    while (true) {  // tile u lies in this chunk (empty requests are skipped)
-      const int t = tiles_of(b);
-      if (u < pos + t) break;
+    while (true) {  // position x lies in this chunk (empty requests cost nothing and are stepped over)
+      const int t = cost_of(b);
+      if (x < pos + t) break;
       pos += t;
       ++b;
     }
-    c_b = b;
-    c_t0 = u - pos;
-    c_g = g_begin;
-    c_req0 = g_begin - c_t0;
-    open_task();
-  }
-  auto advance = [&]() {  // to this wave's next WI (every wave visits every task at least once)
+    b_out = b;
+    rt_out = x - pos > kOvh ? x - pos - kOvh : 0;
+    cc_out = pos;
+  };
+  int c_p = wg % npair, c_b, c_rt0, c_cc, e_b, e_rt, e_cc;
+  locate(static_cast<int>(g_begin), c_b, c_rt0, c_cc);
+  locate(static_cast<int>(g_end), e_b, e_rt, e_cc);
+  if (c_b == e_b && c_rt0 >= e_rt) return;  // the whole range lies inside one request's overhead units
+  int c_wi, c_nwi, c_ltot, c_tiles, c_tok_end, c_valid = 1;
+  auto open_task = [&]() __attribute__((always_inline)) {  // c_b, c_rt0, c_cc set: derive the rest
+    c_ltot = ltot_of(c_b);
+    c_tiles = (c_ltot + 63) >> 6;
+    const int end_t = c_b == e_b ? e_rt : c_tiles;
+    c_tok_end = end_t * 64 < c_ltot ? end_t * 64 : c_ltot;
+    c_nwi = (c_tok_end - c_rt0 * 64 + kTok - 1) / kTok;
+    c_wi = wave;
+  };
+  open_task();
+  auto advance = [&]() __attribute__((always_inline)) {  // to this wave's next WI (every wave visits every task at least once)
     c_wi += kWaves;
     const int lim = c_nwi > wave + 1 ? c_nwi : wave + 1;
     if (c_wi < lim) return;
-    c_g += c_n;
-    if (c_g >= g_end) {
+    if (c_b == e_b) {  // that was the range's last task
       c_valid = 0;
       return;
     }
-    // a task ends at the end of its request or at the end of the range: here the request ended
-    // (c_g < g_end <= Th: another non-empty request follows)
+    c_cc += c_tiles + kOvh;
     do {
       ++c_b;
-    } while (tiles_of(c_b) == 0);
-    c_t0 = 0;
-    c_req0 = c_g;
+    } while (c_b < e_b && tiles_of(c_b) == 0);
+    if (c_b == e_b && e_rt == 0) {
+      c_valid = 0;
+      return;
+    }
+    c_rt0 = 0;
     open_task();
   };
-  auto snapshot = [&](Stage& st) {
+  auto snapshot = [&](Stage& st) __attribute__((always_inline)) {
     const int lim = c_nwi > wave + 1 ? c_nwi : wave + 1;
     st.flags = c_valid | ((c_wi + kWaves >= lim) ? 2 : 0) | (c_wi == wave ? 4 : 0);
     st.bp = c_b | (c_p << 16);
-    st.tok0 = c_t0 * 64 + c_wi * kTok;
-    const int te = (c_t0 + c_n) * 64;
-    st.tok_end = te < c_ltot ? te : c_ltot;
+    st.tok0 = c_rt0 * 64 + c_wi * kTok;
+    st.tok_end = c_tok_end;
     st.ltot = c_ltot;
-    st.req0 = static_cast<int>(c_req0);
+    st.req0 = c_cc;
     st.tiles = c_tiles;
   };
 
   // ---- the registers the next WI lands in ------------------------------------------------------------------------
   u32x4 kr[2][4];    // [16-token block][4 token rows x 256 B per instruction]
   u32x4 vr[2][4];
-  u32x4 qs[kHP][2];  // Q fragments (real only for a wave's first WI of a task)
   uint32_t qsc[kHP];
   Stage nx;          // descriptor of the WI those registers belong to
   const int kts = static_cast<int>(a.k_token_stride), vts = static_cast<int>(a.v_token_stride);
   const int k_voff = (lane >> 4) * kts + (lane & 15) * 16;  // row lane/16, 16-byte chunk lane%16 of the 256 B
   const int v_voff = (lane >> 4) * vts + (lane & 15) * 16;
   const int k_voff16 = k_voff + 16 * kts, v_voff16 = v_voff + 16 * vts;  // block 1 of a WI inside the same page
-  const int q_voff = (n >> a.g_shift) * a.ldq + (n & (G - 1)) * 128 + g * 16;
-  const int s_voff = ((n >> a.g_shift) * a.qscale_stride + (n & (G - 1))) * 4;
   const int ks1 = sgpr(4 * kts), ks2 = sgpr(8 * kts), ks3 = sgpr(12 * kts);
   const int vs1 = sgpr(4 * vts), vs2 = sgpr(8 * vts), vs3 = sgpr(12 * vts);
   // SGPR economy matters (a wave issues at most one instruction every 4 cycles, scalar ones included): with 32- or
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   // lookup in front of every batch of loads was ~0.5 us of exposed latency per WI.
   Stage nn;
   int nn_pid0 = 0, nn_pid1 = 0;
-  auto prefetch_pages = [&]() {
+  auto prefetch_pages = [&]() __attribute__((always_inline)) {
     snapshot(nn);
     const bool valid = nn.flags & 1;
     const cint_ptr bid_row = as_const(a.block_ids) + static_cast<long>(nn.bp & 0xffff) * a.max_blocks;
@@ -314,23 +323,12 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     if (c_valid) advance();
   };
   const bool mem = a.dev_nomem == 0;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing)
-  auto issue = [&]() {
+  auto issue = [&]() __attribute__((always_inline)) {
     nx = nn;
     const Stage& d = nx;
     const int db = d.bp & 0xffff, dp = d.bp >> 16;
     const bool valid = d.flags & 1;
     const int pid0 = sgpr(nn_pid0), pid1 = sgpr(nn_pid1);
-    // Q (real only for a wave's first WI of a task; these loads are the OLDEST of the batch, so leaving them out
-    // changes no count a K or V wait relies on): one descriptor for the pair - the 2 G q heads of two adjacent kv
-    // heads are contiguous - bounded to the request's Sq rows: lanes of the rows past rows_valid read zeros
-    if (valid && (d.flags & 4)) {
-      const i32x4 rq = srd(qbase + static_cast<long>(db) * Sq * a.ldq + ((dp * kHP) << a.g_shift) * 128,
-                           static_cast<unsigned>((Sq - 1) * a.ldq + kHP * G * 128));
-      const i32x4 rsq = srd(a.qscale + static_cast<long>(db) * Sq * a.qscale_stride + ((dp * kHP) << a.g_shift),
-                            static_cast<unsigned>(((Sq - 1) * a.qscale_stride + kHP * G) * 4));
-      ld_q3(qs[0], qsc[0], q_voff, rq, s_voff, rsq);
-      ld_q3(qs[1], qsc[1], q_voff + G * 128, rq, s_voff + G * 4, rsq);
-    }
     const int pair_off = dp * kRow;
     const bool on0 = valid && d.tok0 < d.tok_end, on1 = valid && d.tok0 + 16 < d.tok_end;
     const int tk0 = on0 ? d.tok0 : 0, tk1 = on1 ? d.tok0 + 16 : 0;
@@ -367,14 +365,14 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   float* my_so = reinterpret_cast<float*>(my_lds);
   const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8*)my_lds));  // LDS byte address of the stage
   // writes: lane (r4 = lane / 16, c = lane % 16) of instruction (tb, q) holds chunk c of token tb * 16 + q * 4 + r4
-  const uint32_t w0 = lds0 + (lane >> 4) * kRow + (((lane & 15) ^ (lane >> 4)) * 16);
+  const uint32_t w0_inv = lds0 + (lane >> 4) * kRow + (((lane & 15) ^ (lane >> 4)) * 16);
   // K reads: lane (n, g), token tb * 16 + n, chunk hh * 8 + g + 4 c
-  const uint32_t r0 = lds0 + n * kRow + ((g ^ n) * 16);
+  const uint32_t r0_inv = lds0 + n * kRow + ((g ^ n) * 16);
   // V transpose reads: lane (i = lane % 16, g): row j = i / 2 of the 8 x 16 tile is token 16 (j / 4) + 4 g + (j % 4)
   // (the k-slot order of P: slot hb * 4 + r <-> token 16 hb + 4 g + r), 8-byte half i % 2, chunk hh * 8 + jj
   const int tj = (lane & 15) >> 1;
   const int ttok = 16 * (tj >> 2) + 4 * g + (tj & 3);
-  const uint32_t t0 = lds0 + kVOff + ttok * kRow + ((((ttok & 15) ^ ((ttok >> 4) << 3))) * 16) + (lane & 1) * 8;
+  const uint32_t t0_inv = lds0 + kVOff + ttok * kRow + ((((ttok & 15) ^ ((ttok >> 4) << 3))) * 16) + (lane & 1) * 8;
 
   // ---- per-task state ----------------------------------------------------------------------------------------
   u32x4 qf[kHP][2];      // fp8 Q fragments: 16-byte chunks g and g + 4 of row n
@@ -382,7 +380,22 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   float out_scale[kHP];  // vscale (l_run carries the factor 256 of P~)
   f32x4 o[kHP][8];       // O^T: o[hh][jj][r] = dim jj * 16 + 4 g + r of q row n
   float m_run[kHP], l_run[kHP];
-  auto reset_state = [&]() {
+  // Q fragments + q scales of the task (b, p), straight into qf / qsc.  Called when the PREVIOUS task has been
+  // finished (qf is dead then) for the task of the WI that is already in flight, so these 6 loads are the
+  // youngest in the queue: the K / V waits of that WI only get more conservative, and its last wait (vmcnt(0))
+  // covers them.  One descriptor for the pair - the 2 G q heads of two adjacent kv heads are contiguous - bounded to
+  // the request's Sq rows: lanes of the rows past rows_valid read zeros.
+  auto load_q = [&](int db, int dp) __attribute__((always_inline)) {
+    const int q_voff = (n >> a.g_shift) * a.ldq + (n & (G - 1)) * 128 + g * 16;
+    const int s_voff = ((n >> a.g_shift) * a.qscale_stride + (n & (G - 1))) * 4;
+    const i32x4 rq = srd(qbase + static_cast<long>(db) * Sq * a.ldq + ((dp * kHP) << a.g_shift) * 128,
+                         static_cast<unsigned>((Sq - 1) * a.ldq + kHP * G * 128));
+    const i32x4 rsq = srd(a.qscale + static_cast<long>(db) * Sq * a.qscale_stride + ((dp * kHP) << a.g_shift),
+                          static_cast<unsigned>(((Sq - 1) * a.qscale_stride + kHP * G) * 4));
+    ld_q3(qf[0], qsc[0], q_voff, rq, s_voff, rsq);
+    ld_q3(qf[1], qsc[1], q_voff + G * 128, rq, s_voff + G * 4, rsq);
+  };
+  auto reset_state = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int hh = 0; hh < kHP; ++hh) {
 #pragma unroll
@@ -393,10 +406,11 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   };
 
   // ---- end of a task: merge the 4 waves and emit (the stage regions are idle: they double as s_o) ---------------
-  auto finish_task = [&](const Stage& d) {
+  auto finish_task = [&](const Stage& d) __attribute__((always_inline)) {
     const int db = d.bp & 0xffff, dp = d.bp >> 16;
-    const int first_rng = static_cast<int>(d.req0 / per);
-    const int nchunks = static_cast<int>((d.req0 + d.tiles - 1) / per) - first_rng + 1;
+    // tile t of the request sits at cost position req0 + kOvh + t
+    const int first_rng = (d.req0 + kOvh) / per;
+    const int nchunks = (d.req0 + kOvh + d.tiles - 1) / per - first_rng + 1;
     const int ichunk = rng - first_rng;
 #pragma unroll
     for (int hh = 0; hh < kHP; ++hh) {
@@ -467,6 +481,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     }
     __syncthreads();
     reset_state();
+    if (nx.flags & 1) load_q(nx.bp & 0xffff, nx.bp >> 16);  // nx: the WI in flight = the next task's first WI
   };
 
   // ---- prologue ------------------------------------------------------------------------------------------------
@@ -475,30 +490,21 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   for (int hh = 0; hh < kHP; ++hh) {
     qf[hh][0] = qf[hh][1] = u32x4{0u, 0u, 0u, 0u};
     row_scale[hh] = out_scale[hh] = 0.f;
-    qs[hh][0] = qs[hh][1] = u32x4{0u, 0u, 0u, 0u};
     qsc[hh] = 0u;
   }
   prefetch_pages();
   issue();
+  load_q(nx.bp & 0xffff, nx.bp >> 16);
 
   // ---- main loop: one wave-iteration per trip -------------------------------------------------------------
   while (true) {
     const Stage d = nx;  // the WI whose loads are landing
     if (!(d.flags & 1)) break;
+    // keep the ~32 LDS addresses of a WI out of loop-invariant registers: they are one XOR away from these three
+    // bases, and 32 pinned VGPRs were the difference between 2 waves per SIMD and spilling
+    uint32_t w0 = w0_inv, r0 = r0_inv, t0 = t0_inv;
+    asm volatile("" : "+v"(w0), "+v"(r0), "+v"(t0));
     const int dp = d.bp >> 16;
-    // Q of a new task
-    if (d.flags & 4) {
-      wait_q<kNK + kNV>(qs[0], qs[1], qsc[0], qsc[1]);
-      const bool ok = n < rows_valid;
-      const float kmul = as_constf(a.kscale)[0];
-#pragma unroll
-      for (int hh = 0; hh < kHP; ++hh) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c) qf[hh][c] = ok ? qs[hh][c] : u32x4{0u, 0u, 0u, 0u};
-        row_scale[hh] = ok ? a.scale_log2 * __uint_as_float(qsc[hh]) * kmul : 0.f;
-        out_scale[hh] = as_constf(a.vscale)[0];  // the 1/256 of the reference formula cancels: l = 256 sum p
-      }
-    }
     // registers -> the wave's LDS stage (token rows of 256 B, chunks swizzled)
     wait_x4x4<kNV + 4>(kr[0]);
     wait_x4x4<kNV>(kr[1]);
@@ -514,6 +520,17 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q << 2) ^ (tb << 3)) * 16)) + kVOff + (tb * 16 + q * 4) * kRow)) = vr[tb][q];
+    // first WI of a task: its Q loads were the youngest in the queue, the vmcnt(0) above covered them
+    // (rows past rows_valid came back as zeros from the bounded descriptors)
+    if (d.flags & 4) {
+      wait_q<0>(qf[0], qf[1], qsc[0], qsc[1]);
+      const float kmul = as_constf(a.kscale)[0];
+#pragma unroll
+      for (int hh = 0; hh < kHP; ++hh) {
+        row_scale[hh] = a.scale_log2 * __uint_as_float(qsc[hh]) * kmul;
+        out_scale[hh] = as_constf(a.vscale)[0];  // the 1/256 of the reference formula cancels: l = 256 sum p
+      }
+    }
     // the registers are free again: the next WI (of this or the next task) goes in flight now
     issue();
 
@@ -587,20 +604,21 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     }
 
     // O^T += V^T P^T: the transpose read hands every lane one dim (column) of an 8-token x 16-dim tile.
-    // Reads go out four at a time ahead of their MFMAs (hipcc, left alone, reuses one register pair and
+    constexpr int kTrBatch = 8;
+    // Reads go out eight at a time ahead of their MFMAs (hipcc, left alone, reuses one register pair and
     // serialises read -> lgkmcnt(0) -> MFMA sixteen times: sixteen exposed LDS round trips per WI).
 #pragma unroll
     for (int hh = 0; hh < kHP; ++hh)
 #pragma unroll
-      for (int j4 = 0; j4 < 8; j4 += 4) {
-        v2i32 vt[4];
+      for (int j4 = 0; j4 < 8; j4 += kTrBatch) {
+        v2i32 vt[kTrBatch];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < kTrBatch; ++u)
           vt[u] = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
               reinterpret_cast<lds_v2i32*>(static_cast<uint32_t>(t0 ^ (((hh << 3) | (j4 + u)) * 16))));
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < kTrBatch; ++u)
           o[hh][j4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
               pack64(static_cast<uint32_t>(vt[u][0]), static_cast<uint32_t>(vt[u][1])), pack64(pf[hh][0], pf[hh][1]),
               o[hh][j4 + u], 0, 0, 0);
@@ -630,7 +648,7 @@ __global__ __launch_bounds__(kThreads) void decode2_combine_kernel(const Args a)
   if (row >= rows_valid) return;
   const int G = 1 << a.g_shift;
   const int npair = a.num_head_kv / kHP;
-  auto slot_of = [&](int c) { return ((static_cast<long>(fw + c) * npair + p) * 2 + (c == 0 ? 1 : 0)) * kHP + hh; };
+  auto slot_of = [&](int c) __attribute__((always_inline)) { return ((static_cast<long>(fw + c) * npair + p) * 2 + (c == 0 ? 1 : 0)) * kHP + hh; };
   float M = kNegInf;
   for (int c0 = 0; c0 < nchunks; c0 += 8) {
     float l8[8];
