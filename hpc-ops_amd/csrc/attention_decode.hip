@@ -771,7 +771,7 @@ extern "C" int hpc_attention_decode_fp8_async(
     b.lens = num_seq_kvcache_ptr;
     b.y = static_cast<uint16_t*>(y_ptr);
     b.part_o = b.part_lse = nullptr;
-    b.table = nullptr;
+    b.arrive = nullptr;
     b.qscale = qscale_ptr;
     b.kscale = static_cast<const float*>(kscale_ptr);
     b.vscale = vscale_ptr;
@@ -786,6 +786,7 @@ extern "C" int hpc_attention_decode_fp8_async(
     b.qscale_stride = qscale_pad_stride;
     b.new_kv_included = new_kv_included;
     b.dev_nomem = hpc_dev_tuning_get(15);
+    b.in_kernel_combine = hpc_dev_tuning_get(17) == 2 ? 0 : 1;  // key 17 = 2: merge split requests in a second kernel
     b.k_block_stride = kcache_block_stride;
     b.k_token_stride = kcache_token_stride;
     b.v_block_stride = vcache_block_stride;

@@ -16,12 +16,15 @@ struct Args {
   uint16_t* y;
   float* part_o;         // [workgroups][2][2 heads][16][128]
   float* part_lse;       // [workgroups][2][2 heads][16]
-  int* table;            // [pairs * B][2]: chunks of the request, first workgroup
+  int* arrive;           // [pairs * B] epoch-tagged arrival counters of split requests (left zero), then the
+                         // chunk table [pairs * B][2] of the two-kernel form
   const float* qscale;   // [B * Sq, qscale_stride]
   const float* kscale;   // [1] or the K-scale tail rows of the cache
   const float* vscale;   // [1] or [Hkv]
   int num_batch, num_seq_q, num_head_kv, g_shift, page_shift, max_blocks;
   int ldq, ldy, qscale_stride, new_kv_included;
+  int epoch;              // 1..32767, tags the arrival counters of this launch
+  int in_kernel_combine;  // 1: the last-arriving chunk of a split request merges it; 0: second kernel
   int dev_nomem;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing; results are wrong)
   long k_block_stride, k_token_stride;  // bytes
   long v_block_stride, v_token_stride;

@@ -30,10 +30,15 @@
 //    prefix sum - the closed form of csrc/assign_task.hip (reference assign_task.cu:362-492) on a different
 //    axis, so the caller's task map is not needed here (the first-generation kernel consumes it).
 //  * the 4 waves of a workgroup share a task (WIs w, w+4, ...), merge through LDS once per task (the idle
-//    stage regions double as the merge buffer) and write bf16 y or, for a request cut by a workgroup boundary,
-//    an fp32 partial + base-2 LSE that decode2_combine_kernel merges (chunk table written by the workgroup
-//    that owns the first chunk).  Two workgroups per CU.
+//    stage regions double as the merge buffer) and write bf16 y.  A request cut by a range boundary leaves
+//    an fp32 partial + base-2 LSE per chunk (write-through stores) and takes a ticket on the request's arrival
+//    counter; the chunk that arrives LAST merges all of them in the same launch (the reference's static path
+//    does the same, static_splitk_kernels.cuh:362-377) - no second kernel, no launch boundary.  The counters
+//    live in the call's scratch, are tagged with a per-launch epoch (stale contents read as zero arrivals) and
+//    are left zero.  Development key 17 = 2 keeps the merge in a second kernel (measured equal: 148.6 vs 148.1 us
+//    on the C3 mix, same box).  Two workgroups per CU.
 //  * fp8 numerics as in the first generation / the reference kernels.
+#include <atomic>
 #include <type_traits>
 #include <utility>
 
@@ -164,6 +169,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   __shared__ __attribute__((aligned(1024))) uint8_t s_wave[kWaves][kWaveLds];  // stage addresses are (base) ^ (bits 4-7)
   __shared__ float s_m[kHP][kWaves][16];
   __shared__ float s_l[kHP][kWaves][16];
+  __shared__ int s_ticket;
   // loads of one WI, in issue order: Q (6) | K (8) | V (8)
   constexpr int kNQ = 6, kNK = 8, kNV = 8;
 
@@ -182,6 +188,8 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   const uint8_t* qbase = static_cast<const uint8_t*>(a.q);
   const uint8_t* kbase = static_cast<const uint8_t*>(a.kcache);
   const uint8_t* vbase = static_cast<const uint8_t*>(a.vcache);
+  const auto part_rs = make_rsrc(a.part_o);
+  const auto lse_rs = make_rsrc(a.part_lse);
   auto ltot_of = [&](int b) __attribute__((always_inline)) { const int l = lens[b] + add_new; return l > 0 ? l : 0; };
   auto tiles_of = [&](int b) __attribute__((always_inline)) { return (ltot_of(b) + 63) >> 6; };
 
@@ -465,18 +473,103 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
             for (int i = 0; i < 4; ++i) pk[i] = pack_bf16x2(acc[2 * i], acc[2 * i + 1]);
             st16(dst, pk);
           } else {
+            // fp32 partial + base-2 LSE of this chunk, written THROUGH to memory (sc1): the workgroup that
+            // arrives last at the request reads them with sc1 loads - per-XCD L2s are not coherent, and
+            // write-through stores + a drained counter are the cheap valid hand-off (no cache-wide fences)
             const long slot = (static_cast<long>(wg) * 2 + (ichunk == 0 ? 1 : 0)) * kHP + hh;
-            float* po = a.part_o + (slot * 16 + row16) * 128 + c8 * 8;
-            *reinterpret_cast<f32x4*>(po) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-            *reinterpret_cast<f32x4*>(po + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
-            if (c8 == 0) a.part_lse[slot * 16 + row16] = L > 0.f ? M + __builtin_amdgcn_logf(L) - 8.0f : kNegInf;
+            const int off = static_cast<int>(((slot * 16 + row16) * 128 + c8 * 8) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]),
+                                                         __float_as_uint(acc[3])}, part_rs, off, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc[4]), __float_as_uint(acc[5]), __float_as_uint(acc[6]),
+                                                         __float_as_uint(acc[7])}, part_rs, off + 16, 0, 16);
+            if (c8 == 0)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(L > 0.f ? M + __builtin_amdgcn_logf(L) - 8.0f : kNegInf),
+                                                    lse_rs, static_cast<int>((slot * 16 + row16) * 4), 0, 16);
           }
         }
       }
-      if (tid == 0 && ichunk == 0) {
-        int* e = a.table + 2 * (static_cast<long>(dp) * B + db);
+    }
+    if (!a.in_kernel_combine) {
+      if (tid == 0 && ichunk == 0) {  // chunk table for the combine kernel (every request: 1 = nothing to merge)
+        int* e = a.arrive + static_cast<long>(npair) * B + 2 * (static_cast<long>(dp) * B + db);
         e[0] = nchunks;
         e[1] = first_rng;
+      }
+    }
+    if (nchunks > 1 && a.in_kernel_combine) {
+      // ---- split request: take a ticket; the last chunk to arrive merges all of them (reference: the last
+      // CTA of a request reduces, static_splitk_kernels.cuh:362-377; combine math: splitk_combine_kernels.cuh)
+      int* cnt = a.arrive + static_cast<long>(dp) * B + db;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my partial stores have reached memory
+      __syncthreads();
+      if (tid == 0) {
+        // arrival count tagged with this launch's epoch: whatever the word held before (an aborted launch, a buffer
+        // that was never cleared) reads as "no arrivals yet"; the last arriver leaves 0 behind, which no epoch matches
+        int cur = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), next;
+        do {
+          next = (cur >> 16) == a.epoch ? cur + 1 : ((a.epoch << 16) | 1);
+        } while (!__hip_atomic_compare_exchange_strong(cnt, &cur, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT));
+        s_ticket = next & 0xffff;
+      }
+      __syncthreads();
+      if (s_ticket == nchunks) {
+        const int row16 = tid >> 4, c8 = tid & 15;
+        if (row16 < rows_valid) {
+#pragma unroll 1
+          for (int hh = 0; hh < kHP; ++hh) {
+            auto slot_of = [&](int c) __attribute__((always_inline)) {
+              return ((static_cast<long>(first_rng + c) * npair + dp) * 2 + (c == 0 ? 1 : 0)) * kHP + hh;
+            };
+            float M = kNegInf;
+            for (int c0 = 0; c0 < nchunks; c0 += 8) {
+              float l8[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u < nchunks ? c0 + u : nchunks - 1;
+                l8[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(lse_rs, static_cast<int>((slot_of(c) * 16 + row16) * 4), 0, 16));
+              }
+#pragma unroll
+              for (int u = 0; u < 8; ++u) M = fmaxf(M, l8[u]);
+            }
+            const float Mu = M == kNegInf ? 0.f : M;
+            float W = 0.f, acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+            for (int c0 = 0; c0 < nchunks; c0 += 4) {
+              float l4[4];
+              u32x4 x0[4], x1[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u < nchunks ? c0 + u : nchunks - 1;
+                const long slot = slot_of(c);
+                l4[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(lse_rs, static_cast<int>((slot * 16 + row16) * 4), 0, 16));
+                const int off = static_cast<int>(((slot * 16 + row16) * 128 + c8 * 8) * 4);
+                x0[u] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, off, 0, 16);
+                x1[u] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, off + 16, 0, 16);
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const float wgt = c0 + u < nchunks ? __builtin_amdgcn_exp2f(l4[u] - Mu) : 0.f;
+                W += wgt;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  acc[i] = fmaf(wgt, __uint_as_float(x0[u][i]), acc[i]);
+                  acc[4 + i] = fmaf(wgt, __uint_as_float(x1[u][i]), acc[4 + i]);
+                }
+              }
+            }
+            const float inv = W > 0.f ? 1.0f / W : 0.f;
+            const int rs = row16 >> a.g_shift;
+            const int h = dp * kHP + hh;
+            uint16_t* dst = a.y + (static_cast<long>(db) * Sq + rs) * a.ldy + ((h << a.g_shift) + (row16 & (G - 1))) * 128 + c8 * 8;
+            u32x4 pk;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pk[i] = pack_bf16x2(acc[2 * i] * inv, acc[2 * i + 1] * inv);
+            st16(dst, pk);
+          }
+        }
+        if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
       }
     }
     __syncthreads();
@@ -639,9 +732,10 @@ __global__ __launch_bounds__(kThreads) void decode2_combine_kernel(const Args a)
   const int p = pb / a.num_batch, b = pb % a.num_batch;
   const int ltot = as_const(a.lens)[b] + (a.new_kv_included ? 0 : a.num_seq_q);
   if (ltot <= 0) return;
-  const int nchunks = as_const(a.table)[2 * pb];
+  const int* table = a.arrive + (a.num_head_kv / kHP) * a.num_batch;
+  const int nchunks = as_const(table)[2 * pb];
   if (nchunks <= 1) return;
-  const int fw = as_const(a.table)[2 * pb + 1];
+  const int fw = as_const(table)[2 * pb + 1];
   const int tid = threadIdx.x;
   const int row = tid >> 4, c8 = tid & 15;
   const int rows_valid = a.num_seq_q << a.g_shift;
@@ -701,8 +795,8 @@ __global__ __launch_bounds__(kThreads) void decode2_combine_kernel(const Args a)
 int64_t workspace_bytes(int num_wg, int num_batch, int num_head_kv) {
   const int64_t part_o = static_cast<int64_t>(num_wg) * 2 * kHP * 16 * 128 * 4;
   const int64_t part_lse = static_cast<int64_t>(num_wg) * 2 * kHP * 16 * 4;
-  const int64_t table = (static_cast<int64_t>(num_batch) * (num_head_kv / kHP + 1) * 8 + 15) / 16 * 16;
-  return part_o + part_lse + table;
+  const int64_t arrive = (static_cast<int64_t>(num_batch) * (num_head_kv / kHP + 1) * 12 + 15) / 16 * 16;  // counters + chunk table
+  return part_o + part_lse + arrive;
 }
 
 bool eligible(const Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride) {
@@ -719,15 +813,19 @@ int launch(Args a, void* workspace, int num_wg, int quant_type, hipStream_t stre
   ws += static_cast<int64_t>(num_wg) * 2 * kHP * 16 * 128 * 4;
   a.part_lse = reinterpret_cast<float*>(ws);
   ws += static_cast<int64_t>(num_wg) * 2 * kHP * 16 * 4;
-  a.table = reinterpret_cast<int*>(ws);
+  a.arrive = reinterpret_cast<int*>(ws);
+  static std::atomic<int> epoch{0};
+  a.epoch = (epoch.fetch_add(1, std::memory_order_relaxed) % 32767) + 1;  // 1 .. 32767, frozen inside a captured graph
   if (quant_type != 1) return HPC_ERR_UNSUPPORTED;  // per-token K scales: first-generation kernel
   if (hpc_dev_tuning_get(0) == 1)
     decode2_kernel<0><<<num_wg, kThreads, 0, stream>>>(a);
   else
     decode2_kernel<2><<<num_wg, kThreads, 0, stream>>>(a);
   HPC_CHECK_LAUNCH();
-  decode2_combine_kernel<<<a.num_batch * a.num_head_kv, kThreads, 0, stream>>>(a);
-  HPC_CHECK_LAUNCH();
+  if (!a.in_kernel_combine) {
+    decode2_combine_kernel<<<a.num_batch * a.num_head_kv, kThreads, 0, stream>>>(a);
+    HPC_CHECK_LAUNCH();
+  }
   return HPC_OK;
 }
 

@@ -112,6 +112,25 @@ def _alloc_task_workspace(device, num_cu, max_num_batch, max_seqlen, num_head_kv
     return ws
 
 
+_DECODE_WS = {}
+
+
+def _decode_workspace(device, nbytes):
+    """Scratch of a decode call (split-KV partials, arrival counters; no initialisation needed).  One buffer per
+    (device, stream) is kept and reused instead of an allocator round trip on every step (the reference allocates
+    per call, src/attention/entry.cc:660-663).  Calls on one stream are ordered, so sharing the buffer between them
+    is safe; different streams get different buffers; while a hipGraph is being captured the buffer comes from the
+    graph's own pool (torch.empty inside the capture) and lives as long as the graph."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _DECODE_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _DECODE_WS[key] = ws
+    return ws
+
+
 def _decode_common_checks(q, kcache, vcache, block_ids, num_seq_kvcache, mtp, max_mtp):
     _C.require(q.is_cuda, "q tensor must be cuda")
     _C.require(kcache.is_cuda, "kcache tensor must be cuda")
@@ -167,7 +186,7 @@ def _attention_decode_bf16_entry(q, kcache, vcache, block_ids, num_seq_kvcache, 
         (num_batch * num_seq_q, num_head_q, vcache.size(3)), dtype=torch.bfloat16, device=q.device)
     bins = num_bins(num_seq_q, q.device)
     ws_bytes = _C.lib.hpc_attention_decode_workspace_bytes(bins, num_batch, num_head_kv, num_seq_q, group)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+    ws = _decode_workspace(q.device, ws_bytes)
     rc = _C.lib.hpc_attention_decode_bf16_async(
         _C.ptr(y), _C.ptr(ws), ctypes.cast(task_map.data_ptr(), _INT_P), _C.ptr(q), _C.ptr(kcache),
         _C.ptr(vcache), ctypes.cast(block_ids.data_ptr(), _INT_P), bins, num_batch, num_seq_q,
@@ -216,7 +235,7 @@ def _attention_decode_fp8_entry(q, kcache, vcache, block_ids, num_seq_kvcache, q
         (num_batch * num_seq_q, num_head_q, vcache.size(3)), dtype=torch.bfloat16, device=q.device)
     bins = num_bins(num_seq_q, q.device)
     ws_bytes = _C.lib.hpc_attention_decode_workspace_bytes(bins, num_batch, num_head_kv, num_seq_q, group)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+    ws = _decode_workspace(q.device, ws_bytes)
     rc = _C.lib.hpc_attention_decode_fp8_async(
         _C.ptr(y), _C.ptr(ws), ctypes.cast(task_map.data_ptr(), _INT_P), _C.ptr(q), _C.ptr(kcache),
         _C.ptr(vcache), ctypes.cast(block_ids.data_ptr(), _INT_P),

@@ -81,10 +81,13 @@ int hpc_assign_attention_decode_task_async(int* task_map, const int* num_seq_kvc
  * with element strides (block, token, head), block_ids int32 [B, num_seq_max_blocks],
  * y bf16 [B*Sq, Hq, 128] (row stride ldY).  `task_map_ptr` is a task map produced by the
  * scheduler above for the same num_seq_kvcache / num_seq_q / new_kv_included; `num_bins` must be
- * its header[1].  `workspace` holds the fp32 split-KV partials: hpc_attention_decode_workspace_bytes
- * bytes, no initialisation needed (the reference allocates lse/split_out per call,
- * src/attention/entry.cc:492-499; here it is 2 slots per bin instead of splitk slots per request).
- * The split-KV combine runs inside the call (second kernel on the same stream). */
+ * its header[1].  `workspace` holds the fp32 split-KV partials and the arrival counters of split requests:
+ * hpc_attention_decode_workspace_bytes bytes, no initialisation needed (the counters are tagged with a per-launch
+ * epoch and left zero), so one buffer per stream can be reused call after call and inside a captured
+ * hipGraph (the reference allocates lse/split_out per call, src/attention/entry.cc:492-499; here it is 2 slots
+ * per workgroup instead of splitk slots per request).  The split-KV combine runs inside the call: a second
+ * kernel on the same stream for the first-generation kernels, the last-arriving chunk of a request for the
+ * second-generation FP8 kernel (reference: static_splitk_kernels.cuh:362-377). */
 int64_t hpc_attention_decode_workspace_bytes(int num_bins, int num_batch, int num_head_kv,
                                              int num_seq_q, int heads_per_group);
 int hpc_attention_decode_bf16_async(void* y_ptr, void* workspace, const int* task_map_ptr,

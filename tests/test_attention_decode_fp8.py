@@ -134,3 +134,27 @@ def test_attn_fp8_bins_of_short_requests(k_per_token, num_seq_q, solo):
         _run(len(lens), num_seq_q, lens, 64, (2, 16), k_per_token, True, True, "NHD", 0.1 if k_per_token else 0.2)
     finally:
         hpc._C.lib.hpc_dev_tuning_set(5, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["last_arriver", "second_kernel", "poisoned_scratch"])
+def test_attn_fp8_split_request_merge_variants(mode):
+    """Requests cut by range boundaries (second-generation kernel): merged inside the launch by the chunk that
+    arrives last (default), by a second kernel (development key 17 = 2), and with the call's scratch - partial
+    slots and arrival counters - full of garbage before the call (the counters are epoch-tagged: stale contents
+    must read as 'no arrivals yet'); the same call twice must also agree (the counters are left clean)."""
+    import hpc
+    from hpc import _entry_attention as ea
+
+    lens = torch.tensor([20000, 3, 9000, 130, 64, 4097, 700, 31000], dtype=torch.int32)
+    hpc._C.lib.hpc_dev_tuning_set(17, 2 if mode == "second_kernel" else 0)
+    try:
+        if mode == "poisoned_scratch":
+            _run(len(lens), 1, lens, 64, (4, 32), False, True, True, "NHD", 0.2)  # creates the cached scratch
+            for ws in ea._DECODE_WS.values():
+                ws.fill_(0xAB)
+            torch.cuda.synchronize()
+        for _ in range(2):
+            _run(len(lens), 1, lens, 64, (4, 32), False, True, True, "NHD", 0.2)
+    finally:
+        hpc._C.lib.hpc_dev_tuning_set(17, 0)
