@@ -31,3 +31,6 @@ int hpc_ggemm_launch_tiled(const hpc::ggemm::Args& a, const int* cu_tiles, int n
                            hipStream_t stream);
 int hpc_ggemm_launch_tiled256(const hpc::ggemm::Args& a, const int* cu_tiles, int num_group, int m, int n,
                               hipStream_t stream);
+// 256 x 256 tile, staggered wave groups (group_gemm_p8.hip); derives its 256-token tiles from the same scan
+int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a, const int* cu_tiles, int num_group, int m, int n,
+                        hipStream_t stream);

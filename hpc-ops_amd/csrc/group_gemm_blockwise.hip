@@ -248,8 +248,13 @@ int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const v
   // groups above ~40 tokens: tiled kernels (need the scan of ceil(seqlens/128)): the 256 x 128 LDS-DMA ring
   // kernel when n allows (one pass over the weights for up to 128 tokens; measured faster than the
   // streaming form from ~40 tokens per group on), else the 128 x 128 register-staged one
-  const int tiled_mode = hpc_dev_tuning_get(3);  // 0 auto, 1 never, 2 always (when possible), 3 always, 128x128 only
+  // development key 3: 0 auto, 1 never tiled, 2 always 256 x 128 (when possible), 3 always 128 x 128,
+  // 4 always 256 x 256 (when possible)
+  const int tiled_mode = hpc_dev_tuning_get(3);
   if (cu_tiles128 && n % 128 == 0 && tiled_mode != 1 && (tiled_mode >= 2 || m / num_group > 40)) {
+    // 256-token tiles from ~192 tokens per group on: below that most of a second half-tile would be padding
+    if (n % 256 == 0 && a.K >= 128 && (tiled_mode == 4 || (tiled_mode == 0 && m / num_group >= 192)))
+      return hpc_ggemm_launch_p8(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);
     if (n % 256 == 0 && a.K >= 128 && tiled_mode != 3)
       return hpc_ggemm_launch_tiled256(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);
     return hpc_ggemm_launch_tiled(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);

@@ -1,0 +1,443 @@
+// Grouped FP8 GEMM, 256 x 256 tile, two staggered wave groups, two MFMA sections per k-tile - gfx950.
+//
+// Same contract as group_gemm_tiled256.hip (reference src/group_gemm/kernels.cuh:215-892).  The
+// 256 x 128 ring kernel stages 48 KB per k-step for 16 MFMAs per wave and its waves spend as long
+// issuing LDS-DMA pieces and operand reads as the matrix pipe spends multiplying.  This form halves the
+// staging per MFMA and takes most of what is left off the matrix pipe's critical path:
+//   * tile = 256 weight rows x 256 tokens x 128 k-bytes; 8 waves = 2 groups (weight-row halves) x 4
+//     (64-token strips); a wave owns 128 x 64 outputs = 8 x 4 MFMA blocks, one
+//     v_mfma_f32_16x16x128_f8f6f4 per block and k-tile (32 per k-tile and wave, 2048 matrix-pipe cycles per
+//     SIMD), 24 ds_read_b128 and 8-9 DMA pieces (the 256 x 128 kernel: 16 MFMAs, 16-20 reads, 6-7 pieces);
+//   * a wave's k-tile is two SECTIONS of 16 MFMAs (rows 0-63 / rows 64-127 of its half, all 64 tokens):
+//     [operand reads | DMA pieces | counted vmcnt + lgkmcnt(0) | barrier | 16 MFMAs at raised priority |
+//     barrier].  Waves 0-3 and waves 4-7 - the two waves of every SIMD - run ONE BARRIER apart, so while one
+//     wave of a SIMD multiplies the other loads: the matrix pipe sees back-to-back MFMA sections, and
+//     whatever a load section costs is free as long as it is shorter than 16 MFMAs (512 cycles);
+//   * a DMA piece costs its wave 60-100 cycles of issue (address path).  Load section Y (8 reads) takes
+//     four pieces, load section X (16 reads) two, and three go between the MFMAs of section Y (measured:
+//     all nine between MFMAs 1.86 / 2.00 PFLOP/s on the two GEMMs of the MoE, this split 1.86 / 2.07,
+//     four sections of 8 MFMAs per k-tile 1.78 / 1.91; with no DMA at all the loop runs at 2.5 / 2.8);
+//   * staging is in four 16 KB units per k-tile, cut by the section that reads them: U0 = weight rows
+//     0-63 of either group's half, U3 = rows 64-127, U1 / U2 = the first / second 32 tokens of every strip.
+//     Two buffers; a unit is refilled behind the barrier after its last read (operand reads retire BEFORE a
+//     section's barrier) and lands two or more sections before its first read; the waits are the constants
+//     vmcnt(9|8) and vmcnt(6);
+//   * the blockwise rescale is software-pipelined by hand: the four FMAs of block n follow the MFMA of
+//     block n+1, the last block's follow the barrier that ends the section;
+//   * LDS image, source-side XOR swizzle and the K = 128 MFMA operand convention as in
+//     group_gemm_tiled256.hip; 2 x 64 KB + scales = 131 KB of LDS, one workgroup per CU;
+//   * epilogue: neighbouring row blocks are exchanged between lane quarters (v_permlane16_swap) so that a
+//     lane stores 16 contiguous bytes of an output row instead of 8.
+#include "hpc_common.h"
+#include "hpc_dev.h"
+#include "../../include/hpc_amd.h"
+#include "group_gemm.h"
+
+namespace hpc {
+namespace ggemm {
+namespace {
+
+constexpr int kThreads = 512;
+constexpr int kBN = 256, kBM = 256, kBK = 128;
+constexpr int kUnit = 128 * kBK;       // 16 KB: 128 rows of 128 k-bytes
+constexpr int kBuf = 4 * kUnit;        // [U0 weights early | U1 tokens early | U2 tokens late | U3 weights late]
+constexpr int kXsOff = 2 * kBuf;       // 2 x 1 KB of token scales + 1 KB nobody reads (idle waves' scale DMA)
+constexpr int kLds = kXsOff + 3 * 1024;
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int kN>
+struct IntC {
+  static constexpr int value = kN;
+};
+
+// The work item of this workgroup: items are ordered group -> weight tile -> 256-token tile and dealt to the XCDs
+// in contiguous eighths (as in the 256 x 128 kernel).  The 256-token tile counts come from the scan of
+// ceil(len / 128) the callers already have; one pass of loads: lane g holds group g0 + g.
+struct Item {
+  int e, rem, mtiles, m_cnt, m0;
+  bool valid;
+};
+__device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, const int* cu_seqlens, int num_group,
+                                            int nt, int lane, int lin) {
+  Item it = {0, 0, 0, 0, 0, false};
+  if (num_group <= 64) {  // the usual case: everything from one round of loads
+    const bool on = lane < num_group;
+    const int t = on ? ((cut[lane + 1] - cut[lane] + 1) >> 1) : 0;
+    const int len = on ? seqlens[lane] : 0, row0 = on ? cu_seqlens[lane] : 0;
+    int inc = t;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o, 64);
+      inc += lane >= o ? v : 0;
+    }
+    const int total = __shfl(inc, 63, 64) * nt;
+    const int chunk = (total + 7) >> 3;
+    const int item = (lin & 7) * chunk + (lin >> 3);
+    if ((lin >> 3) >= chunk || item >= total) return it;
+    const unsigned long long hit = __ballot(on && item < inc * nt);
+    const int l = __builtin_ctzll(hit);
+    it.e = l;
+    it.mtiles = __shfl(t, l, 64);
+    it.rem = item - (__shfl(inc, l, 64) - it.mtiles) * nt;
+    it.m_cnt = __shfl(len, l, 64);
+    it.m0 = __shfl(row0, l, 64);
+    it.valid = true;
+    return it;
+  }
+  int total = 0;
+  for (int g0 = 0; g0 < num_group; g0 += 64) {
+    const int g = g0 + lane;
+    int t = g < num_group ? ((cut[g + 1] - cut[g] + 1) >> 1) : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    total += t;
+  }
+  total *= nt;
+  const int chunk = (total + 7) >> 3;
+  const int item = (lin & 7) * chunk + (lin >> 3);
+  if ((lin >> 3) >= chunk || item >= total) return it;
+  int base = 0;
+  for (int g0 = 0; g0 < num_group; g0 += 64) {
+    const int g = g0 + lane;
+    const int t = g < num_group ? ((cut[g + 1] - cut[g] + 1) >> 1) : 0;
+    int inc = t;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(inc, o, 64);
+      inc += lane >= o ? v : 0;
+    }
+    const unsigned long long hit = __ballot(g < num_group && item < (base + inc) * nt);
+    if (hit) {
+      const int l = __builtin_ctzll(hit);
+      it.e = g0 + l;
+      it.mtiles = __shfl(t, l, 64);
+      it.rem = item - (base + __shfl(inc, l, 64) - it.mtiles) * nt;
+      it.m_cnt = as_const(seqlens)[it.e];
+      it.m0 = as_const(cu_seqlens)[it.e];
+      it.valid = true;
+      return it;
+    }
+    base += __shfl(inc, 63, 64);
+  }
+  return it;
+}
+
+// kNoDma (development key 18 = 1, timing only - results are wrong): no DMA inside the k-loop
+template <bool kHasXs, bool kNoDma = false>
+__global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, const int* __restrict__ cu_tiles,
+                                                                  int num_group) {
+  __shared__ __attribute__((aligned(1024))) uint8_t s_mem[kLds];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int wn = wave >> 2, wm = wave & 3;  // group (weight-row half) / 64-token strip
+
+  const int nt = a.N / kBN;
+  const Item it = locate_item(as_const(cu_tiles), a.seqlens, a.cu_seqlens, num_group, nt, lane, blockIdx.x);
+  if (!it.valid) return;
+  const int e = __builtin_amdgcn_readfirstlane(it.e);
+  const int rem = __builtin_amdgcn_readfirstlane(it.rem);
+  const int mtiles = __builtin_amdgcn_readfirstlane(it.mtiles);
+  const int m_cnt = __builtin_amdgcn_readfirstlane(it.m_cnt);
+  const int m0 = __builtin_amdgcn_readfirstlane(it.m0);
+  const int mt0 = (rem % mtiles) * kBM;
+  const int n0 = (rem / mtiles) * kBN;
+  const int K = a.K, KB = a.KB;
+
+  // ---- DMA roles: two 8-row pieces of every unit per wave --------------------------------------------------
+  // piece pc = wave * 2 + q covers unit rows pc*8 .. +8; lane -> row lane/8, LDS position lane%8 <- source
+  // chunk (lane%8) ^ (lane/8).  Unit rows: weights  ur -> n = (ur/64)*128 + ur%64 (+64 for U3);
+  // tokens ur -> slot (ur/32)*64 + ur%32 (+32 for U2).
+  const int p_row = lane >> 3, p_chunk = (lane & 7) ^ (lane >> 3);
+  const uint8_t* wsrc = a.w + (static_cast<long>(e) * a.N + n0) * K;
+  const unsigned w_bytes = static_cast<unsigned>(kBN) * static_cast<unsigned>(K);
+  const int late_w = 64 * K;  // byte distance of the U3 rows from the U0 rows
+  unsigned w_voff[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int ur = (wave * 2 + q) * 8 + p_row;
+    w_voff[q] = static_cast<unsigned>((ur >> 6) * 128 + (ur & 63)) * static_cast<unsigned>(K) + p_chunk * 16;
+  }
+  // k-tile T -> buffer T & 1 (`par`, a compile-time value).  Past the end: empty descriptors (nothing fetched,
+  // zeros written, still counted by vmcnt).  One piece (q = 0, 1) per call.
+  auto dma_w = [&](int T, bool on, auto par, auto late, int q) {
+    constexpr int kP = decltype(par)::value, kLate = decltype(late)::value;
+    const int koff = T * kBK;
+    const auto rw = make_rsrc(wsrc, on ? w_bytes : 0u);
+    // K % 128 == 64 (per-tensor scales only): the chunks past K get an out-of-range offset and land as zeros
+    const bool k_ok = kHasXs || koff + p_chunk * 16 < K;
+    uint8_t* base = s_mem + kP * kBuf + (kLate ? 3 * kUnit : 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + (wave * 2 + q) * 1024), 16,
+                                             k_ok ? w_voff[q] : 0xffffff00u, koff + (kLate ? late_w : 0), 0, 0);
+  };
+  // the weight pieces of k-tiles 0 and 1 do not depend on the token rows: they go out before the row-index loads
+  dma_w(0, true, IntC<0>{}, IntC<0>{}, 0);
+  dma_w(0, true, IntC<0>{}, IntC<0>{}, 1);
+  dma_w(0, true, IntC<0>{}, IntC<1>{}, 0);
+  dma_w(0, true, IntC<0>{}, IntC<1>{}, 1);
+  dma_w(1, 1 < KB, IntC<1>{}, IntC<0>{}, 0);
+  dma_w(1, 1 < KB, IntC<1>{}, IntC<0>{}, 1);
+
+  unsigned x_voff[2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int ur = (wave * 2 + q) * 8 + p_row;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int slot = mt0 + (ur >> 5) * 64 + (ur & 31) + u * 32;
+      const int sc = slot < m_cnt ? slot : m_cnt - 1;
+      const int xrow = a.row_index ? a.row_index[m0 + sc] : m0 + sc;
+      x_voff[u][q] = static_cast<unsigned>(xrow) * static_cast<unsigned>(K) + p_chunk * 16;
+    }
+  }
+  unsigned xs_voff = 0;
+  if constexpr (kHasXs) {
+    const int slot = mt0 + (wave & 3) * 64 + lane;
+    const int sc = slot < m_cnt ? slot : m_cnt - 1;
+    const long col0 = a.col_base ? static_cast<long>(as_const(a.col_base)[e]) * a.tile_m : 0;
+    const long term = a.col_base ? col0 + sc : static_cast<long>(a.row_index ? a.row_index[m0 + sc] : m0 + sc);
+    xs_voff = static_cast<unsigned>(term * a.xs_row_stride * 4);
+  }
+  const int xs_kb_bytes = static_cast<int>(a.xs_kb_stride * 4);
+  auto dma_x = [&](int T, bool on, auto par, auto late, int q) {
+    constexpr int kP = decltype(par)::value, kLate = decltype(late)::value;
+    const int koff = T * kBK;
+    const auto rx = make_rsrc(a.x, on ? a.x_bytes : 0u);
+    const bool k_ok = kHasXs || koff + p_chunk * 16 < K;
+    uint8_t* base = s_mem + kP * kBuf + (1 + kLate) * kUnit;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(base + (wave * 2 + q) * 1024), 16,
+                                             k_ok ? x_voff[kLate][q] : 0xffffff00u, koff, 0, 0);
+  };
+  auto dma_xs = [&](int T, bool on, auto par) {
+    constexpr int kP = decltype(par)::value;
+    if constexpr (kHasXs) {
+      // all eight waves issue it (the vmcnt arithmetic needs equal counts); waves 4-7 fetch nothing
+      const auto rs = make_rsrc(a.xs, __builtin_amdgcn_readfirstlane(on && wave < 4 ? 0xffffffffu : 0u));
+      uint8_t* dst = s_mem + kXsOff + (wave < 4 ? kP * 1024 + wave * 256 : 2048);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 4, xs_voff, T * xs_kb_bytes, 0, 0);
+    }
+  };
+
+  const cint_ptr ws_row = as_const(reinterpret_cast<const int*>(a.ws)) + static_cast<long>(e) * a.ws_group_stride +
+                          ((n0 + wn * 128) >> 7) * a.ws_ntile_stride;
+
+  f32x4 tot[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // operand read offsets inside a unit (swizzled): row r, chunk c -> r*128 + ((c ^ (r & 7)) << 4); the rows of a
+  // wave's blocks are 16 apart, so (r & 7) does not depend on the block and block offsets are immediates
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    a_off[c] = (wn * 64 + r16) * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);
+    b_off[c] = kUnit + (wm * 32 + r16) * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);
+  }
+  auto read_a = [&](const uint8_t* unit0, u32x4 (&af)[4][2]) {  // unit0: start of U0 or U3 of the buffer
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) af[i][c] = *reinterpret_cast<const u32x4*>(unit0 + a_off[c] + i * 2048);
+  };
+  auto read_b = [&](const uint8_t* buf, int late, u32x4 (&bf)[2][2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+        bf[j][c] = *reinterpret_cast<const u32x4*>(buf + b_off[c] + late * kUnit + j * 2048);
+  };
+
+  // One section: 4 row blocks x all 4 token blocks (16 MFMAs), written as the software pipeline it has to be:
+  // the rescale of block n follows the MFMA of block n + 1 (its result is ready by then), `hook(n)` may issue
+  // one DMA piece behind them, and the order is pinned.  Blockwise form: fp32 partial of the 128-k block,
+  // rescaled into the running sum (reference kernels.cuh:473-476); the rescale of the LAST block is the
+  // caller's (`tail`), behind the barrier that ends the section - otherwise that barrier would wait for the last
+  // MFMA's result and the other wave of the SIMD would start its section ~40 cycles late.
+  auto section = [&](int i0, const u32x4 (&af)[4][2], const u32x4 (&be)[2][2], const u32x4 (&bl)[2][2],
+                     const float (&f)[4], f32x4& tail, auto&& hook) {
+    f32x4 prev = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 16; ++n) {
+      const int i = n >> 2, j = n & 3;
+      const u32x4(&bf)[2] = j < 2 ? be[j] : bl[j - 2];
+      const i32x8 av = {static_cast<int>(af[i][0][0]), static_cast<int>(af[i][0][1]), static_cast<int>(af[i][0][2]),
+                        static_cast<int>(af[i][0][3]), static_cast<int>(af[i][1][0]), static_cast<int>(af[i][1][1]),
+                        static_cast<int>(af[i][1][2]), static_cast<int>(af[i][1][3])};
+      const i32x8 bv = {static_cast<int>(bf[0][0]), static_cast<int>(bf[0][1]), static_cast<int>(bf[0][2]),
+                        static_cast<int>(bf[0][3]), static_cast<int>(bf[1][0]), static_cast<int>(bf[1][1]),
+                        static_cast<int>(bf[1][2]), static_cast<int>(bf[1][3])};
+      if constexpr (kHasXs) {
+        const f32x4 part = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0,
+                                                                            0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // MFMA n first, then the rescale of block n - 1
+        if (n > 0) {
+          const int pi = (n - 1) >> 2, pj = (n - 1) & 3;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tot[i0 + pi][pj][r] = fmaf(prev[r], f[pj], tot[i0 + pi][pj][r]);
+        }
+        prev = part;
+      } else {
+        // one scale per group: accumulate straight into the running sum, scale once in the epilogue
+        // (the reference scales every k-tile: same value up to fp32 rounding)
+        tot[i0 + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, tot[i0 + i][j], 0, 0, 0, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      hook(n);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    tail = prev;
+  };
+  auto apply_tail = [&](int i0, const float (&f)[4], const f32x4& tail) {
+    if constexpr (kHasXs) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tot[i0 + 3][3][r] = fmaf(tail[r], f[3], tot[i0 + 3][3][r]);
+    }
+  };
+
+  // s_waitcnt immediates: vmcnt = n (split 4 + 2 bits), expcnt untouched, lgkmcnt 0 (or untouched: | 0x0F00)
+  constexpr int kFlyX = kHasXs ? 9 : 8, kFlyY = 6;
+  auto enter_mma = [&](auto fly) {  // end of a load section
+    constexpr int kN = decltype(fly)::value;
+    __builtin_amdgcn_sched_barrier(0);
+    // this wave's pieces of the unit(s) read behind the NEXT barrier have landed; its operand reads have retired
+    if constexpr (kNoDma)
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+    else
+      __builtin_amdgcn_s_waitcnt(0x0070 | (kN & 15) | ((kN >> 4) << 14));
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+  };
+  auto leave_mma = [&]() {
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  // ---- prologue: the token pieces of k-tiles 0 and 1 ---------------------------------------------------------
+  // Steady-state issue order per k-tile T: load section Y: U0(T+2), U1(T+2); MFMAs of Y: U2(T+2), scales(T+2);
+  // load section X of T+1: U3(T+2).  Every target's last reads (by either group) retired before the barrier
+  // that precedes the issue.  Waits: end of load section X leaves kFlyX pieces in flight - U3(T), read behind
+  // the next barrier but one, has landed; end of load section Y leaves 6 - all of k-tile T+1 up to its scales
+  // has landed.  Here the weight pieces went first, so the first wait leaves k-tile 1's token pieces.
+  dma_x(0, true, IntC<0>{}, IntC<0>{}, 0);
+  dma_x(0, true, IntC<0>{}, IntC<0>{}, 1);
+  dma_x(0, true, IntC<0>{}, IntC<1>{}, 0);
+  dma_x(0, true, IntC<0>{}, IntC<1>{}, 1);
+  dma_xs(0, true, IntC<0>{});
+  dma_x(1, 1 < KB, IntC<1>{}, IntC<0>{}, 0);
+  dma_x(1, 1 < KB, IntC<1>{}, IntC<0>{}, 1);
+  dma_x(1, 1 < KB, IntC<1>{}, IntC<1>{}, 0);
+  dma_x(1, 1 < KB, IntC<1>{}, IntC<1>{}, 1);
+  dma_xs(1, 1 < KB, IntC<1>{});
+  constexpr int kFly0 = kHasXs ? 5 : 4;
+  __builtin_amdgcn_s_waitcnt(0x0F70 | kFly0);  // k-tile 0 (and the weight pieces of k-tile 1) have landed
+  __builtin_amdgcn_s_barrier();
+  if (wn == 1) __builtin_amdgcn_s_barrier();  // the second group runs one barrier behind from here on
+  __builtin_amdgcn_sched_barrier(0);
+
+  u32x4 a_frag[4][2], b_early[2][2], b_late[2][2];
+  f32x4 tail;
+  auto k_tile = [&](int T, auto par) {
+    constexpr int kP = decltype(par)::value;
+    const uint8_t* buf = s_mem + kP * kBuf;
+    const bool on1 = T + 1 < KB, on2 = T + 2 < KB;
+    // ---- section X: rows 0-63 of the wave's half ------------------------------------------------------------
+    read_b(buf, 0, b_early);
+    read_b(buf, 1, b_late);
+    read_a(buf, a_frag);
+    float f[4] = {1.f, 1.f, 1.f, 1.f}, xsv[4] = {1.f, 1.f, 1.f, 1.f}, wsk = 1.f;
+    if constexpr (kHasXs) {
+      wsk = __int_as_float(ws_row[T * a.ws_kb_stride]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        xsv[j] = *reinterpret_cast<const float*>(s_mem + kXsOff + kP * 1024 + (wm * 64 + j * 16 + r16) * 4);
+    }
+    if constexpr (!kNoDma) {
+      dma_w(T + 1, on1, IntC<1 - kP>{}, IntC<1>{}, 0);
+      dma_w(T + 1, on1, IntC<1 - kP>{}, IntC<1>{}, 1);
+    }
+    enter_mma(IntC<kFlyX>{});
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[j] = wsk * xsv[j];
+    section(0, a_frag, b_early, b_late, f, tail, [&](int) {});
+    leave_mma();
+    apply_tail(0, f, tail);
+    // ---- section Y: rows 64-127 ----------------------------------------------------------------------------
+    read_a(buf + 3 * kUnit, a_frag);
+    if constexpr (!kNoDma) {
+      dma_w(T + 2, on2, IntC<kP>{}, IntC<0>{}, 0);
+      dma_w(T + 2, on2, IntC<kP>{}, IntC<0>{}, 1);
+      dma_x(T + 2, on2, IntC<kP>{}, IntC<0>{}, 0);
+      dma_x(T + 2, on2, IntC<kP>{}, IntC<0>{}, 1);
+    }
+    enter_mma(IntC<kFlyY>{});
+    section(4, a_frag, b_early, b_late, f, tail, [&](int n) {
+      if constexpr (!kNoDma) {
+        if (n == 3) dma_x(T + 2, on2, IntC<kP>{}, IntC<1>{}, 0);
+        if (n == 8) dma_x(T + 2, on2, IntC<kP>{}, IntC<1>{}, 1);
+        if (n == 12) dma_xs(T + 2, on2, IntC<kP>{});
+      }
+    });
+    leave_mma();
+    apply_tail(4, f, tail);
+  };
+  for (int kb = 0; kb < KB; kb += 2) {
+    k_tile(kb, IntC<0>{});
+    if (kb + 1 < KB) k_tile(kb + 1, IntC<1>{});
+  }
+  if (wn == 0) __builtin_amdgcn_s_barrier();  // even out the barrier count
+  __builtin_amdgcn_s_waitcnt(0x0F70);         // drain the (empty) tail DMAs before the workgroup's LDS is released
+
+  if constexpr (!kHasXs) {
+    const float gs = __int_as_float(ws_row[0]);  // per-tensor form: strides are zero, one scale per group
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tot[i][j] *= gs;
+  }
+  // ---- epilogue ---------------------------------------------------------------------------------------------
+  // A lane holds rows n = wn*128 + i*16 + g4*4 + r of token slot wm*64 + j*16 + r16: 8 bytes of the token's output
+  // row per block.  v_permlane16_swap on the blocks i, i+1 hands lane quarter q the 8 rows [(q&2)*4, +8) of block
+  // i + (q&1): 16 contiguous bytes per store, half as many stores.
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int slot = mt0 + wm * 64 + j * 16 + r16;
+    uint16_t* yrow = a.y + static_cast<long>(m0 + slot) * a.N + n0 + wn * 128 + (g4 & 1) * 16 + (g4 >> 1) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      const uint32_t a0 = pack_bf16x2(tot[i][j][0], tot[i][j][1]), a1 = pack_bf16x2(tot[i][j][2], tot[i][j][3]);
+      const uint32_t b0 = pack_bf16x2(tot[i + 1][j][0], tot[i + 1][j][1]), b1 = pack_bf16x2(tot[i + 1][j][2], tot[i + 1][j][3]);
+      const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+      const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+      if (slot < m_cnt) *reinterpret_cast<u32x4*>(yrow + i * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+    }
+  }
+}
+
+}  // namespace
+}  // namespace ggemm
+}  // namespace hpc
+
+int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a, const int* cu_tiles, int num_group, int m, int n,
+                        hipStream_t stream) {
+  using namespace hpc::ggemm;
+  if (n % kBN || a.K < kBK) return HPC_ERR_UNSUPPORTED;
+  const long max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 256)
+  const long items = max_tiles * (n / kBN) + 8;  // + 8: the per-XCD chunks round up
+  if (items > 0x7fffffffl) return HPC_ERR_UNSUPPORTED;
+  dim3 grid(static_cast<unsigned>(items));
+  if (a.has_xs && hpc_dev_tuning_get(18) == 1)
+    gemm_fp8_p8_kernel<true, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  else if (a.has_xs)
+    gemm_fp8_p8_kernel<true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  else
+    gemm_fp8_p8_kernel<false><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}

@@ -1,6 +1,6 @@
 // Development tuning registers - INTERNAL, not part of the C-ABI of include/hpc_amd.h.
 //
-// 16 small integers that select kernel variants inside the launchers for A/B measurements and for
+// 32 small integers that select kernel variants inside the launchers for A/B measurements and for
 // the parity tests that pin one variant (tests/, tools/).  All zero = the shipped configuration.
 // Storage is a set of relaxed atomics (any host thread may read them while another one writes);
 // the environment variable HPC_AMD_TUNING="key=value,key=value" seeds them once at library load,
@@ -8,13 +8,19 @@
 // for the in-tree tools only; they are deliberately absent from the public header.
 //   key 0  decode KV load cache policy (1 = temporal instead of nt)
 //   key 1  streaming grouped GEMM: forced tokens-per-pass / waves variant
-//   key 3  grouped GEMM tiled mode (0 auto, 1 never, 2 always when possible, 3 always 128x128)
+//   key 3  grouped GEMM tiled mode (0 auto, 1 never, 2 always 256x128 when possible, 3 always 128x128,
+//          4 always 256x256 when possible)
 //   key 5  decode: 1 = never run one task per wave ("solo")
 //   key 6  256x128 tiled GEMM: 2 = 32-token narrow form
 //   key 7  block-sparse prefill row mapping (1 head-major, 2 position-major)
 //   key 9  fused all-reduce (high throughput): 1 = runtime-world-size kernel at any world size
 //   key 10 fused all-reduce: bounded spins give up after 2^value rounds (default 2^22)
 //   key 11 fused all-reduce (high throughput): minimum grid (default 256 = one workgroup per CU)
+//   key 12 decode fp8: 1 = never the head-pair kernel (attention_decode_v2.hip)
+//   key 14 decode fp8 v2: workgroup count override
+//   key 15 decode fp8 v2: 1 = no KV loads (compute-only timing)
+//   key 17 decode fp8 v2: 2 = merge split requests in a second kernel
+//   key 18 256x256 grouped GEMM: 1 = no DMA in the k-loop (timing only)
 //   others: see the launchers that read them
 #pragma once
 

@@ -66,7 +66,8 @@ extern "C" int hpc_get_cu_count(int device_id) {
 
 namespace {
 struct Tuning {
-  std::atomic<int> v[16];
+  static constexpr int kKeys = 32;
+  std::atomic<int> v[kKeys];
   Tuning() {
     for (auto& x : v) x.store(0, std::memory_order_relaxed);
     const char* env = std::getenv("HPC_AMD_TUNING");  // "key=value,key=value"
@@ -77,7 +78,7 @@ struct Tuning {
       env = end + 1;
       const long val = std::strtol(env, &end, 10);
       if (end == env) break;
-      if (k >= 0 && k < 16) v[k].store(static_cast<int>(val), std::memory_order_relaxed);
+      if (k >= 0 && k < kKeys) v[k].store(static_cast<int>(val), std::memory_order_relaxed);
       env = (*end == ',') ? end + 1 : end;
       if (*end != ',') break;
     }
@@ -90,10 +91,10 @@ Tuning& tuning() {
 }  // namespace
 
 extern "C" int hpc_dev_tuning_set(int key, int value) {
-  if (key < 0 || key >= 16) return -2;
+  if (key < 0 || key >= Tuning::kKeys) return -2;
   tuning().v[key].store(value, std::memory_order_relaxed);
   return 0;
 }
 extern "C" int hpc_dev_tuning_get(int key) {
-  return (key < 0 || key >= 16) ? 0 : tuning().v[key].load(std::memory_order_relaxed);
+  return (key < 0 || key >= Tuning::kKeys) ? 0 : tuning().v[key].load(std::memory_order_relaxed);
 }

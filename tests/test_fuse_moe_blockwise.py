@@ -148,7 +148,7 @@ def test_reduce():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tiled_mode", [2, 3, 12])  # 2: 256x128 ring kernel (12: its 32-token-tile form); 3: 128x128 kernel
+@pytest.mark.parametrize("tiled_mode", [2, 3, 4, 12])  # 2: 256x128 ring kernel (12: its 32-token-tile form); 3: 128x128 kernel; 4: 256x256 kernel
 @pytest.mark.parametrize("n,k", [(512, 1024), (768, 4096), (384, 1408)])
 def test_group_gemm_blockwise_tiled_kernels(tiled_mode, n, k):
     """the MFMA-bound tiled kernels on ragged groups (empty, 1 token, > 128 tokens, > 256 tokens)."""

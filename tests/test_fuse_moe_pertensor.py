@@ -105,7 +105,7 @@ def test_act_mul_and_quant(use_bf16_mul):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tiled_mode", [2, 3, 12])  # 12 = LDS-DMA ring kernel with 32-token tiles
+@pytest.mark.parametrize("tiled_mode", [2, 3, 4, 12])  # 12 = LDS-DMA ring kernel with 32-token tiles; 4 = 256x256 kernel
 @pytest.mark.parametrize("k", [1792, 1088, 192])  # 1088 and 192 end in a half k-block (K % 128 == 64)
 def test_group_gemm_pertensor_tiled_kernels(tiled_mode, k):
     import hpc
