@@ -538,6 +538,78 @@ def extra_router(dev, hpc):
 
 
 # ================================================================================ AllReduce (N >= 1)
+def extra_host_overhead(dev, hpc, calls=200):
+    """EAGER per-call host cost of the hot-path ops (no hipGraph): `enqueue_us` = host wall time per call over
+    `calls` back-to-back calls with nothing waiting on the GPU (torch dispatcher + Python entry + ctypes call +
+    kernel launches), `eager_us` = the same loop including the final synchronize (max of host and GPU).  Shapes
+    are a decode step of 64 requests at a short context, so that the GPU side is shorter than the host side
+    wherever the op allows it."""
+    import time
+
+    out = {}
+    torch.manual_seed(41)
+    B, Hkv, Hq, D, P, ctx = 64, 8, 64, 128, 64, 512
+    f8 = torch.float8_e4m3fn
+
+    def measure(name, fn):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            fn()
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        out[name] = {"enqueue_us": round((t1 - t0) / calls * 1e6, 1), "eager_us": round((t2 - t0) / calls * 1e6, 1)}
+
+    w = dict(C3, batch=B)
+    lens = torch.full((B,), ctx, dtype=torch.int32)
+    inp = c3_inputs(dev, w, lens=lens)
+    tm = hpc.get_attention_decode_task_workspace(B, ctx, Hkv, 64)
+    o = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=dev)
+    measure("assign_attention_decode_task", lambda: hpc.assign_attention_decode_task(inp["kv_lens"], tm, Hkv, 1, True, 64))
+    measure("attention_decode_fp8", lambda: hpc.attention_decode_fp8(
+        inp["q"], inp["k_cache"], inp["v_cache"], inp["block_ids"], inp["kv_lens"], inp["q_scale"], inp["k_scale"],
+        inp["v_scale"], 0, True, hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, True, tm, None, o))
+    nb = ctx // P
+    qb = torch.randn(B, Hq, D, dtype=torch.bfloat16, device=dev)
+    kb = torch.randn(B * nb + 8, P, Hkv, D, dtype=torch.bfloat16, device=dev)
+    vb = torch.randn_like(kb)
+    bid = torch.arange(B * nb, dtype=torch.int32, device=dev).reshape(B, nb)
+    measure("attention_decode_bf16", lambda: hpc.attention_decode_bf16(qb, kb, vb, bid, inp["kv_lens"], 0, True, True, tm, None, o))
+    # rope + KV store (fp8 cache)
+    cs = torch.cat([torch.rand(1024, 64).cos(), torch.rand(1024, 64).sin()], -1).to(dev)
+    qw, kw = torch.rand(D, device=dev) + 0.5, torch.rand(D, device=dev) + 0.5
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * D, dtype=torch.bfloat16, device=dev)
+    kc8 = torch.zeros(B * nb + 8, P, Hkv, D, device=dev).to(f8)
+    vc8 = torch.zeros_like(kc8)
+    qi = torch.arange(0, B + 1, dtype=torch.int32, device=dev)
+    one = torch.ones(1, device=dev)
+    oq8 = torch.empty(B, Hq, D, dtype=f8, device=dev)
+    measure("rope_norm_store_kv_fp8", lambda: hpc.rope_norm_store_kv_fp8(
+        kc8, vc8, qkv, cs, inp["kv_lens"], qi, bid, False, one, one, 1, 1, None, None, qw, kw, oq8, None, None, 1))
+    # norm, router, MoE, sampler
+    hid = torch.randn(B, 4096, dtype=torch.bfloat16, device=dev)
+    wgt = torch.rand(4096, device=dev).to(torch.bfloat16)
+    measure("fused_rmsnorm_with_scale", lambda: hpc.fused_rmsnorm_with_scale(hid, wgt, scale=one))
+    rw = torch.randn(64, 4096, device=dev)
+    wh = rw.to(torch.bfloat16)
+    wl = ((rw - wh.float()) * 256).to(torch.bfloat16)
+    measure("gemm_bf16xfp32", lambda: hpc.gemm_bf16xfp32(hid, wh, wl, 1 / 256, True, True))
+    logits = torch.randn(B, 64, device=dev)
+    measure("topk_router", lambda: hpc.topk_router(logits, 8))
+    wm = dict(C4, num_expert=8, inter=512, hidden=1024)
+    mm = c4_inputs(dev, wm, tokens=B)
+    measure("fuse_moe_blockwise_fp8", lambda: hpc.fuse_moe_blockwise_fp8(
+        mm["x"], mm["x_scale"], mm["guw"], mm["guws"], mm["dw"], mm["dws"], mm["ids"], mm["scale"], 0, 8))
+    lg = torch.randn(B, 32768, device=dev)
+    tk = torch.full((B,), 20, dtype=torch.int32, device=dev)
+    tp = torch.full((B,), 0.9, device=dev)
+    measure("fused_sampler", lambda: hpc.fused_sampler(lg, temperature=0.7, softmax_policy=2, topk=tk, topp=tp, max_topk=32, seed=7))
+    return out
+
+
 def _ar_child(rank, world, local_rank, name, port, q):
     """Fused AllReduce+residual+RMSNorm (BASELINE configs[4], H=8192) in a child process per rank so
     that a failure on an untested fabric cannot take the headline measurement down with it.  Results are
@@ -820,9 +892,10 @@ def main():
                 second = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()
         if not args.no_extras:  # N-independent single-GPU numbers: reported at N=1
-            for fn in (extra_decode, extra_rope, extra_router, extra_sampler, extra_prefill):
+            for fn in (extra_decode, extra_rope, extra_router, extra_sampler, extra_prefill, extra_host_overhead):
                 try:
-                    extras.update(fn(dev, hpc))
+                    r = fn(dev, hpc)
+                    extras.update({"eager_host_overhead": r} if fn is extra_host_overhead else r)
                 except Exception as e:  # noqa: BLE001
                     extras[fn.__name__] = {"error": repr(e)[:200]}
                 torch.cuda.empty_cache()
