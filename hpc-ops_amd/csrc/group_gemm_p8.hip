@@ -23,7 +23,7 @@
 //     section's barrier) and lands two or more sections before its first read; the waits are the constants
 //     vmcnt(9|8) and vmcnt(6);
 //   * the blockwise rescale is software-pipelined by hand: the four FMAs of block n follow the MFMA of
-//     block n+1, the last block's follow the barrier that ends the section;
+//     block n+2, the last two blocks' follow the barrier that ends the section;
 //   * LDS image, source-side XOR swizzle and the K = 128 MFMA operand convention as in
 //     group_gemm_tiled256.hip; 2 x 64 KB + scales = 131 KB of LDS, one workgroup per CU;
 //   * epilogue: neighbouring row blocks are exchanged between lane quarters (v_permlane16_swap) so that a
@@ -124,7 +124,7 @@ __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, co
 }
 
 // kNoDma (development key 18 = 1, timing only - results are wrong): no DMA inside the k-loop
-template <bool kHasXs, bool kNoDma = false>
+template <bool kHasXs, bool kNoDma = false, bool kNoFma = false>
 __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, const int* __restrict__ cu_tiles,
                                                                   int num_group) {
   __shared__ __attribute__((aligned(1024))) uint8_t s_mem[kLds];
@@ -252,14 +252,15 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   };
 
   // One section: 4 row blocks x all 4 token blocks (16 MFMAs), written as the software pipeline it has to be:
-  // the rescale of block n follows the MFMA of block n + 1 (its result is ready by then), `hook(n)` may issue
-  // one DMA piece behind them, and the order is pinned.  Blockwise form: fp32 partial of the 128-k block,
-  // rescaled into the running sum (reference kernels.cuh:473-476); the rescale of the LAST block is the
-  // caller's (`tail`), behind the barrier that ends the section - otherwise that barrier would wait for the last
-  // MFMA's result and the other wave of the SIMD would start its section ~40 cycles late.
+  // the rescale of block n follows the MFMA of block n + 2 (its result is ready by then without wait states: with
+  // one MFMA in between hipcc pads 7-11 idle cycles per MFMA and the matrix pipe is busy 52-55 % of the time),
+  // `hook(n)` may issue one DMA piece behind them, and the order is pinned.  Blockwise form: fp32 partial of the
+  // 128-k block, rescaled into the running sum (reference kernels.cuh:473-476); the rescale of the LAST TWO blocks
+  // is the caller's (`tail`), behind the barrier that ends the section - otherwise that barrier would wait for the
+  // last MFMA's result and the other wave of the SIMD would start its section ~40 cycles late.
   auto section = [&](int i0, const u32x4 (&af)[4][2], const u32x4 (&be)[2][2], const u32x4 (&bl)[2][2],
-                     const float (&f)[4], f32x4& tail, auto&& hook) {
-    f32x4 prev = {0.f, 0.f, 0.f, 0.f};
+                     const float (&f)[4], f32x4 (&tail)[2], auto&& hook) {
+    f32x4 prev1 = {0.f, 0.f, 0.f, 0.f}, prev2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < 16; ++n) {
       const int i = n >> 2, j = n & 3;
@@ -273,13 +274,18 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
       if constexpr (kHasXs) {
         const f32x4 part = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0,
                                                                             0, 0);
-        __builtin_amdgcn_sched_barrier(0);  // MFMA n first, then the rescale of block n - 1
-        if (n > 0) {
-          const int pi = (n - 1) >> 2, pj = (n - 1) & 3;
+        __builtin_amdgcn_sched_barrier(0);  // MFMA n first, then the rescale of block n - 2
+        if (n > 1) {
+          const int pi = (n - 2) >> 2, pj = (n - 2) & 3;
+          if constexpr (kNoFma) {
+            asm volatile("" ::"v"(prev2));  // development: keep the MFMA, drop its rescale
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) tot[i0 + pi][pj][r] = fmaf(prev[r], f[pj], tot[i0 + pi][pj][r]);
+            for (int r = 0; r < 4; ++r) tot[i0 + pi][pj][r] = fmaf(prev2[r], f[pj], tot[i0 + pi][pj][r]);
+          }
         }
-        prev = part;
+        prev2 = prev1;
+        prev1 = part;
       } else {
         // one scale per group: accumulate straight into the running sum, scale once in the epilogue
         // (the reference scales every k-tile: same value up to fp32 rounding)
@@ -289,12 +295,15 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
       hook(n);
       __builtin_amdgcn_sched_barrier(0);
     }
-    tail = prev;
+    tail[0] = prev2;
+    tail[1] = prev1;
   };
-  auto apply_tail = [&](int i0, const float (&f)[4], const f32x4& tail) {
+  auto apply_tail = [&](int i0, const float (&f)[4], const f32x4 (&tail)[2]) {
     if constexpr (kHasXs) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tot[i0 + 3][3][r] = fmaf(tail[r], f[3], tot[i0 + 3][3][r]);
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tot[i0 + 3][2 + t][r] = fmaf(tail[t][r], f[2 + t], tot[i0 + 3][2 + t][r]);
     }
   };
 
@@ -342,7 +351,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   __builtin_amdgcn_sched_barrier(0);
 
   u32x4 a_frag[4][2], b_early[2][2], b_late[2][2];
-  f32x4 tail;
+  f32x4 tail[2];
   auto k_tile = [&](int T, auto par) {
     constexpr int kP = decltype(par)::value;
     const uint8_t* buf = s_mem + kP * kBuf;
@@ -434,6 +443,8 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a, const int* cu_tiles, int num_
   dim3 grid(static_cast<unsigned>(items));
   if (a.has_xs && hpc_dev_tuning_get(18) == 1)
     gemm_fp8_p8_kernel<true, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  else if (a.has_xs && hpc_dev_tuning_get(18) == 2)
+    gemm_fp8_p8_kernel<true, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else if (a.has_xs)
     gemm_fp8_p8_kernel<true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else

@@ -1,7 +1,7 @@
 """Development tool: the two grouped GEMMs of the fused MoE at BASELINE configs[3] timed on their own
 (E64, 32768 routed rows; N=22016/K=4096 and N=4096/K=11008), with the routed group sizes of the bench
 generator and with exactly 512 rows per group (no partial tiles).
-usage: python tools/tune_ggemm.py ["k=v,k=v" ...]   each argument is one configuration of tuning registers"""
+usage: python tools/tune_ggemm.py [--pertensor] ["k=v,k=v" ...]   each argument is one configuration of tuning registers"""
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -9,6 +9,8 @@ sys.path.insert(0, str(ROOT / "hpc-ops_amd")); sys.path.insert(0, str(ROOT))
 import torch, bench, hpc
 from hpc import _C
 dev = torch.device("cuda", 0)
+PT = "--pertensor" in sys.argv
+if PT: sys.argv.remove("--pertensor")
 w = bench.C4
 m_ = bench.c4_inputs(dev, w)
 E, T, topk = w["num_expert"], w["tokens"], w["topk"]
@@ -26,6 +28,9 @@ def case(seqlens, wt, wsc):
     xs_t = torch.rand(k // 128, m_pad, device=dev) + 0.5
     sl, cud = seqlens.to(dev), cu.to(dev)
     out = torch.empty(M, n, dtype=torch.bfloat16, device=dev)
+    ys = torch.rand(E, device=dev) * 0.01 + 0.01
+    if PT:
+        return lambda: hpc.group_gemm_pertensor_fp8(x, wt, sl, cud, ys, num_seq_per_group_avg=avg, output=out), 2.0 * M * n * k
     return lambda: hpc.group_gemm_blockwise_fp8(x, wt, sl, cud, xs_t, wsc, num_seq_per_group_avg=avg, output=out), 2.0 * M * n * k
 cases = []
 for nm, sl in (("routed", routed), ("even512", torch.full((E,), M // E, dtype=torch.int32))):
