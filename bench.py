@@ -350,7 +350,7 @@ def moe_block(dev, hpc, with_cpu=True, iters=10):
         "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": FP8_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(tf / FP8_PEAK_TFLOPS, 4), "traffic": None,
                      "algorithmic_flops_per_launch": flops, "mfma_busy_frac_rocprof": mfma_busy,
-                     "kernel": "whole fused op (hpc::ggemm::gemm_fp8_tiled256_kernel x2 is > 90 % of it), HIP events per call"},
+                     "kernel": "whole fused op (hpc::ggemm::gemm_fp8_p8_kernel<true> x2 is > 90 % of it), HIP events per call"},
         "parity": parity,
         "cpu_baseline": c4_cpu_baseline(m, w) if with_cpu else None,
     }
@@ -936,8 +936,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
                 "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBPS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": nbytes,
-                "kernel": "hpc::decode2::decode2_kernel<2> + decode2_combine_kernel (the step's two launches), HIP events "
-                          "per graph replay / steps per replay",
+                "kernel": "hpc::decode2::decode2_kernel<2> (one launch per step: split requests are merged inside it), HIP "
+                          "events per graph replay / steps per replay",
             },
             "parity": parity,
             "cpu_baseline": cpu,
