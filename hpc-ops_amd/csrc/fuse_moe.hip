@@ -15,6 +15,8 @@
 //    count_and_gather op still produces the reference's gathered / transposed layouts.
 //  * Everything is launched back to back on one stream (hipGraph-capturable, no host sync).
 #include "hpc_common.h"
+#include "group_gemm.h"
+#include "hpc_dev.h"
 #include "../../include/hpc_amd.h"
 
 extern "C" int hpc_group_gemm_blockwise_fp8_async(
@@ -23,6 +25,11 @@ extern "C" int hpc_group_gemm_blockwise_fp8_async(
     const void* row_index_ptr, const void* col_base_ptr, int num_group, int m, int n, int k,
     int num_block_k_pad4, int tile_m, int64_t xscale_row_stride, int64_t xscale_kb_stride,
     const void* cu_tiles128_ptr, hipStream_t stream);
+int hpc_group_gemm_blockwise_fp8_act(void* act_out, void* act_scale, const void* x_ptr, const void* w_ptr,
+                                     const void* seqlens_ptr, const void* cu_seqlens_ptr, const void* xscale_ptr,
+                                     const void* wscale_ptr, const void* row_index_ptr, int num_group, int m, int n,
+                                     int k, int num_block_k_pad4, int64_t xscale_row_stride, int64_t xscale_kb_stride,
+                                     const void* cu_tiles128_ptr, hipStream_t stream);
 
 extern "C" int hpc_group_gemm_pertensor_fp8_async(void* y_ptr, const void* x_ptr, const void* w_ptr,
                                                   const void* seqlens_ptr, const void* cu_seqlens_ptr,
@@ -576,18 +583,29 @@ extern "C" int hpc_fuse_moe_blockwise_async(
                                         ws + w.seqlens, ws + w.cu_seqlens, ws + w.tiles,
                                         ws + w.cu_tiles, ws + w.topk_pos, ws + w.row_index, stream);
   if (rc) return rc;
-  // gate_up: rows come straight from x through row_index, scales from x_scale[token][kb]
-  rc = hpc_group_gemm_blockwise_fp8_async(ws + w.gate_up_out, x_ptr, gate_up_weight_ptr,
-                                          ws + w.seqlens, ws + w.cu_seqlens, x_scale_ptr,
-                                          gate_up_weight_scale_ptr, ws + w.row_index, nullptr,
-                                          num_expert, m, intermediate_size2, hidden_size,
-                                          gate_up_ws_pad4, 16, hidden_size / 128, 1, ws + w.cu_tiles, stream);
-  if (rc) return rc;
-  rc = hpc_act_mul_and_blockwise_quant_async(
-      ws + w.down_in, ws + w.down_in_scale, ws + w.gate_up_out,
-      reinterpret_cast<const int*>(ws + w.cu_seqlens) + num_expert, m, inter, inter / 128, 1, nullptr,
-      stream);
-  if (rc) return rc;
+  // gate_up: rows come straight from x through row_index, scales from x_scale[token][kb].  With the 256 x 256 tile
+  // kernel the activation + quantisation runs in the GEMM's epilogue (a tile = 128 gate rows + the 128 up rows of
+  // the same columns) and the bf16 gate-up matrix is never written (development key 19 = 1: keep them apart)
+  if ((inter & 127) == 0 && hpc_dev_tuning_get(19) != 1 &&
+      hpc_ggemm_p8_selected(num_expert, m, intermediate_size2, hidden_size, ws + w.cu_tiles)) {
+    rc = hpc_group_gemm_blockwise_fp8_act(ws + w.down_in, ws + w.down_in_scale, x_ptr, gate_up_weight_ptr,
+                                          ws + w.seqlens, ws + w.cu_seqlens, x_scale_ptr, gate_up_weight_scale_ptr,
+                                          ws + w.row_index, num_expert, m, intermediate_size2, hidden_size,
+                                          gate_up_ws_pad4, hidden_size / 128, 1, ws + w.cu_tiles, stream);
+    if (rc) return rc;
+  } else {
+    rc = hpc_group_gemm_blockwise_fp8_async(ws + w.gate_up_out, x_ptr, gate_up_weight_ptr,
+                                            ws + w.seqlens, ws + w.cu_seqlens, x_scale_ptr,
+                                            gate_up_weight_scale_ptr, ws + w.row_index, nullptr,
+                                            num_expert, m, intermediate_size2, hidden_size,
+                                            gate_up_ws_pad4, 16, hidden_size / 128, 1, ws + w.cu_tiles, stream);
+    if (rc) return rc;
+    rc = hpc_act_mul_and_blockwise_quant_async(
+        ws + w.down_in, ws + w.down_in_scale, ws + w.gate_up_out,
+        reinterpret_cast<const int*>(ws + w.cu_seqlens) + num_expert, m, inter, inter / 128, 1, nullptr,
+        stream);
+    if (rc) return rc;
+  }
   rc = hpc_group_gemm_blockwise_fp8_async(ws + w.down_out, ws + w.down_in, down_weight_ptr,
                                           ws + w.seqlens, ws + w.cu_seqlens, ws + w.down_in_scale,
                                           down_weight_scale_ptr, nullptr, nullptr, num_expert, m,

@@ -21,6 +21,11 @@ struct Args {
   int has_xs;                                           // 0: no activation scales (factor 1)
   unsigned x_bytes;                                     // bytes of x (bounds the activation loads)
   long xs_row_stride, xs_kb_stride;                     // in floats
+  // fused SiLU(gate) * up + 128-block quantisation in the epilogue of the gate-up GEMM (256 x 256 tile kernel only;
+  // N = 2 * inter, a tile = 128 gate rows + the 128 up rows of the same columns): act_out e4m3 [M, inter],
+  // act_scale f32 [M, inter / 128]; y is not written
+  uint8_t* act_out = nullptr;
+  float* act_scale = nullptr;
 };
 
 }  // namespace ggemm
@@ -34,3 +39,5 @@ int hpc_ggemm_launch_tiled256(const hpc::ggemm::Args& a, const int* cu_tiles, in
 // 256 x 256 tile, staggered wave groups (group_gemm_p8.hip); derives its 256-token tiles from the same scan
 int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a, const int* cu_tiles, int num_group, int m, int n,
                         hipStream_t stream);
+// would launch_stream_gemm pick the 256 x 256 kernel for this problem? (the fused MoE asks before it fuses)
+bool hpc_ggemm_p8_selected(int num_group, int m, int n, int k, const void* cu_tiles128);

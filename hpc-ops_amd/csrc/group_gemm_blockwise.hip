@@ -241,6 +241,11 @@ __global__ __launch_bounds__(64 * kWaves, (kWaves == 8 || kMT * kR >= 8) ? 1 : 2
 }  // namespace ggemm
 }  // namespace hpc
 
+bool hpc_ggemm_p8_selected(int num_group, int m, int n, int k, const void* cu_tiles128) {
+  const int tiled_mode = hpc_dev_tuning_get(3);
+  return cu_tiles128 && n % 256 == 0 && k >= 128 && (tiled_mode == 4 || (tiled_mode == 0 && m / num_group >= 192));
+}
+
 namespace {
 int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const void* cu_tiles128,
                        hipStream_t stream) {
@@ -253,7 +258,7 @@ int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const v
   const int tiled_mode = hpc_dev_tuning_get(3);
   if (cu_tiles128 && n % 128 == 0 && tiled_mode != 1 && (tiled_mode >= 2 || m / num_group > 40)) {
     // 256-token tiles from ~192 tokens per group on: below that most of a second half-tile would be padding
-    if (n % 256 == 0 && a.K >= 128 && (tiled_mode == 4 || (tiled_mode == 0 && m / num_group >= 192)))
+    if (hpc_ggemm_p8_selected(num_group, m, n, a.K, cu_tiles128))
       return hpc_ggemm_launch_p8(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);
     if (n % 256 == 0 && a.K >= 128 && tiled_mode != 3)
       return hpc_ggemm_launch_tiled256(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);
@@ -368,4 +373,40 @@ extern "C" int hpc_group_gemm_pertensor_fp8_async(void* y_ptr, const void* x_ptr
   a.xs_row_stride = 0;
   a.xs_kb_stride = 0;
   return launch_stream_gemm(a, num_group, m, n, cu_tiles128_ptr, stream);
+}
+
+// Gate-up GEMM of the fused MoE with SiLU(gate) * up + 128-block quantisation in its epilogue (256 x 256 tile kernel;
+// the caller has checked hpc_ggemm_p8_selected and inter % 128 == 0).  Same arguments as
+// hpc_group_gemm_blockwise_fp8_async with n = 2 * inter; writes act_out e4m3 [m, inter] and act_scale f32 [m, inter/128].
+int hpc_group_gemm_blockwise_fp8_act(void* act_out, void* act_scale, const void* x_ptr, const void* w_ptr,
+                                     const void* seqlens_ptr, const void* cu_seqlens_ptr, const void* xscale_ptr,
+                                     const void* wscale_ptr, const void* row_index_ptr, int num_group, int m, int n,
+                                     int k, int num_block_k_pad4, int64_t xscale_row_stride, int64_t xscale_kb_stride,
+                                     const void* cu_tiles128_ptr, hipStream_t stream) {
+  using namespace hpc::ggemm;
+  if (static_cast<int64_t>(m) * k > 0xfffffe00ll || static_cast<int64_t>(n) * k > 0xfffffe00ll) return HPC_ERR_UNSUPPORTED;
+  Args a;
+  a.x = static_cast<const uint8_t*>(x_ptr);
+  a.w = static_cast<const uint8_t*>(w_ptr);
+  a.xs = static_cast<const float*>(xscale_ptr);
+  a.ws = static_cast<const float*>(wscale_ptr);
+  a.y = nullptr;
+  a.seqlens = static_cast<const int*>(seqlens_ptr);
+  a.cu_seqlens = static_cast<const int*>(cu_seqlens_ptr);
+  a.row_index = static_cast<const int*>(row_index_ptr);
+  a.col_base = nullptr;
+  a.N = n;
+  a.K = k;
+  a.KB = k / 128;
+  a.tile_m = 16;
+  a.ws_group_stride = (n / 128) * num_block_k_pad4;
+  a.ws_ntile_stride = num_block_k_pad4;
+  a.ws_kb_stride = 1;
+  a.has_xs = 1;
+  a.x_bytes = 0xfffffe00u;
+  a.xs_row_stride = xscale_row_stride;
+  a.xs_kb_stride = xscale_kb_stride;
+  a.act_out = static_cast<uint8_t*>(act_out);
+  a.act_scale = static_cast<float*>(act_scale);
+  return hpc_ggemm_launch_p8(a, static_cast<const int*>(cu_tiles128_ptr), num_group, m, n, stream);
 }

@@ -124,7 +124,9 @@ __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, co
 }
 
 // kNoDma (development key 18 = 1, timing only - results are wrong): no DMA inside the k-loop
-template <bool kHasXs, bool kNoDma = false, bool kNoFma = false>
+// kAct: the gate-up GEMM of the fused MoE - a tile is 128 gate rows (wave group 0) + the 128 up rows of the same
+// columns (group 1); the epilogue applies SiLU(gate) * up and the 128-block quantisation instead of storing y
+template <bool kHasXs, bool kNoDma = false, bool kNoFma = false, bool kAct = false>
 __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, const int* __restrict__ cu_tiles,
                                                                   int num_group) {
   __shared__ __attribute__((aligned(1024))) uint8_t s_mem[kLds];
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   const int r16 = lane & 15, g4 = lane >> 4;
   const int wn = wave >> 2, wm = wave & 3;  // group (weight-row half) / 64-token strip
 
-  const int nt = a.N / kBN;
+  const int nt = a.N / kBN;  // kAct: N = 2 * inter, tile tn = columns [tn * 128, +128) of gate and of up
   const Item it = locate_item(as_const(cu_tiles), a.seqlens, a.cu_seqlens, num_group, nt, lane, blockIdx.x);
   if (!it.valid) return;
   const int e = __builtin_amdgcn_readfirstlane(it.e);
@@ -151,14 +153,17 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   // chunk (lane%8) ^ (lane/8).  Unit rows: weights  ur -> n = (ur/64)*128 + ur%64 (+64 for U3);
   // tokens ur -> slot (ur/32)*64 + ur%32 (+32 for U2).
   const int p_row = lane >> 3, p_chunk = (lane & 7) ^ (lane >> 3);
-  const uint8_t* wsrc = a.w + (static_cast<long>(e) * a.N + n0) * K;
-  const unsigned w_bytes = static_cast<unsigned>(kBN) * static_cast<unsigned>(K);
+  const int inter = a.N >> 1;      // kAct only
+  const int col0 = n0 >> 1;        // kAct only: first activation column of the tile
+  const uint8_t* wsrc = a.w + (static_cast<long>(e) * a.N + (kAct ? 0 : n0)) * K;
+  const unsigned w_bytes = static_cast<unsigned>(kAct ? a.N : kBN) * static_cast<unsigned>(K);
   const int late_w = 64 * K;  // byte distance of the U3 rows from the U0 rows
   unsigned w_voff[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int ur = (wave * 2 + q) * 8 + p_row;
-    w_voff[q] = static_cast<unsigned>((ur >> 6) * 128 + (ur & 63)) * static_cast<unsigned>(K) + p_chunk * 16;
+    const int wrow = kAct ? (ur >> 6) * inter + col0 + (ur & 63) : (ur >> 6) * 128 + (ur & 63);
+    w_voff[q] = static_cast<unsigned>(wrow) * static_cast<unsigned>(K) + p_chunk * 16;
   }
   // k-tile T -> buffer T & 1 (`par`, a compile-time value).  Past the end: empty descriptors (nothing fetched,
   // zeros written, still counted by vmcnt).  One piece (q = 0, 1) per call.
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   };
 
   const cint_ptr ws_row = as_const(reinterpret_cast<const int*>(a.ws)) + static_cast<long>(e) * a.ws_group_stride +
-                          ((n0 + wn * 128) >> 7) * a.ws_ntile_stride;
+                          ((kAct ? wn * inter + col0 : n0 + wn * 128) >> 7) * a.ws_ntile_stride;
 
   f32x4 tot[8][4];
 #pragma unroll
@@ -410,6 +415,80 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
 #pragma unroll
       for (int j = 0; j < 4; ++j) tot[i][j] *= gs;
   }
+  if constexpr (kAct) {
+    // ---- fused activation epilogue ------------------------------------------------------------------------------
+    // Wave (group 0, strip s) holds the gate values and wave (group 1, strip s) the up values of the same 128
+    // columns x 64 tokens, in the same lane <-> (column, token) mapping.  They swap halves through LDS (a
+    // lane-linear 8-byte slot per block, bf16-rounded like the GEMM output the separate kernel would read): group
+    // 0 finishes token blocks 0-1, group 1 token blocks 2-3.  a = silu(g) * u in fp32, abs-max over the tile's 128
+    // columns per token (32 values in the lane, 4 lanes per token), scale = amax / 448, q = e4m3(a / (scale + 1e-8)) -
+    // the arithmetic of act_mul_blockwise_quant_kernel (reference src/activation/activation.cu:282-355), bit for bit.
+    __builtin_amdgcn_s_barrier();  // every wave is past its last LDS read and its last (empty) DMA has landed
+    uint32_t* xch = reinterpret_cast<uint32_t*>(s_mem) + (wm * 16 * 64 + lane) * 2;  // [strip][i * 2 + jj][lane] of 8 B
+    auto send = [&](auto j0c) {  // the two token blocks the OTHER group finishes
+      constexpr int j0 = decltype(j0c)::value;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          *reinterpret_cast<u32x2*>(xch + (i * 2 + jj) * 128) =
+              u32x2{pack_bf16x2(tot[i][j0 + jj][0], tot[i][j0 + jj][1]), pack_bf16x2(tot[i][j0 + jj][2], tot[i][j0 + jj][3])};
+    };
+    auto finish = [&](auto j0c, auto mine_is_gate) {
+      constexpr int j0 = decltype(j0c)::value;
+      constexpr bool kGate = decltype(mine_is_gate)::value;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int j = j0 + jj;
+        const int slot = mt0 + wm * 64 + j * 16 + r16;
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const u32x2 ov = *reinterpret_cast<const u32x2*>(xch + (i * 2 + jj) * 128);
+          const uint32_t m01 = pack_bf16x2(tot[i][j][0], tot[i][j][1]), m23 = pack_bf16x2(tot[i][j][2], tot[i][j][3]);
+          const float mine[4] = {bf16lo_to_f32(m01), bf16hi_to_f32(m01), bf16lo_to_f32(m23), bf16hi_to_f32(m23)};
+          const float oth[4] = {bf16lo_to_f32(ov[0]), bf16hi_to_f32(ov[0]), bf16lo_to_f32(ov[1]), bf16hi_to_f32(ov[1])};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float g = kGate ? mine[r] : oth[r], u = kGate ? oth[r] : mine[r];
+            const float v = g / (1.0f + __expf(-g)) * u;
+            tot[i][j][r] = v;
+            amax = fmaxf(amax, fabsf(v));
+          }
+        }
+        // the token's other 96 columns sit in lanes r16 + 16, + 32, + 48
+        amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        const float scale = amax / 448.0f;
+        const float inv = 1.0f / (scale + 1e-8f);
+        if (slot < m_cnt) {
+          uint8_t* orow = a.act_out + static_cast<long>(m0 + slot) * inter + col0 + g4 * 4;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<uint32_t*>(orow + i * 16) =
+                quant_4xe4m3(tot[i][j][0] * inv, tot[i][j][1] * inv, tot[i][j][2] * inv, tot[i][j][3] * inv);
+          if (g4 == 0) a.act_scale[static_cast<long>(m0 + slot) * (inter >> 7) + (col0 >> 7)] = scale;
+        }
+      }
+    };
+    // group 0 sends its gate values of token blocks 2-3 into the first 32 KB, group 1 its up values of blocks 0-1
+    // into the second; each then reads the other's region
+    if (wn == 0) {
+      send(IntC<2>{});
+    } else {
+      xch += 4 * 16 * 64 * 2;
+      send(IntC<0>{});
+    }
+    __syncthreads();
+    if (wn == 0) {
+      xch += 4 * 16 * 64 * 2;
+      finish(IntC<0>{}, IntC<1>{});
+    } else {
+      xch -= 4 * 16 * 64 * 2;
+      finish(IntC<2>{}, IntC<0>{});
+    }
+    return;
+  }
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // A lane holds rows n = wn*128 + i*16 + g4*4 + r of token slot wm*64 + j*16 + r16: 8 bytes of the token's output
   // row per block.  v_permlane16_swap on the blocks i, i+1 hands lane quarter q the 8 rows [(q&2)*4, +8) of block
@@ -441,7 +520,9 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a, const int* cu_tiles, int num_
   const long items = max_tiles * (n / kBN) + 8;  // + 8: the per-XCD chunks round up
   if (items > 0x7fffffffl) return HPC_ERR_UNSUPPORTED;
   dim3 grid(static_cast<unsigned>(items));
-  if (a.has_xs && hpc_dev_tuning_get(18) == 1)
+  if (a.has_xs && a.act_out)
+    gemm_fp8_p8_kernel<true, false, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  else if (a.has_xs && hpc_dev_tuning_get(18) == 1)
     gemm_fp8_p8_kernel<true, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else if (a.has_xs && hpc_dev_tuning_get(18) == 2)
     gemm_fp8_p8_kernel<true, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);

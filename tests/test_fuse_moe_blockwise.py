@@ -53,6 +53,34 @@ def test_fuse_moe_blockwise_fp8(num_tokens, inter, rank_ep, size_ep, shared):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("num_tokens,num_expert,num_topk,hidden,inter", [(600, 4, 2, 512, 256), (257, 2, 2, 1024, 384),
+                                                                         (1500, 8, 4, 512, 128)])
+def test_fused_activation_epilogue(num_tokens, num_expert, num_topk, hidden, inter):
+    """long groups (>= 192 rows per expert): the gate-up GEMM runs on the 256 x 256 tile kernel with SiLU * up +
+    128-block quantisation in its epilogue.  Bit-equal to the same kernel followed by the separate activation
+    kernel (development key 19 = 1), and within the reference tolerance of the oracle; ragged groups (a few rows,
+    one row past a 256-row tile) come from the random routing."""
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    args = _inputs(num_tokens, num_topk, hidden, inter, num_expert, 1, False, seed=5)
+    x, x_scale, guw, guws, dw, dws, topk_ids, topk_scale, _ = args
+    assert num_tokens * num_topk // num_expert >= 192
+    gt = omoe.fuse_moe_blockwise_fp8(x, x_scale, guw, guws, dw, dws, topk_ids, topk_scale, 0, num_expert, None)
+    dev = [t.cuda() if t is not None else None for t in args]
+    run = lambda: hpc.fuse_moe_blockwise_fp8(dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], dev[6], dev[7], 0, num_expert)
+    fused = run()
+    hpc._C.lib.hpc_dev_tuning_set(19, 1)
+    try:
+        apart = run()
+        torch.cuda.synchronize()
+    finally:
+        hpc._C.lib.hpc_dev_tuning_set(19, 0)
+    assert torch.equal(fused, apart)
+    assert allclose(gt.float(), fused.cpu().float(), rtol=0.01, atol=0.01)
+
+
+@pytest.mark.gpu
 def test_moe_routing_is_bit_exact():
     """routing indices must be bit-exact (BASELINE north_star): compare the device prep with the
     oracle's stable slotting through the C-ABI."""
