@@ -250,13 +250,14 @@ namespace {
 int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const void* cu_tiles128,
                        hipStream_t stream) {
   using namespace hpc::ggemm;
-  // groups above ~40 tokens: tiled kernels (need the scan of ceil(seqlens/128)): the 256 x 128 LDS-DMA ring
-  // kernel when n allows (one pass over the weights for up to 128 tokens; measured faster than the
-  // streaming form from ~40 tokens per group on), else the 128 x 128 register-staged one
+  // groups above ~20 tokens: tiled kernels (need the scan of ceil(seqlens/128)): the 256 x 128 LDS-DMA ring
+  // kernel when n allows (one pass over the weights for up to 128 tokens, 100 KB in flight per CU without
+  // staging registers; measured on E64 / top-8: T = 128 (16 per group) 1.61 vs 1.50 ms for the streaming form,
+  // T = 192 1.63 vs 1.79, T = 256 1.73 vs 1.85, T = 384 1.75 ms), else the 128 x 128 register-staged one
   // development key 3: 0 auto, 1 never tiled, 2 always 256 x 128 (when possible), 3 always 128 x 128,
   // 4 always 256 x 256 (when possible)
   const int tiled_mode = hpc_dev_tuning_get(3);
-  if (cu_tiles128 && n % 128 == 0 && tiled_mode != 1 && (tiled_mode >= 2 || m / num_group > 40)) {
+  if (cu_tiles128 && n % 128 == 0 && tiled_mode != 1 && (tiled_mode >= 2 || m / num_group > 20)) {
     // 256-token tiles from ~192 tokens per group on: below that most of a second half-tile would be padding
     if (hpc_ggemm_p8_selected(num_group, m, n, a.K, cu_tiles128))
       return hpc_ggemm_launch_p8(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);

@@ -56,7 +56,7 @@ struct TileCfg {
   static constexpr int kIN = kBN / kWN / 16;         // 16-row blocks per wave
   static constexpr int kJN = kTok / kWM / 16;        // 16-token blocks per wave
   static constexpr int kXBytes = kTok * kBK;
-  static constexpr int kStages = kTok == 128 ? 3 : 4;
+  static constexpr int kStages = kTok >= 64 ? 3 : 4;
   static constexpr int kStageBytes = kWBytes + kXBytes + kXsBytes;
   static constexpr int kXQ = kTok == 128 ? 2 : 1;    // activation DMA pieces per wave (8 rows each)
   static constexpr int kXPieces = kTok / 8;
@@ -373,15 +373,20 @@ int hpc_ggemm_launch_tiled256(const hpc::ggemm::Args& a, const int* cu_tiles, in
   // group; measured it is SLOWER (E64: 3.6 ms vs 2.2 ms at T = 256 .. 768) - its extra token tiles re-read
   // the weight tile through L2 and do a quarter of the MFMA work per slab - so it only runs on request.
   const bool narrow = hpc_dev_tuning_get(6) == 2;
+  // 64-token tiles (8 x 1 waves of 32 x 64, 42 KB per slab, three slabs in the ring) - also measured SLOWER than
+  // the 128-token tile on groups of 24-64 rows (E64: T = 256 2.19 vs 1.73 ms, T = 384 2.25 vs 1.75 ms): on request only
+  const bool half = hpc_dev_tuning_get(6) == 3;
   const long max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 128)
-  const long items = max_tiles * (n / kBN) * (narrow ? 4 : 1) + 8;  // + 8: the per-XCD chunks round up
+  const long items = max_tiles * (n / kBN) * (narrow ? 4 : (half ? 2 : 1)) + 8;  // + 8: the per-XCD chunks round up
   if (items > 0x7fffffffl) return HPC_ERR_UNSUPPORTED;
   dim3 grid(static_cast<unsigned>(items));
   if (a.has_xs) {
     if (narrow) gemm_fp8_tiled256_kernel<true, 32><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+    else if (half) gemm_fp8_tiled256_kernel<true, 64><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
     else gemm_fp8_tiled256_kernel<true, 128><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   } else {
     if (narrow) gemm_fp8_tiled256_kernel<false, 32><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+    else if (half) gemm_fp8_tiled256_kernel<false, 64><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
     else gemm_fp8_tiled256_kernel<false, 128><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   }
   HPC_CHECK_LAUNCH();

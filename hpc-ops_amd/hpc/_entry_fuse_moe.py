@@ -43,7 +43,7 @@ def _cu_tiles128(seqlens, m, num_group, stream):
     """Scan of ceil(seqlens/128) for the tiled (large-group) GEMM kernel; None keeps the streaming one.
     Returns the TENSOR: the caller keeps it referenced until its GEMM launch has been enqueued (a raw pointer
     into a tensor that died at return would only be safe by grace of the caching allocator's stream ordering)."""
-    if m // max(num_group, 1) <= 40:
+    if m // max(num_group, 1) <= 20:
         return None
     tiles = torch.empty(num_group, dtype=torch.int32, device=seqlens.device)
     cu = torch.empty(num_group + 1, dtype=torch.int32, device=seqlens.device)

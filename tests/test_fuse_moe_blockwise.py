@@ -176,7 +176,7 @@ def test_reduce():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tiled_mode", [2, 3, 4, 12])  # 2: 256x128 ring kernel (12: its 32-token-tile form); 3: 128x128 kernel; 4: 256x256 kernel
+@pytest.mark.parametrize("tiled_mode", [2, 3, 4, 12, 22])  # 2: 256x128 ring kernel (12: its 32-token-tile form); 3: 128x128 kernel; 4: 256x256 kernel
 @pytest.mark.parametrize("n,k", [(512, 1024), (768, 4096), (384, 1408)])
 def test_group_gemm_blockwise_tiled_kernels(tiled_mode, n, k):
     """the MFMA-bound tiled kernels on ragged groups (empty, 1 token, > 128 tokens, > 256 tokens)."""
@@ -202,7 +202,7 @@ def test_group_gemm_blockwise_tiled_kernels(tiled_mode, n, k):
         c0 = int(cu_tiles[g]) * tile_m
         xs_t[:, c0 : c0 + int(seqlens[g])] = xs_rows[int(cu[g]) : int(cu[g]) + int(seqlens[g])].t()
     hpc._C.lib.hpc_dev_tuning_set(3, tiled_mode % 10)
-    hpc._C.lib.hpc_dev_tuning_set(6, 2 if tiled_mode >= 10 else 1)
+    hpc._C.lib.hpc_dev_tuning_set(6, 1 + tiled_mode // 10)  # 1x: 32-token tiles, 2x: 64-token tiles
     try:
         my = hpc.group_gemm_blockwise_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), xs_t.cuda(), wscale.cuda(),
                                           num_seq_per_group_avg=avg)

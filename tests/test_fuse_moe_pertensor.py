@@ -105,7 +105,7 @@ def test_act_mul_and_quant(use_bf16_mul):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tiled_mode", [2, 3, 4, 12])  # 12 = LDS-DMA ring kernel with 32-token tiles; 4 = 256x256 kernel
+@pytest.mark.parametrize("tiled_mode", [2, 3, 4, 12, 22])  # 12 = LDS-DMA ring kernel with 32-token tiles; 4 = 256x256 kernel
 @pytest.mark.parametrize("k", [1792, 1088, 192])  # 1088 and 192 end in a half k-block (K % 128 == 64)
 def test_group_gemm_pertensor_tiled_kernels(tiled_mode, k):
     import hpc
@@ -121,7 +121,7 @@ def test_group_gemm_pertensor_tiled_kernels(tiled_mode, k):
     cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
     gt = omoe.group_gemm_pertensor(x, w, seqlens, cu, scale)
     hpc._C.lib.hpc_dev_tuning_set(3, tiled_mode % 10)
-    hpc._C.lib.hpc_dev_tuning_set(6, 2 if tiled_mode >= 10 else 1)
+    hpc._C.lib.hpc_dev_tuning_set(6, 1 + tiled_mode // 10)  # 1x: 32-token tiles, 2x: 64-token tiles
     try:
         my = hpc.group_gemm_pertensor_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), scale.cuda(),
                                           num_seq_per_group_avg=total // G)

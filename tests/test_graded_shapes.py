@@ -176,7 +176,7 @@ def test_c4_fused_moe_graded_shape(c4_weights, num_tokens, shared):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,k", [(4096, 11008), (22016, 4096)])
-@pytest.mark.parametrize("tiled_mode", [0, 1, 2, 3, 4, 12])
+@pytest.mark.parametrize("tiled_mode", [0, 1, 2, 3, 4, 12, 22])
 def test_c4_group_gemm_blockwise_graded(c4_weights, n, k, tiled_mode):
     """group_gemm_blockwise_fp8 on the two GEMMs of the graded configuration (down: K = 11008 = 86 k-blocks with
     the pad-4 scale stride 88; gate_up: N = 22016), 64 ragged groups incl. empty / 1 / 129 / 257 / 700 rows, for
@@ -205,7 +205,7 @@ def test_c4_group_gemm_blockwise_graded(c4_weights, n, k, tiled_mode):
         s, c = int(cu[g]), int(seqlens[g])
         xs_t[:, int(cu_tiles[g]) * tile: int(cu_tiles[g]) * tile + c] = xs_rows[s: s + c].t()
     hpc._C.lib.hpc_dev_tuning_set(3, tiled_mode % 10)
-    hpc._C.lib.hpc_dev_tuning_set(6, 2 if tiled_mode >= 10 else 1)
+    hpc._C.lib.hpc_dev_tuning_set(6, 1 + tiled_mode // 10)  # 1x: 32-token tiles, 2x: 64-token tiles
     try:
         y = hpc.group_gemm_blockwise_fp8(x.cuda(), w, seqlens.cuda(), cu.cuda(), xs_t.cuda(), wsc,
                                          num_seq_per_group_avg=avg)

@@ -99,7 +99,24 @@ def main():
     decode_case("C3_fp8_loguniform_128_32k_x64_h8_64_HND", logu, 8, 64, "HND", True, 512)
     # ---- C4: fused MoE blockwise ----
     toks = (4, 16, 64, 128, 256, 1024, 4096) if not quick else (16, 256)
-    out.update(bench.extra_moe(dev, hpc, tokens=toks))
+    wc = bench.C4
+    base = bench.c4_inputs(dev, wc, tokens=4)
+    res = {}
+    for T in toks:
+        ml = bench.c4_inputs(dev, wc, tokens=T)
+        for kk in ("guw", "guws", "dw", "dws"):
+            ml[kk] = base[kk]
+        us = bench.timed(lambda: hpc.fuse_moe_blockwise_fp8(ml["x"], ml["x_scale"], ml["guw"], ml["guws"], ml["dw"], ml["dws"],
+                                                           ml["ids"], ml["scale"], 0, wc["num_expert"]), iters=10, warm=2)
+        hit = int(torch.unique(ml["ids"]).numel())
+        wbytes = hit * 3 * wc["inter"] * wc["hidden"]
+        res[f"T{T}"] = {"us": round(us, 1), "TFLOPS": round(bench.c4_flops(T, wc) / us / 1e6, 1),
+                        "weight_GBps": round(wbytes / us / 1e3, 1), "hbm_frac": round(wbytes / us / 1e3 / HBM, 3),
+                        "frac_of_5PF": round(bench.c4_flops(T, wc) / us / 1e6 / 5000, 4)}
+        print("fuse_moe_blockwise_fp8", T, res[f"T{T}"], flush=True)
+    out["fuse_moe_blockwise_fp8_E64_top8_H4096_I11008"] = res
+    del base, ml
+    torch.cuda.empty_cache()
     # ---- C4': the per-tensor fused MoE API the reference's benchmark driver calls (same GEMM kernels) ----
     E, k, H, I = 64, 8, 4096, 11008
     torch.manual_seed(41)
@@ -130,7 +147,7 @@ def main():
         print(nm, out[nm], flush=True)
     # ---- widening rows ----
     out.update(bench.extra_rope(dev, hpc))
-    out.update(bench.extra_router_gemm(dev, hpc))
+    out.update(bench.extra_router(dev, hpc))
     out.update(bench.extra_sampler(dev, hpc))
     out.update(bench.extra_prefill(dev, hpc))
     Path(ROOT / "gpurun_out").mkdir(exist_ok=True)
