@@ -31,6 +31,7 @@
 //    O = sum(P~ V) / sum(p) * vscale / 256.
 #include <type_traits>
 
+#define HPC_SOFT_BF16_PACK 1
 #include "hpc_common.h"
 #include "hpc_dev.h"
 #include "../../include/hpc_amd.h"
