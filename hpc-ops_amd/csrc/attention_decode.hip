@@ -787,6 +787,7 @@ extern "C" int hpc_attention_decode_fp8_async(
     b.qscale_stride = qscale_pad_stride;
     b.new_kv_included = new_kv_included;
     b.dev_nomem = hpc_dev_tuning_get(15);
+    b.min_range_cost = hpc_dev_tuning_get(20) > 0 ? hpc_dev_tuning_get(20) : 8;  // development key 20 overrides (15 x 64 + 1 x 16k tokens: 87 us without a floor, 47 / 49 / 61 / 105 us at 8 / 16 / 32 / 64)
     b.in_kernel_combine = hpc_dev_tuning_get(17) == 2 ? 0 : 1;  // key 17 = 2: merge split requests in a second kernel
     b.k_block_stride = kcache_block_stride;
     b.k_token_stride = kcache_token_stride;

@@ -25,6 +25,7 @@ struct Args {
   int ldq, ldy, qscale_stride, new_kv_included;
   int epoch;              // 1..32767, tags the arrival counters of this launch
   int in_kernel_combine;  // 1: the last-arriving chunk of a split request merges it; 0: second kernel
+  int min_range_cost;  // smallest range of the in-kernel plan, in cost units (64-token tiles + 2 per request)
   int dev_nomem;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing; results are wrong)
   long k_block_stride, k_token_stride;  // bytes
   long v_block_stride, v_token_stride;

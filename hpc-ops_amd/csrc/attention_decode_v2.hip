@@ -228,7 +228,11 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   // The grid is a multiple of npair (launcher).
   const int nrange = nwg / npair;
   const int rng = wg / npair;
-  const int per = (Th + nrange - 1) / nrange;
+  // a range is never smaller than min_range_cost: a batch with little work (one long request among a few short
+  // ones) runs on fewer workgroups instead of being cut into one-tile chunks that the last arriver of the long
+  // request has to merge one by one (15 x 64 + 1 x 16k tokens: 87-99 us with 128 ranges per pair, 47 us with a floor of 8)
+  const int per_even = (Th + nrange - 1) / nrange;
+  const int per = per_even > a.min_range_cost ? per_even : a.min_range_cost;
   const long g_begin = static_cast<long>(rng) * per;
   const long g_end = g_begin + per < Th ? g_begin + per : Th;
   if (g_begin >= g_end) return;

@@ -22,7 +22,9 @@ def run(lens_c, heads=(8, 64), graph=True):
 mixed = bench.c3_lens()
 cases = (("uniform8k", torch.full((B,), 8192, dtype=torch.int32)), ("mixed", mixed),
          ("skewed_mix", torch.tensor([128] * 32 + [4096] * 32, dtype=torch.int32)),
-         ("uniform512", torch.full((B,), 512, dtype=torch.int32)))
+         ("uniform512", torch.full((B,), 512, dtype=torch.int32)),
+         ("extreme", torch.tensor([64] * 15 + [16384] + [0] * 48, dtype=torch.int32)),
+         ("one64k", torch.tensor([65536] + [4096] * 31 + [0] * 32, dtype=torch.int32)))
 configs = sys.argv[1:] or ["12=1", ""]
 for cfg in configs:
     pairs = [tuple(int(x) for x in kv.split("=")) for kv in cfg.split(",") if kv]
