@@ -204,14 +204,6 @@ def c3_bytes(kv_lens, w=C3):
     return int(kv_lens.sum()) * w["num_head_kv"] * 2 * w["head_dim"] + rows * (w["head_dim"] * 3 + 4)
 
 
-def c3_sample_rows(kv_lens, n=6):
-    """bounded request sample for the in-run parity check and the CPU baseline: the shortest and the
-    longest request plus evenly spaced ranks of the length distribution"""
-    order = torch.argsort(kv_lens.cpu()).tolist()
-    picks = sorted({order[round(i * (len(order) - 1) / (n - 1))] for i in range(n)})
-    return picks
-
-
 def c3_cpu_baseline(inp, w=C3, rows=None):
     """The reference's PyTorch-eager fp8 oracle (oracle/attention.py::ref_attn_fp8_separate, restating
     tests/test_attention_decode_qpertoken_perhead_kvpertensor_fp8.py:14-79) timed on the host cores over a
@@ -220,7 +212,8 @@ def c3_cpu_baseline(inp, w=C3, rows=None):
 
     cores = min(os.cpu_count() or 1, 32)  # more threads than this only adds contention for this op
     torch.set_num_threads(cores)
-    rows = c3_sample_rows(inp["kv_lens"]) if rows is None else rows
+    rows = list(range(w["batch"])) if rows is None else rows  # every request: ~5 s on 32 threads, and the parity
+    # check of the timed output covers the whole batch
     c = {k: v.cpu() for k, v in inp.items()}
     args = (c["q"], c["k_cache"], c["v_cache"], c["block_ids"], c["kv_lens"], w["num_seq_q"], c["q_scale"],
             c["k_scale"], c["v_scale"])
@@ -234,7 +227,7 @@ def c3_cpu_baseline(inp, w=C3, rows=None):
         "value": round(nbytes / dt / 1e9, 3), "unit": "GB/s", "cores": cores, "kind": "port",
         "us_per_call_equivalent": round(dt * 1e6 * int(c["kv_lens"].sum()) / max(tok, 1), 1),
         "sample": f"{len(rows)} of {w['batch']} requests of the same workload ({tok} of {int(c['kv_lens'].sum())} "
-                  f"KV tokens: shortest, longest and evenly spaced ranks), PyTorch-eager fp8 oracle, {dt:.2f} s",
+                  f"KV tokens), PyTorch-eager fp8 oracle, {dt:.2f} s",
     }
 
 
@@ -300,7 +293,7 @@ def c4_cpu_baseline(m, w=C4):
     counts = torch.bincount(ids.flatten().long(), minlength=w["num_expert"])
     e = int(counts.argmax())
     toks = (ids == e).any(dim=1).nonzero().flatten()
-    toks = toks[: min(int(toks.numel()), 256)]
+    toks = toks[: min(int(toks.numel()), 1024)]  # the busiest expert's rows (~570 of 32768): ~3 s on 64 threads
     x, xs = m["x"].cpu()[toks], m["x_scale"].cpu()[toks]
     guw, guws, dw, dws = m["guw"][e].cpu(), m["guws"][e].cpu(), m["dw"][e].cpu(), m["dws"][e].cpu()
     t0 = time.perf_counter()
@@ -847,7 +840,8 @@ def main():
         got = out.reshape(w["batch"], w["num_seq_q"], w["num_head_q"], w["head_dim"])[rows].cpu()
         err = (got.float() - ref.float()).abs().max().item()
         assert err <= 0.2, f"bench output does not match the fp8 oracle: max abs err {err}"
-        parity = {"checked_requests": rows, "max_abs_err": round(err, 5), "tolerance": "atol=0.2 (reference test)"}
+        parity = {"checked_requests": f"all {len(rows)}" if len(rows) == w["batch"] else rows, "max_abs_err": round(err, 5),
+                  "tolerance": "atol=0.2 (reference test)"}
 
     # Timed region: K steps = K / R replays of a hipGraph that holds R back-to-back steps (R = 10 when it divides K):
     # a graph replay costs ~10 us of host / launch floor whatever it contains, which at ~140 us per step would be
