@@ -171,7 +171,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   __shared__ float s_l[kHP][kWaves][16];
   __shared__ int s_ticket;
   // loads of one WI, in issue order: Q (6) | K (8) | V (8)
-  constexpr int kNQ = 6, kNK = 8, kNV = 8;
+  constexpr int kNV = 8;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   auto issue = [&]() __attribute__((always_inline)) {
     nx = nn;
     const Stage& d = nx;
-    const int db = d.bp & 0xffff, dp = d.bp >> 16;
+    const int dp = d.bp >> 16;
     const bool valid = d.flags & 1;
     const int pid0 = sgpr(nn_pid0), pid1 = sgpr(nn_pid1);
     const int pair_off = dp * kRow;
@@ -601,7 +601,6 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     // bases, and 32 pinned VGPRs were the difference between 2 waves per SIMD and spilling
     uint32_t w0 = w0_inv, r0 = r0_inv, t0 = t0_inv;
     asm volatile("" : "+v"(w0), "+v"(r0), "+v"(t0));
-    const int dp = d.bp >> 16;
     // registers -> the wave's LDS stage (token rows of 256 B, chunks swizzled)
     wait_x4x4<kNV + 4>(kr[0]);
     wait_x4x4<kNV>(kr[1]);
