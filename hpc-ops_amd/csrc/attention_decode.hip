@@ -662,7 +662,7 @@ inline Common fill_common(Args& a, void* y_ptr, void* workspace, const int* task
   a.block_ids = block_ids_ptr;
   a.task_map = task_map_ptr;
   a.y = static_cast<uint16_t*>(y_ptr);
-  char* ws = static_cast<char*>(workspace);
+  char* ws = static_cast<char*>(workspace) + hpc::decode2::kCounterBytes;  // the workspace starts with the v2 arrival counters
   a.part_o = reinterpret_cast<float*>(ws);
   ws += static_cast<int64_t>(num_bins) * 2 * 16 * c.num_nb * 128 * 4;
   a.part_lse = reinterpret_cast<float*>(ws);
@@ -703,16 +703,18 @@ int64_t v1_workspace_bytes(int num_bins, int num_batch, int num_head_kv, int num
 }
 }  // namespace
 
-// Scratch of one decode call: the first-generation kernel's region (2 partial slots per bin, first-bin table)
-// followed by the second-generation FP8 / NHD kernel's (2 slots per workgroup x 2 heads, chunk table; its grid
-// never exceeds num_bins workgroups).
+// Scratch of one decode call: [arrival counters of the second-generation kernel: hpc_attention_decode_workspace_zero_bytes()
+// bytes that must be zero the first time the buffer is used and are left zero by every call] [the first-generation
+// kernel's region: 2 partial slots per bin, first-bin table] [the second-generation FP8 / NHD kernel's partial slots:
+// 2 per workgroup x 2 heads; its grid never exceeds num_bins workgroups].
 extern "C" int64_t hpc_attention_decode_workspace_bytes(int num_bins, int num_batch, int num_head_kv,
                                                         int num_seq_q, int heads_per_group) {
   if (num_bins <= 0 || num_batch <= 0 || num_head_kv <= 0 || num_seq_q <= 0 || heads_per_group <= 0)
     return HPC_ERR_INVALID;
-  return v1_workspace_bytes(num_bins, num_batch, num_head_kv, num_seq_q, heads_per_group) +
-         hpc::decode2::workspace_bytes(num_bins, num_batch, num_head_kv);
+  return hpc::decode2::kCounterBytes + v1_workspace_bytes(num_bins, num_batch, num_head_kv, num_seq_q, heads_per_group) +
+         hpc::decode2::workspace_bytes(num_bins) + hpc::decode2_old::workspace_bytes(num_bins, num_batch, num_head_kv);
 }
+extern "C" int64_t hpc_attention_decode_workspace_zero_bytes(void) { return hpc::decode2::kCounterBytes; }
 
 extern "C" int hpc_attention_decode_bf16_async(
     void* y_ptr, void* workspace, const int* task_map_ptr, const void* q_ptr, const void* kcache_ptr,
@@ -798,19 +800,27 @@ extern "C" int hpc_attention_decode_fp8_async(
     b.ks_head_stride = kscale_head_stride;
     b.scale_log2 = a.scale_log2;
     const int gen = hpc_dev_tuning_get(12);  // 0 auto, 1 first generation only
-    if (gen != 1 && quant_type == 1 &&
-        hpc::decode2::eligible(b, num_head_q, block_size, kcache_head_stride, vcache_head_stride)) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess) return HPC_ERR_LAUNCH;
+    const int mode = (gen != 1 && quant_type == 1)
+                         ? hpc::decode2::mode_of(b, num_head_q, block_size, kcache_head_stride, vcache_head_stride)
+                         : 0;
+    int dev = 0;
+    if (mode != 0 && hipGetDevice(&dev) == hipSuccess) {
+      const int unit = mode == 1 ? num_head_kv / 2 : num_head_kv;  // workgroup = (token range, head pair | head)
       int num_wg = 2 * hpc_get_cu_count(dev);  // two 4-wave workgroups per CU (<= 256 registers, 65 KB of LDS each)
       const int wg_dev = hpc_dev_tuning_get(14);
       if (wg_dev > 0) num_wg = wg_dev;
       if (num_wg > num_bins) num_wg = num_bins;  // the scratch is sized for num_bins workgroups
-      num_wg -= num_wg % (num_head_kv / 2);      // workgroup = (token range, head pair)
-      if (num_wg <= 0) return HPC_ERR_LAUNCH;
-      char* ws2 = static_cast<char*>(workspace) +
-                  v1_workspace_bytes(num_bins, num_batch, num_head_kv, num_seq_q, num_head_q / num_head_kv);
-      return hpc::decode2::launch(b, ws2, num_wg, quant_type, stream);
+      num_wg -= num_wg % unit;
+      // (a grid that rounds down to nothing - fewer bins than head pairs - falls through to the first generation)
+      if (num_wg > 0) {
+        char* base = static_cast<char*>(workspace);
+        char* part = base + hpc::decode2::kCounterBytes +
+                     v1_workspace_bytes(num_bins, num_batch, num_head_kv, num_seq_q, num_head_q / num_head_kv);
+        if (hpc_dev_tuning_get(21) == 1 && mode == 1 &&
+            hpc::decode2_old::eligible(b, num_head_q, block_size, kcache_head_stride, vcache_head_stride))
+          return hpc::decode2_old::launch(b, part + hpc::decode2::workspace_bytes(num_bins), num_wg, quant_type, stream);
+        return hpc::decode2::launch(b, base, part, num_wg, mode, stream);
+      }
     }
   }
   if (quant_type == 1) return launch<true, 1>(a, num_bins, c.num_nb, stream);

@@ -16,8 +16,7 @@ struct Args {
   uint16_t* y;
   float* part_o;         // [workgroups][2][2 heads][16][128]
   float* part_lse;       // [workgroups][2][2 heads][16]
-  int* arrive;           // [pairs * B] epoch-tagged arrival counters of split requests (left zero), then the
-                         // chunk table [pairs * B][2] of the two-kernel form
+  int* arrive;           // [pairs * B] epoch-tagged arrival counters of split requests (zero before, left zero)
   const float* qscale;   // [B * Sq, qscale_stride]
   const float* kscale;   // [1] or the K-scale tail rows of the cache
   const float* vscale;   // [1] or [Hkv]
@@ -33,10 +32,22 @@ struct Args {
   float scale_log2;
 };
 
-int64_t workspace_bytes(int num_wg, int num_batch, int num_head_kv);
-// NHD pages with adjacent heads 128 B apart, an even head count, <= 16 q rows per kv head, <= 1024 requests
-bool eligible(const Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride);
-int launch(Args a, void* workspace, int num_wg, int quant_type, hipStream_t stream);
+// Arrival counters of split requests: a fixed region at the very start of a call's workspace.  It must be zero
+// the first time a workspace is used (the kernel leaves it zero); its place and size do not depend on the call.
+constexpr int64_t kCounterBytes = 64 * 1024;
+int64_t workspace_bytes(int num_wg);  // partial slots (2 per workgroup x 2 heads), after the first-generation region
+// 0: not served here; 1: head-pair form (NHD pages with adjacent heads 128 B apart, an even head count);
+// 2: token-pair form (one kv head, token rows 128 B apart).  Both: <= 16 q rows per kv head, <= 1024 requests.
+int mode_of(const Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride);
+int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStream_t stream);
 
 }  // namespace decode2
+}  // namespace hpc
+
+namespace hpc {
+namespace decode2_old {  // the round-2 kernel, kept for A/B timing behind development key 21 = 1
+int64_t workspace_bytes(int num_wg, int num_batch, int num_head_kv);
+bool eligible(const hpc::decode2::Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride);
+int launch(hpc::decode2::Args a, void* workspace, int num_wg, int quant_type, hipStream_t stream);
+}  // namespace decode2_old
 }  // namespace hpc

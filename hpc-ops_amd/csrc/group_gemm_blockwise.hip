@@ -243,9 +243,9 @@ __global__ __launch_bounds__(64 * kWaves, (kWaves == 8 || kMT * kR >= 8) ? 1 : 2
 
 bool hpc_ggemm_p8_selected(int num_group, int m, int n, int k, const void* cu_tiles128) {
   const int tiled_mode = hpc_dev_tuning_get(3);
-  // up to 64 groups: the kernel finds its work item from one round of lane-parallel loads (its multi-round lookup
-  // for more groups exists but no test reaches it yet: the ring kernel takes those)
-  return cu_tiles128 && n % 256 == 0 && k >= 128 && num_group <= 64 &&
+  // (up to 64 groups the kernel finds its work item from one round of lane-parallel loads, above that from one round
+  // per 64 groups: tests/test_fuse_moe_blockwise.py::test_group_gemm_blockwise_many_groups, 65 ... 256 groups)
+  return cu_tiles128 && n % 256 == 0 && k >= 128 &&
          (tiled_mode == 4 || (tiled_mode == 0 && m / num_group >= 192));
 }
 

@@ -116,19 +116,26 @@ _DECODE_WS = {}
 
 
 def _decode_workspace(device, nbytes):
-    """Scratch of a decode call (split-KV partials, arrival counters; no initialisation needed).  One buffer per
-    (device, stream) is kept and reused instead of an allocator round trip on every step (the reference allocates
-    per call, src/attention/entry.cc:660-663).  Calls on one stream are ordered, so sharing the buffer between them
-    is safe; different streams get different buffers; while a hipGraph is being captured the buffer comes from the
-    graph's own pool (torch.empty inside the capture) and lives as long as the graph."""
-    if torch.cuda.is_current_stream_capturing():
-        return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    """Scratch of a decode call: [arrival counters of split requests | split-KV partials].  The counter region
+    (hpc_attention_decode_workspace_zero_bytes(), a fixed place and size) must be zero the first time a buffer is
+    used and every call leaves it zero, so the buffer is allocated ZEROED once and then reused: one buffer per
+    (device, stream) instead of an allocator round trip on every step (the reference allocates per call and zeroes
+    its split_flag per call, src/attention/entry.cc:660-663, 690-694).  Calls on one stream are ordered, so sharing
+    the buffer between them is safe; different streams get different buffers.  While a hipGraph is being captured
+    the buffer of the capturing stream is used if there is one; otherwise it is allocated inside the capture (from
+    the graph's pool, its zero-fill becomes a node of the graph) and kept for the following calls on that stream."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _DECODE_WS.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        ws[: _C.lib.hpc_attention_decode_workspace_zero_bytes()].zero_()
         _DECODE_WS[key] = ws
     return ws
+
+
+def release_decode_workspaces():
+    """Drop the cached decode scratch buffers (e.g. after the streams / graphs that used them are gone)."""
+    _DECODE_WS.clear()
 
 
 def _decode_common_checks(q, kcache, vcache, block_ids, num_seq_kvcache, mtp, max_mtp):

@@ -81,15 +81,20 @@ int hpc_assign_attention_decode_task_async(int* task_map, const int* num_seq_kvc
  * with element strides (block, token, head), block_ids int32 [B, num_seq_max_blocks],
  * y bf16 [B*Sq, Hq, 128] (row stride ldY).  `task_map_ptr` is a task map produced by the
  * scheduler above for the same num_seq_kvcache / num_seq_q / new_kv_included; `num_bins` must be
- * its header[1].  `workspace` holds the fp32 split-KV partials and the arrival counters of split requests:
- * hpc_attention_decode_workspace_bytes bytes, no initialisation needed (the counters are tagged with a per-launch
- * epoch and left zero), so one buffer per stream can be reused call after call and inside a captured
- * hipGraph (the reference allocates lse/split_out per call, src/attention/entry.cc:492-499; here it is 2 slots
- * per workgroup instead of splitk slots per request).  The split-KV combine runs inside the call: a second
- * kernel on the same stream for the first-generation kernels, the last-arriving chunk of a request for the
- * second-generation FP8 kernel (reference: static_splitk_kernels.cuh:362-377). */
+ * its header[1].  `workspace` holds the arrival counters of split requests and the fp32 split-KV partials:
+ * hpc_attention_decode_workspace_bytes bytes.  Its first hpc_attention_decode_workspace_zero_bytes() bytes (the
+ * counters: a fixed place and size whatever the shapes of the call) must be ZERO the first time the buffer is
+ * used - like the reference's split_flag, which its entry allocates zeroed (src/attention/entry.cc:690-694) - and
+ * every call leaves them zero again, so one buffer per stream can be reused call after call, with any sequence
+ * of shapes, and inside a captured hipGraph; the rest needs no initialisation (the reference allocates
+ * lse/split_out per call, src/attention/entry.cc:492-499; here it is 2 slots per workgroup instead of splitk
+ * slots per request).  One buffer must not be used by two calls that may run concurrently (two streams: two
+ * buffers).  The split-KV combine runs inside the call: a second kernel on the same stream for the
+ * first-generation kernels, the last-arriving chunk of a request for the second-generation FP8 kernel
+ * (reference: static_splitk_kernels.cuh:362-377). */
 int64_t hpc_attention_decode_workspace_bytes(int num_bins, int num_batch, int num_head_kv,
                                              int num_seq_q, int heads_per_group);
+int64_t hpc_attention_decode_workspace_zero_bytes(void);
 int hpc_attention_decode_bf16_async(void* y_ptr, void* workspace, const int* task_map_ptr,
                                     const void* q_ptr, const void* kcache_ptr,
                                     const void* vcache_ptr, const int* block_ids_ptr, int num_bins,
@@ -109,9 +114,11 @@ int hpc_attention_decode_bf16_async(void* y_ptr, void* workspace, const int* tas
  * vscale f32[Hkv].  Numerics: P~ = e4m3(256 * 2^(s - running max)), O = sum(P~ V)/sum(p) * vscale/256.
  * num_seq_q <= 4.  block_size 16/32/64 for quant_type 1, 32/64 for quant_type 0.
  * num_seq_kvcache_ptr (device int32 [num_batch]) / new_kv_included as in the reference launcher
- * (decode.h:27-35): with them, NHD pages (adjacent kv heads 128 bytes apart), an even head count and
- * <= 16 q rows per kv head take the second-generation kernel (attention_decode_v2.hip: two heads per load,
- * deep prefetch, the schedule planned in-kernel from the lengths in the closed form of the scheduler above);
+ * (decode.h:27-35): with them, NHD pages (adjacent kv heads 128 bytes apart), <= 16 q rows per kv head and
+ * either an even head count or a single kv head take the second-generation kernel (attention_decode_v2.hip:
+ * 256 contiguous bytes per row and load - two heads of a token, or two tokens of the single head - deep
+ * prefetch, the schedule planned in-kernel from the lengths in the closed form of the scheduler above: the
+ * task map is validated but its bins, min_process_len and split decisions do not apply on that path);
  * num_seq_kvcache_ptr may be NULL, then the task map drives the first-generation kernel as for bf16. */
 int hpc_attention_decode_fp8_async(void* y_ptr, void* workspace, const int* task_map_ptr,
                                    const void* q_ptr, const void* kcache_ptr,

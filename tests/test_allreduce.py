@@ -145,22 +145,27 @@ CASES = [("ht", 128, 8192, 16, 3), ("ht", 77, 5120, 78, 2), ("ht_uneven", 77, 81
          ("ll", 128, 8192, 16, 5), ("ll", 77, 7168, 78, 4), ("ll", 8, 4096, 4, 3), ("ll", 16, 16384, 4, 2)]
 
 
-def _spawn(world_size, one_gpu_per_rank=False, tuning=""):
+def _spawn(world_size, one_gpu_per_rank=False, tuning="", cases=None, timeout=600):
     ctx = multiprocessing.get_context("spawn")
     q = ctx.Queue()
     name = f"t_ar_{os.getpid()}_{world_size}_{len(tuning)}"
     old = os.environ.get("HPC_AMD_TUNING")
     if tuning:
         os.environ["HPC_AMD_TUNING"] = tuning  # inherited by the spawned ranks, read at library load
-    ps = [ctx.Process(target=_ar_task, args=(r, world_size, CASES, name, q, r if one_gpu_per_rank else 0))
+    ps = [ctx.Process(target=_ar_task, args=(r, world_size, cases or CASES, name, q, r if one_gpu_per_rank else 0))
           for r in range(world_size)]
     for p in ps:
         p.start()
     res = []
-    for _ in ps:
-        res.append(q.get(timeout=600))
+    try:
+        for _ in ps:
+            res.append(q.get(timeout=timeout))
+    except Exception:  # noqa: BLE001  (queue.Empty: a rank never reported)
+        res.append(("missing", f"only {len(res)} of {world_size} ranks reported within {timeout} s"))
     for p in ps:
-        p.join(timeout=60)
+        p.join(timeout=30)
+        if p.is_alive():
+            p.kill()
     if tuning:
         if old is None:
             os.environ.pop("HPC_AMD_TUNING", None)
@@ -181,6 +186,27 @@ def test_allreduce_rmsnorm_world2_shared_gpu():
     must be co-resident on the one GPU, so the high-throughput grid floor (one workgroup per CU) is lifted:
     development key 11 = 1 -> grid = num_max_blocks like the reference."""
     _spawn(2, tuning="11=1")
+
+
+# Four / eight ranks on ONE GPU.  Both barrier forms pair workgroup b of a rank with workgroup b of every peer, and
+# the Lamport pollers of one rank wait for the senders of another: every rank's grid has to be RESIDENT on the one
+# GPU at the same time (on a real node every rank has its own GPU).  A first attempt in round 2 ran the 2-rank cases
+# (up to 78 + 128 workgroups per rank and call, 8192-16384 wide rows: ~200 registers, two workgroups per CU) with
+# four ranks: 4 x 128 workgroups plus pollers fill every slot of the GPU, the workgroups that would post the awaited
+# flags cannot become resident, and every spin runs into its 2^22-round limit - minutes, not a protocol defect.
+# Here the grids are tiny (key 11 = 1: grid = num_max_blocks), the rows few, and the spin limit short (key 10), so
+# a lost rendezvous would show up as a reported timeout within seconds instead of a hang.
+SHARED_GPU_CASES = [("ht", 16, 8192, 4, 3), ("ht", 13, 5120, 3, 2), ("ht_uneven", 24, 4096, 4, 2), ("ht", 8, 16384, 2, 2),
+                    ("ll", 16, 8192, 4, 5), ("ll", 13, 7168, 4, 4), ("ll", 8, 4096, 4, 4)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world_size", [4, 8])
+def test_allreduce_rmsnorm_many_ranks_shared_gpu(world_size):
+    """world sizes 4 and 8 - the per-world-size kernel instantiations, pointer tables, pad indices and slot
+    rotation the 8-GPU node uses - with every rank on the one GPU of the test box (real IPC, real cross-process
+    protocol; only the fabric is missing)."""
+    _spawn(world_size, tuning="11=1,10=24", cases=SHARED_GPU_CASES, timeout=240)
 
 
 @pytest.mark.gpu
@@ -275,3 +301,58 @@ def test_high_throughput_grid_is_rank_invariant():
     assert f(8, 64, 72 * 256) == 256 and f(8, 2048, 72 * 256) == 2048
     assert f(8, 64, 72 * 16) == 72 * 16 // 8  # small pad (partitioned device): clamped, not overrun
     assert f(2, 64, 1) < 0 and f(9, 64, 1024) < 0 and f(2, 0, 1024) < 0
+
+
+def test_signal_pad_and_lamport_slot_model():
+    """CPU model of the index arithmetic of csrc/allreduce.hip for world sizes 2 / 4 / 8 (reference
+    high_throughput.cu:37-43, low_latency.h:208-304): (1) signal pads - workgroup b of rank r posts word
+    b * ws + r of peer t's pad and consumes word b * ws + t of its own: for every grid the entry can pick, all
+    words lie inside the pad and every posted word is consumed by exactly one waiter; (2) Lamport slots - the
+    rotation cur -> cur + 1 (mod 3) driven by buffer_flags, the slot cleaned for the next call, and the scatter /
+    broadcast regions of a slot: for rows not divisible by ws every written byte stays inside its slot, the two
+    regions never overlap, and a slot is only ever re-used two calls after it was cleaned."""
+    lib = ctypes.CDLL(str(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so"))
+    grid_of = lib.hpc_fuse_allreduce_rmsnorm_high_throughput_grid
+    for ws in (2, 4, 8):
+        for pad_words in (72 * 256, 72 * 16, 64):
+            for nmb in (1, 16, 64, 300, 5000):
+                g = grid_of(ws, nmb, pad_words)
+                assert g > 0 and g * ws <= pad_words
+                posts = {}
+                for r in range(ws):          # sender rank
+                    for t in range(ws):      # pad owner
+                        for b in (0, g // 2, g - 1):
+                            w = b * ws + r
+                            assert 0 <= w < pad_words
+                            posts[(t, w)] = posts.get((t, w), 0) + 1
+                for t in range(ws):          # waiter: rank t consumes word b * ws + p of ITS pad for every peer p
+                    for p in range(ws):
+                        for b in (0, g // 2, g - 1):
+                            assert posts.pop((t, b * ws + p)) == 1
+                assert not posts
+        # Lamport slots: restate the flag updates of ll_scatter_kernel / ll_reduce_norm_kernel
+        H = 8192
+        max_rows = 77
+        n_pad_max = (max_rows + ws - 1) // ws * ws
+        m_pad = 2 * n_pad_max * 3                               # rows of the caller's workspace (reference test)
+        slot_bytes = (m_pad * H * 2 // 3) // 16 * 16
+        flags = [0, 2, slot_bytes, 0, 0, 0, 0, 0, 0]
+        cleaned_at, used_at = {0: -1, 1: -1, 2: -1}, {}
+        for call, rows in enumerate([77, 5, 76, 1, 33, 77, 8, 64]):
+            cur = flags[0] % 3
+            nxt = (cur + 1) % 3
+            assert flags[4 + nxt] <= slot_bytes                 # the region cleaned now fits the slot
+            cleaned_at[nxt] = call
+            assert cleaned_at[cur] < call                       # the slot in use was cleaned by an earlier call (or is fresh)
+            n_pad = (rows + ws - 1) // ws * ws
+            row_bytes = H * 2
+            hi_scatter = max(((t // ws) * ws + r + 1) * row_bytes for t in range(rows) for r in range(ws))
+            bcast_off = n_pad * row_bytes
+            assert hi_scatter <= bcast_off                      # scatter region below the broadcast region
+            assert bcast_off + rows * row_bytes <= slot_bytes   # broadcast region inside the slot
+            used_at[cur] = call
+            # rotation by the last workgroup of ll_reduce_norm_kernel
+            flags[4 + cur] = 2 * n_pad * row_bytes
+            flags[1] = (cur + 2) % 3
+            flags[0] = (cur + 1) % 3
+            assert flags[4 + cur] <= slot_bytes

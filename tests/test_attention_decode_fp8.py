@@ -137,24 +137,79 @@ def test_attn_fp8_bins_of_short_requests(k_per_token, num_seq_q, solo):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["last_arriver", "second_kernel", "poisoned_scratch"])
+@pytest.mark.parametrize("mode", ["last_arriver", "poisoned_partials", "spread_issue"])
 def test_attn_fp8_split_request_merge_variants(mode):
-    """Requests cut by range boundaries (second-generation kernel): merged inside the launch by the chunk that
-    arrives last (default), by a second kernel (development key 17 = 2), and with the call's scratch - partial
-    slots and arrival counters - full of garbage before the call (the counters are epoch-tagged: stale contents
-    must read as 'no arrivals yet'); the same call twice must also agree (the counters are left clean)."""
+    """Requests cut by range boundaries (second-generation kernel) are merged inside the launch by the chunk that
+    arrives last.  The call's scratch is [arrival counters (zero on first use, left zero) | partial slots]: the
+    partial region may hold anything - here words of the form (epoch << 16) | n for every epoch, the pattern a
+    tagged counter would take for 'n chunks arrived' - and the same call twice must agree (counters left clean)."""
     import hpc
     from hpc import _entry_attention as ea
 
     lens = torch.tensor([20000, 3, 9000, 130, 64, 4097, 700, 31000], dtype=torch.int32)
-    hpc._C.lib.hpc_dev_tuning_set(17, 2 if mode == "second_kernel" else 0)
+    hpc._C.lib.hpc_dev_tuning_set(22, 1 if mode == "spread_issue" else 0)
     try:
-        if mode == "poisoned_scratch":
+        if mode == "poisoned_partials":
             _run(len(lens), 1, lens, 64, (4, 32), False, True, True, "NHD", 0.2)  # creates the cached scratch
+            zero = hpc._C.lib.hpc_attention_decode_workspace_zero_bytes()
             for ws in ea._DECODE_WS.values():
-                ws.fill_(0xAB)
+                assert int(ws[:zero].view(torch.int32).abs().max()) == 0  # the call left its counters zero
+                words = ws[zero:].view(torch.int32)
+                idx = torch.arange(words.numel(), device=ws.device, dtype=torch.int32)
+                words.copy_(((idx % 32767 + 1) << 16) | (idx % 7 + 1))
             torch.cuda.synchronize()
         for _ in range(2):
             _run(len(lens), 1, lens, 64, (4, 32), False, True, True, "NHD", 0.2)
     finally:
-        hpc._C.lib.hpc_dev_tuning_set(17, 0)
+        hpc._C.lib.hpc_dev_tuning_set(22, 0)
+
+
+def _mixed_lens(num_batch, seed, hi):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(1, hi, (num_batch,), dtype=torch.int32, generator=g)
+    lens[torch.randperm(num_batch, generator=g)[: max(1, num_batch // 9)]] = 0  # finished / empty requests
+    lens[0] = hi * 4  # one long request that is split over many ranges
+    return lens
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_batch", [65, 200, 1000])
+@pytest.mark.parametrize("num_seq_q,block_size,heads", [(1, 64, (4, 32)), (2, 32, (2, 16)), (2, 16, (8, 32)), (1, 64, (1, 8)),
+                                                         (2, 32, (1, 4))])
+def test_attn_fp8_many_requests(num_batch, num_seq_q, block_size, heads):
+    """More than 64 requests: the in-kernel planner of the second-generation kernel puts several requests on a
+    lane of its prefix scan and walks them (reference grid: num_batch = 200,
+    tests/test_attention_decode_qpertoken_perhead_kvpertensor_fp8.py:263; kernel limit 1024).  Mixed lengths,
+    empty requests, both page-lookup paths, head-pair and token-pair forms."""
+    lens = _mixed_lens(num_batch, 1000 + num_batch, 600 if num_batch >= 1000 else 1500)
+    _run(num_batch, num_seq_q, lens, block_size, heads, False, False, True, "NHD", 0.2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_seq_q", [1, 2])
+@pytest.mark.parametrize("kv_head_q_head", [(1, 8), (4, 32)])
+def test_attn_fp8_reference_grid_batch_200(num_seq_q, kv_head_q_head):
+    """The reference grid's largest batch (tests/test_attention_decode_qpertoken_perhead_kvpertensor_fp8.py:263)."""
+    torch.manual_seed(41)
+    lens = torch.randint(1, 1024, (200,), dtype=torch.int32)
+    _run(200, num_seq_q, lens, 64, kv_head_q_head, False, True, True, "NHD", 0.2)
+
+
+@pytest.mark.gpu
+def test_attn_fp8_workspace_reused_across_shapes():
+    """One cached scratch buffer serves calls of different shapes back to back: the arrival counters sit in a fixed
+    region at its start, so a call can never find them on top of another call's partials."""
+    for num_batch, heads, hi in ((64, (8, 64), 3000), (200, (2, 16), 900), (7, (4, 32), 20000), (64, (8, 64), 3000),
+                                 (33, (1, 8), 5000)):
+        lens = _mixed_lens(num_batch, num_batch, hi)
+        _run(num_batch, 1, lens, 64, heads, False, True, True, "NHD", 0.2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("block_size", [32, 64])
+@pytest.mark.parametrize("num_seq_q", [1, 2, 4])
+def test_attn_fp8_single_kv_head_token_pairs(block_size, num_seq_q):
+    """One kv head (the reference benchmark's default 1/8 heads, bench_attention_decode_fp8.py:44-49): the
+    token-pair form of the second-generation kernel - split requests, short requests, odd lengths."""
+    lens = torch.tensor([20000, 3, 9000, 130, 64, 63, 65, 4097, 700, 1, 127, 129, 31000, 2], dtype=torch.int32)
+    _run(len(lens), num_seq_q, lens, block_size, (1, 8 if num_seq_q <= 2 else 4), False, True, True, "NHD", 0.2)

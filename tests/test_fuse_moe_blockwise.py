@@ -214,6 +214,78 @@ def test_group_gemm_blockwise_tiled_kernels(tiled_mode, n, k):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tiled_mode", [0, 2, 4])  # auto, 256x128 ring kernel, 256x256 kernel
+@pytest.mark.parametrize("num_group", [65, 128, 192, 256])
+def test_group_gemm_blockwise_many_groups(tiled_mode, num_group):
+    """More than 64 groups (the reference benchmark's presets have 128 / 192 / 256 experts,
+    benchmark/fused_moe/benchmark_fuse_moe.py:44-50; reference test grid E = 128): the tiled kernels find their work
+    item with one round of lane-parallel loads per 64 groups.  Ragged groups incl. empty ones and ones that need
+    two and three 128 / 256-row tiles; every row is checked."""
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(num_group)
+    n, k = 512, 512
+    seqlens = torch.randint(150, 330, (num_group,), dtype=torch.int32)
+    seqlens[torch.randperm(num_group)[: num_group // 8]] = 0
+    seqlens[torch.randperm(num_group)[: num_group // 8]] = 1
+    seqlens[-1] = 700
+    seqlens[64 % num_group] = 257
+    total = int(seqlens.sum())
+    x = (torch.randn((total, k)) / 10).to(F8)
+    w = (torch.randn((num_group, n, k)) / 10).to(F8)
+    kb = k // 128
+    xs_rows = torch.rand((total, kb)) + 0.5
+    wscale = torch.rand((num_group, n // 128, (kb + 3) // 4 * 4)) + 0.5
+    cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
+    gt = omoe.group_gemm_blockwise(x, w, seqlens, cu, xs_rows, wscale)
+    avg = total // num_group
+    tile_m = hpc._entry_fuse_moe.aligned_size(avg)
+    tiles = (seqlens + tile_m - 1) // tile_m
+    cu_tiles = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(tiles, 0)])
+    xs_t = torch.zeros((kb, int(cu_tiles[-1]) * tile_m + 64))
+    for g in range(num_group):
+        c0 = int(cu_tiles[g]) * tile_m
+        xs_t[:, c0 : c0 + int(seqlens[g])] = xs_rows[int(cu[g]) : int(cu[g]) + int(seqlens[g])].t()
+    hpc._C.lib.hpc_dev_tuning_set(3, tiled_mode)
+    try:
+        my = hpc.group_gemm_blockwise_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), xs_t.cuda(), wscale.cuda(),
+                                          num_seq_per_group_avg=avg)
+        torch.cuda.synchronize()
+    finally:
+        hpc._C.lib.hpc_dev_tuning_set(3, 0)
+    assert allclose(gt.float(), my.cpu().float(), rtol=0.01, atol=0.02)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_expert,num_topk", [(128, 8), (256, 8)])
+def test_fuse_moe_blockwise_fp8_many_experts(num_expert, num_topk):
+    """The fused op with 128 / 256 experts (reference benchmark presets) at a token count that puts ~200+ rows on
+    every expert, i.e. on the 256 x 256 kernel with the activation epilogue; sampled rows of every expert."""
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(num_expert)
+    T, H, I = 32 * num_expert, 512, 256
+    ids = torch.sort(torch.multinomial(torch.ones(T, num_expert), num_topk, replacement=False).to(torch.int32), dim=1)[0]
+    sc = torch.rand(T, num_topk)
+    sc = sc / sc.sum(1, keepdim=True)
+    x = (torch.randn(T, H) / 10).to(F8)
+    xs = torch.rand(T, H // 128) + 0.5
+    guw = (torch.randn(num_expert, 2 * I, H) / 10).to(F8)
+    dw = (torch.randn(num_expert, H, I) / 10).to(F8)
+    guws = torch.rand(num_expert, 2 * I // 128, (H // 128 + 3) // 4 * 4) + 0.5
+    dws = torch.rand(num_expert, H // 128, (I // 128 + 3) // 4 * 4) + 0.5
+    my = hpc.fuse_moe_blockwise_fp8(x.cuda(), xs.cuda(), guw.cuda(), guws.cuda(), dw.cuda(), dws.cuda(), ids.cuda(),
+                                    sc.cuda(), 0, num_expert)
+    torch.cuda.synchronize()
+    rows = sorted(set(torch.randperm(T)[:512].tolist()))
+    fetch = lambda e: (guw[e], guws[e], dw[e], dws[e])  # noqa: E731
+    gt = omoe.fuse_moe_blockwise_fp8_rows(x, xs, fetch, ids, sc, rows, 0, num_expert)
+    assert allclose(gt.float(), my[rows].cpu().float(), rtol=0.01, atol=0.01)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("num_group,actual_m,m", [(8, 30, 1280), (8, 7, 64), (4, 48, 96), (4, 100, 128)])
 def test_reformat_x_scale_and_deepep_group_gemm(num_group, actual_m, m):
     """reformat_x_scale (reference tests/test_group_gemm_blockwise.py:86-148) and the DeepEP-format call it

@@ -166,7 +166,8 @@ def test_c4_fused_moe_graded_shape(c4_weights, num_tokens, shared):
     my = hpc.fuse_moe_blockwise_fp8(x.cuda(), xs.cuda(), guw, guws, dw, dws, ids.cuda(), sc.cuda(), 0, E,
                                     so.cuda() if shared else None)
     torch.cuda.synchronize()
-    rows = list(range(T)) if T <= 256 else [0, 1, 777, 2048, 3333, 4095]
+    # T = 4096: 256 rows spread over the batch - 2048 routed rows, ~32 on every one of the 64 experts
+    rows = list(range(T)) if T <= 256 else sorted(set(range(0, T, 16)) | {1, 777, 3333, T - 1})[:260]
     torch.set_num_threads(min(torch.get_num_threads(), 64))
     fetch = lambda e: (guw[e].cpu(), guws[e].cpu(), dw[e].cpu(), dws[e].cpu())  # noqa: E731
     gt = omoe.fuse_moe_blockwise_fp8_rows(x, xs, fetch, ids, sc, rows, 0, E, so)

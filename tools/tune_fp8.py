@@ -1,5 +1,5 @@
 """Development tool: FP8 decode timing (uniform 8k / the C3 mix; NHD pages), sweeping development tuning keys.
-usage: python tools/tune_fp8.py ["k=v,k=v" ...]   each argument is one configuration of tuning registers"""
+usage: python tools/tune_fp8.py [heads=8/64,1/8] ["k=v,k=v" ...]   each argument is one configuration of tuning registers"""
 import math, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -16,7 +16,7 @@ def run(lens_c, heads=(8, 64), graph=True):
     o = torch.empty(B, heads[1], D, dtype=torch.bfloat16, device=dev)
     us = bench.timed(lambda: hpc.attention_decode_fp8(inp["q"], inp["k_cache"], inp["v_cache"], inp["block_ids"], inp["kv_lens"],
                      inp["q_scale"], inp["k_scale"], inp["v_scale"], 0, True,
-                     hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, True, tm, None, o), graph=graph, iters=40)
+                     hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, True, tm, None, o), graph=graph, iters=30, reps=10)
     kvb = int(lens_c.sum()) * heads[0] * 256
     return us, kvb / us / 1e3
 mixed = bench.c3_lens()
@@ -25,11 +25,17 @@ cases = (("uniform8k", torch.full((B,), 8192, dtype=torch.int32)), ("mixed", mix
          ("uniform512", torch.full((B,), 512, dtype=torch.int32)),
          ("extreme", torch.tensor([64] * 15 + [16384] + [0] * 48, dtype=torch.int32)),
          ("one64k", torch.tensor([65536] + [4096] * 31 + [0] * 32, dtype=torch.int32)))
-configs = sys.argv[1:] or ["12=1", ""]
-for cfg in configs:
-    pairs = [tuple(int(x) for x in kv.split("=")) for kv in cfg.split(",") if kv]
-    for k, v in pairs: _C.lib.hpc_dev_tuning_set(k, v)
-    for name, lens in cases:
-        us, gb = run(lens)
-        print(f"[{cfg or 'default':>14}] fp8 {name:<11} 8/64: {us:8.1f} us {gb:8.1f} GB/s {gb/8000:.3f}", flush=True)
-    for k, v in pairs: _C.lib.hpc_dev_tuning_set(k, 0)
+args = sys.argv[1:]
+heads_list = [(8, 64)]
+if args and args[0].startswith("heads="):
+    heads_list = [tuple(int(x) for x in h.split("/")) for h in args[0][6:].split(",")]
+    args = args[1:]
+configs = args or ["12=1", ""]
+for heads in heads_list:
+    for cfg in configs:
+        pairs = [tuple(int(x) for x in kv.split("=")) for kv in cfg.split(",") if kv]
+        for k, v in pairs: _C.lib.hpc_dev_tuning_set(k, v)
+        for name, lens in cases:
+            us, gb = run(lens, heads=heads)
+            print(f"[{cfg or 'default':>14}] fp8 {name:<11} {heads[0]}/{heads[1]}: {us:8.1f} us {gb:8.1f} GB/s {gb/8000:.3f}", flush=True)
+        for k, v in pairs: _C.lib.hpc_dev_tuning_set(k, 0)
