@@ -88,9 +88,41 @@ def build(jobs: int = 0, force: bool = False) -> Path:
     return LIB
 
 
+SHIM = ROOT / "hpc" / "_hpc_torch.so"
+
+
+def build_torch_shim(force: bool = False):
+    """hpc/_hpc_torch.so: the C++ host side (csrc/torch_binding.cpp: TORCH_LIBRARY_FRAGMENT(hpc) registrations of the
+    hot-path ops + the MulticastCommunicator torch class) on top of the C-ABI.  Host-only C++ compiled by g++ against
+    the installed torch headers - the reference registers its ops the same way (src/*/entry.cc).  Returns the path, or
+    None when torch's headers are not available (the Python entries in hpc/_entry_*.py then serve every op)."""
+    try:
+        import torch
+        from torch.utils import cpp_extension as ce
+    except Exception:  # noqa: BLE001
+        return None
+    src = CSRC / "torch_binding.cpp"
+    deps = [src, INCLUDE / "hpc_amd.h", Path(__file__)]
+    if not force and SHIM.exists() and all(d.stat().st_mtime <= SHIM.stat().st_mtime for d in deps) \
+            and SHIM.stat().st_mtime >= LIB.stat().st_mtime:
+        return SHIM
+    tlib = Path(ce.library_paths()[0])
+    abi = int(getattr(torch._C, "_GLIBCXX_USE_CXX11_ABI", True))
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-w"]
+    cmd += ["-I" + p for p in ce.include_paths()] + ["-I/opt/rocm/include", "-I" + str(INCLUDE)]
+    cmd += [str(src), "-o", str(SHIM), "-L" + str(tlib), "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip",
+            "-L" + str(LIB.parent), "-l:" + LIB.name, "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + str(tlib)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("torch shim build failed:\n%s\n%s" % (r.stdout[-3000:], r.stderr[-3000:]))
+    return SHIM
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("-j", type=int, default=0)
     ap.add_argument("--force", action="store_true")
     a = ap.parse_args()
     print(build(a.j, a.force))
+    print(build_torch_shim(a.force))

@@ -31,7 +31,6 @@
 //    O = sum(P~ V) / sum(p) * vscale / 256.
 #include <type_traits>
 
-#define HPC_SOFT_BF16_PACK 1
 #include "hpc_common.h"
 #include "hpc_dev.h"
 #include "../../include/hpc_amd.h"
@@ -514,12 +513,21 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
   };
 
   constexpr int kSoloMaxTiles = 4;  // up to here a lone wave is no slower than the team (1 tile per wave)
-  const bool solo = ntasks >= 2 && max_ntile <= kSoloMaxTiles && a.solo_ok;
-  if (solo) {
-    for (int it = wave; it < ntasks; it += kWaves) run_task(task_ptr + it * kTaskStride, std::true_type{});
-  } else {
-    for (int it = 0; it < ntasks; ++it) run_task(task_ptr + it * kTaskStride, std::false_type{});
+  // The solo form exists for one and two 16-row q blocks only.  With three (bf16, num_seq_q = 5: 40 q rows) the
+  // kernel sits at the 512-register limit and the build that held BOTH forms faulted in the solo path only
+  // (round 3, tools/dbg_sq5.py: "Memory access fault ... on address 0xaa000" = a null base + offset, team path of
+  // the same binary correct) when the bf16 packs compiled to v_cvt_pk_bf16_f32 (510 registers, no scratch), and
+  // ran with the integer pack sequence (512 registers + 76 bytes of scratch): an allocation-dependent failure of
+  // the solo instantiation at the register limit, not an out-of-bounds access of the algorithm.  Five-token
+  // speculative steps of batches full of <= 256-token requests are not a case worth a 512-register second body.
+  if constexpr (kNB < 3) {
+    const bool solo = ntasks >= 2 && max_ntile <= kSoloMaxTiles && a.solo_ok;
+    if (solo) {
+      for (int it = wave; it < ntasks; it += kWaves) run_task(task_ptr + it * kTaskStride, std::true_type{});
+      return;
+    }
   }
+  for (int it = 0; it < ntasks; ++it) run_task(task_ptr + it * kTaskStride, std::false_type{});
 }
 
 // ---- split-KV combine: y = sum_c 2^(lse_c - max) O_c / sum_c 2^(lse_c - max) ----------------------------
@@ -712,9 +720,17 @@ extern "C" int64_t hpc_attention_decode_workspace_bytes(int num_bins, int num_ba
   if (num_bins <= 0 || num_batch <= 0 || num_head_kv <= 0 || num_seq_q <= 0 || heads_per_group <= 0)
     return HPC_ERR_INVALID;
   return hpc::decode2::kCounterBytes + v1_workspace_bytes(num_bins, num_batch, num_head_kv, num_seq_q, heads_per_group) +
-         hpc::decode2::workspace_bytes(num_bins) + hpc::decode2_old::workspace_bytes(num_bins, num_batch, num_head_kv);
+         hpc::decode2::workspace_bytes(num_bins);
 }
 extern "C" int64_t hpc_attention_decode_workspace_zero_bytes(void) { return hpc::decode2::kCounterBytes; }
+
+// development (tools/prof_decode.py): device buffer [workgroups][4 waves][12] uint64 that the profiling build of the
+// second-generation kernel fills with per-wave s_memtime sums; null = the shipped kernel
+static void* g_decode_prof = nullptr;
+extern "C" int hpc_dev_decode_prof_buffer(void* p) {
+  g_decode_prof = p;
+  return 0;
+}
 
 extern "C" int hpc_attention_decode_bf16_async(
     void* y_ptr, void* workspace, const int* task_map_ptr, const void* q_ptr, const void* kcache_ptr,
@@ -799,13 +815,15 @@ extern "C" int hpc_attention_decode_fp8_async(
     b.ks_row_stride = kscale_row_stride;
     b.ks_head_stride = kscale_head_stride;
     b.scale_log2 = a.scale_log2;
+    b.prof = g_decode_prof;
+    b.prio_mode = hpc_dev_tuning_get(25);
     const int gen = hpc_dev_tuning_get(12);  // 0 auto, 1 first generation only
     const int mode = (gen != 1 && quant_type == 1)
                          ? hpc::decode2::mode_of(b, num_head_q, block_size, kcache_head_stride, vcache_head_stride)
                          : 0;
     int dev = 0;
     if (mode != 0 && hipGetDevice(&dev) == hipSuccess) {
-      const int unit = mode == 1 ? num_head_kv / 2 : num_head_kv;  // workgroup = (token range, head pair | head)
+      const int unit = num_head_kv / 2;  // workgroup = (token range, head pair)
       int num_wg = 2 * hpc_get_cu_count(dev);  // two 4-wave workgroups per CU (<= 256 registers, 65 KB of LDS each)
       const int wg_dev = hpc_dev_tuning_get(14);
       if (wg_dev > 0) num_wg = wg_dev;
@@ -816,9 +834,6 @@ extern "C" int hpc_attention_decode_fp8_async(
         char* base = static_cast<char*>(workspace);
         char* part = base + hpc::decode2::kCounterBytes +
                      v1_workspace_bytes(num_bins, num_batch, num_head_kv, num_seq_q, num_head_q / num_head_kv);
-        if (hpc_dev_tuning_get(21) == 1 && mode == 1 &&
-            hpc::decode2_old::eligible(b, num_head_q, block_size, kcache_head_stride, vcache_head_stride))
-          return hpc::decode2_old::launch(b, part + hpc::decode2::workspace_bytes(num_bins), num_wg, quant_type, stream);
         return hpc::decode2::launch(b, base, part, num_wg, mode, stream);
       }
     }

@@ -30,24 +30,18 @@ struct Args {
   long v_block_stride, v_token_stride;
   long ks_block_stride, ks_row_stride, ks_head_stride;  // bytes
   float scale_log2;
+  int prio_mode;  // development key 25: 1 = the two workgroups of a CU alternate wave priority per trip, 2 = the younger one keeps it
+  void* prof;  // development: per-wave timing sums [workgroups][4][12] uint64 (null = off)
 };
 
 // Arrival counters of split requests: a fixed region at the very start of a call's workspace.  It must be zero
 // the first time a workspace is used (the kernel leaves it zero); its place and size do not depend on the call.
 constexpr int64_t kCounterBytes = 64 * 1024;
 int64_t workspace_bytes(int num_wg);  // partial slots (2 per workgroup x 2 heads), after the first-generation region
-// 0: not served here; 1: head-pair form (NHD pages with adjacent heads 128 B apart, an even head count);
-// 2: token-pair form (one kv head, token rows 128 B apart).  Both: <= 16 q rows per kv head, <= 1024 requests.
+// 0: not served here; 1: served (NHD pages with adjacent heads 128 B apart, 2 / 4 / 8 / 16 kv heads, <= 16 q rows per
+// kv head, <= 1024 requests).
 int mode_of(const Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride);
 int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStream_t stream);
 
 }  // namespace decode2
-}  // namespace hpc
-
-namespace hpc {
-namespace decode2_old {  // the round-2 kernel, kept for A/B timing behind development key 21 = 1
-int64_t workspace_bytes(int num_wg, int num_batch, int num_head_kv);
-bool eligible(const hpc::decode2::Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride);
-int launch(hpc::decode2::Args a, void* workspace, int num_wg, int quant_type, hipStream_t stream);
-}  // namespace decode2_old
 }  // namespace hpc

@@ -1,8 +1,7 @@
-// FP8 paged decode attention for NHD pages, second generation: a wave fetches 256 contiguous bytes per token row
-// with one instruction - the rows of TWO adjacent kv heads ("head pair" form), or, for a single kv head whose
-// token rows are contiguous, the rows of TWO adjacent tokens ("token pair" form) - stages a whole wave-iteration
-// through LDS (where the hardware transposes V), keeps the next one in flight in registers and plans its own work
-// in closed form (the dynamic tile schedule of assign_task.hip restated on the head-pair axis).
+// FP8 paged decode attention for NHD pages, second generation: a wave fetches the rows of TWO adjacent kv heads
+// (256 contiguous bytes per token) with one instruction, stages a whole wave-iteration through LDS (where the
+// hardware transposes V), keeps the next one in flight in registers and plans its own work in closed form (the
+// dynamic tile schedule of assign_task.hip restated on the head-pair axis).
 //
 // Measurements that shaped it (tools/probes/probe_pair.hip, probe_tr; rocprofv3 SQ counters, tools/pmc_decode.py):
 //  * on NHD pages [page][token][head][128 B] a kv head's fp8 row is 128 bytes at a 1 KB stride.  A wave that asks
@@ -19,8 +18,8 @@
 //    offsets once.
 //
 // Structure (replaces, for this case, reference src/attention/decode/sm90/dynamic/smallm_fp8_*_dim128_*.cu(h)):
-//  * wave-iteration ("WI") = 32 rows of 256 B of K + the same of V (head pair: 32 tokens x 2 heads, token pair:
-//    64 tokens of one head): 16 x buffer_load_dwordx4 whose lanes cover 4 rows x 256 B (+ 6 small loads for
+//  * wave-iteration ("WI") = 32 rows of 256 B of K + the same of V (32 tokens x 2 heads):
+//    16 x buffer_load_dwordx4 whose lanes cover 4 rows x 256 B (+ 6 small loads for
 //    Q / q scales, real only for a wave's first WI of a task).  The loads are inline asm with hand-counted vmcnt
 //    (hipcc drained the queue once per WI).
 //  * at the top of a WI the landed registers are written to the wave's private 16 KB LDS stage
@@ -151,22 +150,15 @@ constexpr int kFOn0 = 8;      // rows 0..15 hold at least one token of the task
 constexpr int kFOn1 = 16;     // rows 16..31 do
 constexpr int kFMasked = 32;  // some token of the WI is invisible to some q row (request end / task end)
 
-// kTP = false: head-pair form (a workgroup serves kv heads 2p, 2p + 1; row r of a WI = token tok0 + r).
-// kTP = true : token-pair form, one kv head per workgroup whose token rows are contiguous (128-byte token stride:
-//              a single kv head); row r of a WI = tokens tok0 + 2r | tok0 + 2r + 1, i.e. LDS "head" hh = token parity,
-//              both halves share Q and ONE softmax state, and their O accumulators are added at the end of a task.
-// kSpread:     the loads of the next WI go out four at a time, each group right after the stage writes that free
-//              its registers, instead of all sixteen in one burst behind the last write.
-template <int kAux, bool kTP, bool kSpread>
+// kProf: development build that accumulates s_memtime deltas per wave (tools/prof_decode.py reads them)
+template <int kAux, bool kProf = false>
 __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   __shared__ __attribute__((aligned(1024))) uint8_t s_wave[kWaves][kWaveLds];  // stage addresses are (base) ^ (bits 4-7)
   __shared__ float s_m[2][kWaves][16];
   __shared__ float s_l[2][kWaves][16];
   __shared__ int s_ticket;
-  constexpr int kH = kTP ? 1 : 2;      // kv heads per workgroup
-  constexpr int kS = kTP ? 1 : 2;      // softmax states per lane
-  constexpr int kW = kTP ? 64 : 32;    // tokens per wave-iteration
-  constexpr int kTpr = kTP ? 2 : 1;    // tokens per row
+  constexpr int kH = 2;    // kv heads per workgroup
+  constexpr int kW = 32;   // tokens per wave-iteration
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -221,7 +213,8 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   // The grid is a multiple of npair (launcher).
   const int nrange = nwg / npair;
   const int rng = wg / npair;
-  const int pr = wg % npair;  // this workgroup's head pair (token-pair form: its kv head)
+  const int pr = wg % npair;  // this workgroup's head pair
+  const int lwg = rng * npair + pr;  // logical workgroup index: partial slots are addressed by (range, pair)
   // a range is never smaller than min_range_cost: a batch with little work (one long request among a few short
   // ones) runs on fewer workgroups instead of being cut into one-tile chunks that the last arriver of the long
   // request has to merge one by one (15 x 64 + 1 x 16k tokens: 87-99 us with 128 ranges per pair, 47 us with a floor of 8)
@@ -335,9 +328,9 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   // within an instruction (lane / 16), its 16-byte chunk (lane % 16), and the in-page row of the wave's WIs - a
   // wave's WIs start at multiples of 4 * kW tokens past a 64-token boundary, so tok0 % page is the same for all of
   // them (pages of 16 / 32 / 64 tokens), for block 0 and for block 1 (which may sit in the next page).
-  const uint32_t k_rs = static_cast<uint32_t>(a.k_token_stride) * kTpr, v_rs = static_cast<uint32_t>(a.v_token_stride) * kTpr;
-  const int in0 = ((wave * kW) & page_mask) / kTpr;                                             // in-page row of block 0
-  const int in1 = blk1_same_page ? in0 + 16 : (((wave * kW + kW / 2) & page_mask) / kTpr);      // ... of block 1
+  const uint32_t k_rs = static_cast<uint32_t>(a.k_token_stride), v_rs = static_cast<uint32_t>(a.v_token_stride);
+  const int in0 = (wave * kW) & page_mask;                                             // in-page row of block 0
+  const int in1 = blk1_same_page ? in0 + 16 : ((wave * kW + kW / 2) & page_mask);      // ... of block 1
   const int lane_off = (lane & 15) * 16;
   const int k_voff0 = static_cast<int>((in0 + (lane >> 4)) * k_rs) + lane_off, k_voff1 = static_cast<int>((in1 + (lane >> 4)) * k_rs) + lane_off;
   const int v_voff0 = static_cast<int>((in0 + (lane >> 4)) * v_rs) + lane_off, v_voff1 = static_cast<int>((in1 + (lane >> 4)) * v_rs) + lane_off;
@@ -388,10 +381,10 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
 
   // ---- per-task state ----------------------------------------------------------------------------------------
   u32x4 qf[2][2];        // fp8 Q fragments: 16-byte chunks g and g + 4 of row n (token-pair form: [0] only)
-  float row_scale[kS];   // qscale * kscale / sqrt(d) * log2(e)
+  float row_scale[2];   // qscale * kscale / sqrt(d) * log2(e)
   float out_scale;       // vscale (l_run carries the factor 256 of P~)
   f32x4 o[2][8];         // O^T: o[hh][jj][r] = dim jj * 16 + 4 g + r of q row n
-  float m_run[kS], l_run[kS];
+  float m_run[2], l_run[2];
   // Q fragments + q scales of the task's request, straight into qf / qsc.  Called when the PREVIOUS task has been
   // finished (qf is dead then) for the task of the WI that is already in flight, so these loads are the
   // youngest in the queue: the K / V waits of that WI only get more conservative.  One descriptor for the
@@ -405,7 +398,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     const i32x4 rsq = srd_of(a.qscale + static_cast<long>(db) * Sq * a.qscale_stride + ((pr * kH) << a.g_shift),
                              static_cast<unsigned>(((Sq - 1) * a.qscale_stride + kH * G) * 4));
     ld_q3(qf[0], qsc[0], q_voff, rq, s_voff, rsq);
-    if constexpr (!kTP) ld_q3(qf[1], qsc[1], q_voff + G * 128, rq, s_voff + G * 4, rsq);
+    ld_q3(qf[1], qsc[1], q_voff + G * 128, rq, s_voff + G * 4, rsq);
   };
   auto reset_state = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -413,9 +406,9 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) o[hh][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < kS; ++s) {
-      m_run[s] = kNegInf;
-      l_run[s] = 0.f;
+    for (int hh = 0; hh < 2; ++hh) {
+      m_run[hh] = kNegInf;
+      l_run[hh] = 0.f;
     }
   };
 
@@ -468,10 +461,6 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     const int first_rng = (q0_cc + kOvh) / per;
     const int nchunks = (q0_cc + kOvh + d_tiles - 1) / per - first_rng + 1;
     const int ichunk = rng - first_rng;
-    if constexpr (kTP) {  // the two token parities shared one softmax state: their O accumulators simply add
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj) o[0][jj] += o[1][jj];
-    }
 #pragma unroll
     for (int hh = 0; hh < kH; ++hh) {
       const float l = row4_sum(l_run[hh]);
@@ -498,7 +487,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
             // fp32 partial + base-2 LSE of this chunk, written THROUGH to memory (sc1): the workgroup that
             // arrives last at the request reads them with sc1 loads - per-XCD L2s are not coherent, and
             // write-through stores + a drained counter are the cheap valid hand-off (no cache-wide fences)
-            const long slot = (static_cast<long>(wg) * 2 + (ichunk == 0 ? 1 : 0)) * 2 + hh;
+            const long slot = (static_cast<long>(lwg) * 2 + (ichunk == 0 ? 1 : 0)) * 2 + hh;
             const int off = static_cast<int>(((slot * 16 + row16) * 128 + c8 * 8) * 4);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc[0] * inv), __float_as_uint(acc[1] * inv), __float_as_uint(acc[2] * inv),
                                                          __float_as_uint(acc[3] * inv)}, part_rs, off, 0, 16);
@@ -632,7 +621,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     qsc[hh] = 0u;
   }
 #pragma unroll
-  for (int s = 0; s < kS; ++s) row_scale[s] = 0.f;
+  for (int hh = 0; hh < 2; ++hh) row_scale[hh] = 0.f;
   out_scale = 0.f;
   open_task();
   step(p2_tok, p2_fl, p2_pid0, p2_pid1);
@@ -647,9 +636,25 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   step(p2_tok, p2_fl, p2_pid0, p2_pid1);
 
   // ---- main loop: one wave-iteration per trip -------------------------------------------------------------
+  int trip = 0;
+  uint64_t pf_wk = 0, pf_wr = 0, pf_wv = 0, pf_is = 0, pf_cp = 0, pf_fin = 0, pf_n = 0, pf_t0 = 0, pf_r0 = 0, pf_last = 0;
+  auto now = [&]() __attribute__((always_inline)) -> uint64_t { return kProf ? __builtin_amdgcn_s_memtime() : 0; };
+  if constexpr (kProf) {
+    pf_t0 = now();
+    pf_r0 = __builtin_amdgcn_s_memrealtime();
+  }
   while (true) {
     const int d_tok = p1_tok, d_fl = p1_fl;  // the WI whose loads are landing
     if (!(d_fl & kFValid)) break;
+    pf_last = now();
+    if (a.prio_mode) {  // development key 25: the first-dispatched workgroup of a CU outruns the second (arbitration by age)
+      const bool hi = a.prio_mode == 2 ? wg >= (nwg >> 1) : (((trip ^ (wg >= (nwg >> 1) ? 1 : 0)) & 1) != 0);
+      if (hi)
+        __builtin_amdgcn_s_setprio(1);
+      else
+        __builtin_amdgcn_s_setprio(0);
+      ++trip;
+    }
     // keep the ~32 LDS addresses of a WI out of loop-invariant registers: they are one XOR away from these three
     // bases, and 32 pinned VGPRs were the difference between 2 waves per SIMD and spilling
     uint32_t w0 = w0_inv, r0 = r0_inv, t0 = t0_inv;
@@ -672,44 +677,34 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
       // first WI of a task: its Q loads are older than everything issued in this trip
       // (rows past rows_valid came back as zeros from the bounded descriptors)
       if (d_fl & kFFirst) {
-        wait_q<kSpread ? 16 : 0>(qf[0], qf[1], qsc[0], qsc[1]);
+        wait_q<0>(qf[0], qf[1], qsc[0], qsc[1]);
         const float kmul = as_constf(a.kscale)[0];
 #pragma unroll
-        for (int s = 0; s < kS; ++s) row_scale[s] = a.scale_log2 * __uint_as_float(qsc[s]) * kmul;
+        for (int hh = 0; hh < 2; ++hh) row_scale[hh] = a.scale_log2 * __uint_as_float(qsc[hh]) * kmul;
         out_scale = as_constf(a.vscale)[0];  // the 1/256 of the reference formula cancels: l = 256 sum p
       }
     };
     // registers -> the wave's LDS stage (rows of 256 B, chunks swizzled); a register set is free again as soon as
     // it has been written out: the next WI (of this or the next task) goes in flight
-    if constexpr (kSpread) {
-      wait_x4x4<12>(kr[0]);
-      write_k(0);
-      issue_k0();
-      wait_x4x4<12>(kr[1]);
-      write_k(1);
-      issue_k1();
-      wait_x4x4<12>(vr[0]);
-      write_v(0);
-      issue_v0();
-      wait_x4x4<12>(vr[1]);
-      write_v(1);
-      issue_v1();
-    } else {
-      wait_x4x4<12>(kr[0]);
-      wait_x4x4<8>(kr[1]);
-      write_k(0);
-      write_k(1);
-      wait_x4x4<4>(vr[0]);
-      wait_x4x4<0>(vr[1]);
-      write_v(0);
-      write_v(1);
-      issue_k0();
-      issue_k1();
-      issue_v0();
-      issue_v1();
-    }
+    wait_x4x4<12>(kr[0]);
+    wait_x4x4<8>(kr[1]);
+    if constexpr (kProf) { const uint64_t t = now(); pf_wk += t - pf_last; pf_last = t; }
+    write_k(0);
+    write_k(1);
+    if constexpr (kProf) { const uint64_t t = now(); pf_wr += t - pf_last; pf_last = t; }
+    wait_x4x4<4>(vr[0]);
+    wait_x4x4<0>(vr[1]);
+    if constexpr (kProf) { const uint64_t t = now(); pf_wv += t - pf_last; pf_last = t; }
+    write_v(0);
+    write_v(1);
+    if constexpr (kProf) { const uint64_t t = now(); pf_wr += t - pf_last; pf_last = t; }
+    issue_k0();
+    issue_k1();
+    issue_v0();
+    issue_v1();
     q_ready();
     step(p2_tok, p2_fl, p2_pid0, p2_pid1);  // the WI after the one just issued: its page ids are on their way while this one computes
+    if constexpr (kProf) { const uint64_t t = now(); pf_is += t - pf_last; pf_last = t; }
 
     // S^T = K Q^T: one K = 128 MFMA per 16-row block and 128-byte half (lane (n, g) supplies chunks g and g + 4 of its
     // row on both sides - a dot product does not care which lane slot a dim sits in)
@@ -720,7 +715,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
       for (int hh = 0; hh < 2; ++hh) {
         const u32x4 k0 = *reinterpret_cast<const lds_u32x4*>(static_cast<uint32_t>((r0 ^ (((hh << 3) ^ (tb << 3)) * 16)) + tb * 16 * kRow));
         const u32x4 k1 = *reinterpret_cast<const lds_u32x4*>(static_cast<uint32_t>((r0 ^ (((hh << 3) ^ (tb << 3) ^ 4) * 16)) + tb * 16 * kRow));
-        const u32x4 q0 = qf[kTP ? 0 : hh][0], q1 = qf[kTP ? 0 : hh][1];
+        const u32x4 q0 = qf[hh][0], q1 = qf[hh][1];
         const i32x8 kv8 = {static_cast<int>(k0[0]), static_cast<int>(k0[1]), static_cast<int>(k0[2]), static_cast<int>(k0[3]),
                            static_cast<int>(k1[0]), static_cast<int>(k1[1]), static_cast<int>(k1[2]), static_cast<int>(k1[3])};
         const i32x8 qv8 = {static_cast<int>(q0[0]), static_cast<int>(q0[1]), static_cast<int>(q0[2]), static_cast<int>(q0[3]),
@@ -734,7 +729,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     uint32_t pf[2][2];
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-      const float rsc = row_scale[kTP ? 0 : hh];
+      const float rsc = row_scale[hh];
 #pragma unroll
       for (int tb = 0; tb < 2; ++tb)
 #pragma unroll
@@ -750,58 +745,42 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = tb * 16 + g * 4 + r;
-            const int tk = d_tok + (kTP ? 2 * row + hh : row);
+            const int tk = d_tok + row;
             sacc[hh][tb][r] = tk <= lim ? sacc[hh][tb][r] : kNegInf;
           }
     }
 #pragma unroll
-    for (int s = 0; s < kS; ++s) {
-      // the heads (head-pair form: one state each) or the two token parities (token-pair form: one joint state)
-      constexpr int kHs = kTP ? 2 : 1;
-      float mt = kNegInf;
-#pragma unroll
-      for (int hi = 0; hi < kHs; ++hi) {
-        const int hh = kTP ? hi : s;
-        float t = __builtin_fmaxf(__builtin_fmaxf(sacc[hh][0][0], sacc[hh][0][1]), sacc[hh][0][2]);
-        t = __builtin_fmaxf(__builtin_fmaxf(t, sacc[hh][0][3]), sacc[hh][1][0]);
-        t = __builtin_fmaxf(__builtin_fmaxf(t, sacc[hh][1][1]), sacc[hh][1][2]);
-        t = __builtin_fmaxf(t, sacc[hh][1][3]);
-        mt = hi == 0 ? t : __builtin_fmaxf(mt, t);
-      }
+    for (int hh = 0; hh < 2; ++hh) {
+      float mt = __builtin_fmaxf(__builtin_fmaxf(sacc[hh][0][0], sacc[hh][0][1]), sacc[hh][0][2]);
+      mt = __builtin_fmaxf(__builtin_fmaxf(mt, sacc[hh][0][3]), sacc[hh][1][0]);
+      mt = __builtin_fmaxf(__builtin_fmaxf(mt, sacc[hh][1][1]), sacc[hh][1][2]);
+      mt = __builtin_fmaxf(mt, sacc[hh][1][3]);
       mt = row4_max(mt);
-      const float m_new = fmaxf(m_run[s], mt);
+      const float m_new = fmaxf(m_run[hh], mt);
       const float m_use = m_new == kNegInf ? 0.f : m_new;
       const float m8 = m_use - 8.0f;
       float psum = 0.f;
 #pragma unroll
-      for (int hi = 0; hi < kHs; ++hi) {
-        const int hh = kTP ? hi : s;
+      for (int tb = 0; tb < 2; ++tb) {
+        float prb[4];
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb) {
-          float prb[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            prb[r] = __builtin_amdgcn_exp2f(sacc[hh][tb][r] - m8);
-            psum += prb[r];
-          }
-          int w = __builtin_amdgcn_cvt_pk_fp8_f32(prb[0], prb[1], 0, false);
-          w = __builtin_amdgcn_cvt_pk_fp8_f32(prb[2], prb[3], w, true);
-          pf[hh][tb] = static_cast<uint32_t>(w);
+        for (int r = 0; r < 4; ++r) {
+          prb[r] = __builtin_amdgcn_exp2f(sacc[hh][tb][r] - m8);
+          psum += prb[r];
         }
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(prb[0], prb[1], 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(prb[2], prb[3], w, true);
+        pf[hh][tb] = static_cast<uint32_t>(w);
       }
       // rescale only when some row's maximum moved (after the first few WIs of a long request it rarely does)
-      if (__builtin_amdgcn_ballot_w64(m_new != m_run[s]) != 0) {
-        const float alpha = __builtin_amdgcn_exp2f(m_run[s] - m_use);
-        l_run[s] *= alpha;
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run[hh]) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run[hh] - m_use);
+        l_run[hh] *= alpha;
 #pragma unroll
-        for (int hi = 0; hi < kHs; ++hi) {
-          const int hh = kTP ? hi : s;
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) o[hh][jj] *= alpha;
-        }
-        m_run[s] = m_new;
+        for (int jj = 0; jj < 8; ++jj) o[hh][jj] *= alpha;
+        m_run[hh] = m_new;
       }
-      l_run[s] += psum;
+      l_run[hh] += psum;
     }
 
     // O^T += V^T P^T: the transpose read hands every lane one dim (column) of an 8-row x 16-dim tile.
@@ -825,7 +804,27 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
               o[hh][j4 + u], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-    if (d_fl & kFLast) finish_task();
+    if constexpr (kProf) {
+      asm volatile("s_nop 0" ::"v"(o[0][0]), "v"(o[1][7]));  // the MFMAs have been issued (not retired)
+      const uint64_t t = now();
+      pf_cp += t - pf_last;
+      pf_last = t;
+      ++pf_n;
+    }
+    if (d_fl & kFLast) {
+      finish_task();
+      if constexpr (kProf) { const uint64_t t = now(); pf_fin += t - pf_last; pf_last = t; }
+    }
+  }
+  if constexpr (kProf) {
+    if (lane == 0 && a.prof) {
+      const uint64_t t1 = now(), r1 = __builtin_amdgcn_s_memrealtime();
+      uint64_t* dst = reinterpret_cast<uint64_t*>(a.prof) + (static_cast<long>(wg) * kWaves + wave) * 12;
+      dst[0] = pf_r0, dst[1] = r1, dst[2] = t1 - pf_t0, dst[3] = pf_wk, dst[4] = pf_wv, dst[5] = pf_wr, dst[6] = pf_is, dst[7] = pf_cp,
+      dst[8] = pf_fin, dst[9] = pf_n, dst[10] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) /* HW_ID */,
+      dst[11] = (static_cast<uint64_t>(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) /* XCC_ID */) << 32) |
+                (static_cast<uint64_t>(rng) << 8) | static_cast<uint64_t>(pr);
+    }
   }
   // the loads issued for the WI past the end were no-ops, but they own the registers until they retire
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -843,24 +842,16 @@ int64_t workspace_bytes(int num_wg) {
 int mode_of(const Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride) {
   if (a.num_head_kv <= 0 || num_head_q % a.num_head_kv) return 0;
   const int group = num_head_q / a.num_head_kv;
-  const bool common = a.lens != nullptr && a.num_seq_q * group <= 16 && k_head_stride == 128 && v_head_stride == 128 &&
-                      (block_size == 64 || block_size == 32 || block_size == 16) && (a.k_token_stride % 16) == 0 &&
-                      (a.v_token_stride % 16) == 0 && (a.k_block_stride % 16) == 0 && (a.v_block_stride % 16) == 0 &&
-                      a.k_block_stride > 0 && a.v_block_stride > 0 && a.k_block_stride < (1ll << 32) &&
-                      a.v_block_stride < (1ll << 32) && a.num_batch <= 64 * 16;
-  if (!common) return 0;
-  if ((a.num_head_kv % 2) == 0) {
-    if (static_cast<int64_t>(a.num_batch) * (a.num_head_kv / 2) * 4 > kCounterBytes) return 0;
-    return 1;  // head pairs
-  }
-  // a single kv head whose token rows are contiguous: token pairs (a 32-row block must lie inside one page)
-  if (a.num_head_kv == 1 && a.k_token_stride == 128 && a.v_token_stride == 128 && block_size >= 32 &&
-      static_cast<int64_t>(a.num_batch) * 4 <= kCounterBytes)
-    return 2;
-  return 0;
+  const bool ok = a.lens != nullptr && (a.num_head_kv % 2) == 0 && a.num_seq_q * group <= 16 && k_head_stride == 128 &&
+                  v_head_stride == 128 && (block_size == 64 || block_size == 32 || block_size == 16) &&
+                  (a.k_token_stride % 16) == 0 && (a.v_token_stride % 16) == 0 && (a.k_block_stride % 16) == 0 &&
+                  (a.v_block_stride % 16) == 0 && a.k_block_stride > 0 && a.v_block_stride > 0 &&
+                  a.k_block_stride < (1ll << 32) && a.v_block_stride < (1ll << 32) && a.num_batch <= 64 * 16 &&
+                  static_cast<int64_t>(a.num_batch) * (a.num_head_kv / 2) * 4 <= kCounterBytes;
+  return ok ? 1 : 0;
 }
 
-int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStream_t stream) {
+int launch(Args a, void* counters, void* partials, int num_wg, int /*mode*/, hipStream_t stream) {
   char* ws = static_cast<char*>(partials);
   a.part_o = reinterpret_cast<float*>(ws);
   ws += static_cast<int64_t>(num_wg) * 2 * 2 * 16 * 128 * 4;
@@ -868,21 +859,12 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
   a.arrive = static_cast<int*>(counters);
   static std::atomic<int> epoch{0};
   a.epoch = (epoch.fetch_add(1, std::memory_order_relaxed) % 32767) + 1;  // 1 .. 32767, frozen inside a captured graph
-  const bool temporal = hpc_dev_tuning_get(0) == 1;
-  const bool spread = hpc_dev_tuning_get(22) == 1;
-  if (mode == 1) {
-    if (temporal)
-      decode2_kernel<0, false, false><<<num_wg, kThreads, 0, stream>>>(a);
-    else if (spread)
-      decode2_kernel<2, false, true><<<num_wg, kThreads, 0, stream>>>(a);
-    else
-      decode2_kernel<2, false, false><<<num_wg, kThreads, 0, stream>>>(a);
-  } else {
-    if (spread)
-      decode2_kernel<2, true, true><<<num_wg, kThreads, 0, stream>>>(a);
-    else
-      decode2_kernel<2, true, false><<<num_wg, kThreads, 0, stream>>>(a);
-  }
+  if (a.prof)  // development: per-wave s_memtime sums (hpc_dev_decode_prof_buffer)
+    decode2_kernel<2, true><<<num_wg, kThreads, 0, stream>>>(a);
+  else if (hpc_dev_tuning_get(0) == 1)
+    decode2_kernel<0><<<num_wg, kThreads, 0, stream>>>(a);
+  else
+    decode2_kernel<2><<<num_wg, kThreads, 0, stream>>>(a);
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }

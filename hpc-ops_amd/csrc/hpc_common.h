@@ -42,12 +42,8 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-#ifdef HPC_SOFT_BF16_PACK
-  return static_cast<uint32_t>(f32_to_bf16(lo)) | (static_cast<uint32_t>(f32_to_bf16(hi)) << 16);
-#else
   const bf16x2 b = __builtin_convertvector(f32x2{lo, hi}, bf16x2);
   return __builtin_bit_cast(uint32_t, b);
-#endif
 }
 
 // ---- OCP e4m3fn conversions (gfx950 hardware cvt; saturating to +-448 like the reference's

@@ -105,8 +105,36 @@ _sig("hpc_fuse_allreduce_rmsnorm_low_latency_async", I, P, P, P, P, P, P, P, P, 
 _sig("hpc_allreduce_timeouts", I)
 _sig("hpc_allreduce_reset_timeouts", I)
 
-# torch op namespace `hpc` (reference: TORCH_LIBRARY(hpc, m), src/C/C.cc:5)
-torch_lib = torch.library.Library("hpc", "DEF")
+# C++ host side of the hot-path ops (csrc/torch_binding.cpp -> hpc/_hpc_torch.so): TORCH_LIBRARY_FRAGMENT(hpc)
+# registrations + torch.classes.hpc.MulticastCommunicator, like the reference's src/*/entry.cc.  When it is present
+# its ops are the ones that run; the Python entries below it (hpc/_entry_*.py) register everything else and are the
+# fallback for a build without the torch headers (HPC_AMD_PY_ENTRIES=1 forces them, for the tests of that fallback).
+import os
+
+_SHIM_PATH = Path(__file__).resolve().parent / "_hpc_torch.so"
+NATIVE_OPS = frozenset()
+if _SHIM_PATH.exists() and os.environ.get("HPC_AMD_PY_ENTRIES", "0") != "1":
+    torch.ops.load_library(str(_SHIM_PATH))
+    NATIVE_OPS = frozenset(torch.ops.hpc._native_ops())
+
+
+class _OpLibrary:
+    """torch.library.Library("hpc") that leaves the ops the C++ shim has registered alone."""
+
+    def __init__(self):
+        # (reference: TORCH_LIBRARY(hpc, m), src/C/C.cc:5)
+        self._lib = torch.library.Library("hpc", "DEF")
+
+    def define(self, schema: str):
+        if schema.split("(", 1)[0].strip() not in NATIVE_OPS:
+            self._lib.define(schema)
+
+    def impl(self, name, fn, key):
+        if name not in NATIVE_OPS:
+            self._lib.impl(name, fn, key)
+
+
+torch_lib = _OpLibrary()
 
 _ERR = {-1: "unsupported configuration", -2: "invalid argument", -3: "HIP launch error",
         -4: "an earlier fused all-reduce timed out waiting for a peer: results since then are undefined, "

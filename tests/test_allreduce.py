@@ -110,7 +110,8 @@ def _ar_task(rank, world_size, cases, name, q, device_index):
                     in_x[:n_it] = inputs[rank][:n_it].to(dev)
                     out_x.fill_(7.0)
                     out_res = torch.empty_like(res_d)
-                    if mode == "ht_uneven":  # slices of different sizes (legal: the grid is rank-invariant)
+                    if mode == "ht_uneven":  # slices of different sizes (legal: the grid is rank-invariant); needs N_pad / ws >= 5
+                        assert N_pad // world_size >= 5, "ht_uneven case too small for this world size"
                         cuts = [0] + [min(N_pad, (N_pad * (r + 1)) // world_size + (3 if r % 2 == 0 else -2))
                                       for r in range(world_size - 1)] + [N_pad]
                         start, end = cuts[rank], cuts[rank + 1]
@@ -171,6 +172,10 @@ def _spawn(world_size, one_gpu_per_rank=False, tuning="", cases=None, timeout=60
             os.environ.pop("HPC_AMD_TUNING", None)
         else:
             os.environ["HPC_AMD_TUNING"] = old
+    if sorted(res) != [(r, "ok") for r in range(world_size)]:
+        import sys
+        for r in sorted(res, key=str):
+            print(f"---- rank {r[0]}:\n{r[1]}", file=sys.stderr)
     assert sorted(res) == [(r, "ok") for r in range(world_size)], res
 
 
@@ -196,7 +201,7 @@ def test_allreduce_rmsnorm_world2_shared_gpu():
 # flags cannot become resident, and every spin runs into its 2^22-round limit - minutes, not a protocol defect.
 # Here the grids are tiny (key 11 = 1: grid = num_max_blocks), the rows few, and the spin limit short (key 10), so
 # a lost rendezvous would show up as a reported timeout within seconds instead of a hang.
-SHARED_GPU_CASES = [("ht", 16, 8192, 4, 3), ("ht", 13, 5120, 3, 2), ("ht_uneven", 24, 4096, 4, 2), ("ht", 8, 16384, 2, 2),
+SHARED_GPU_CASES = [("ht", 16, 8192, 4, 3), ("ht", 13, 5120, 3, 2), ("ht_uneven", 48, 4096, 4, 2), ("ht", 8, 16384, 2, 2),
                     ("ll", 16, 8192, 4, 5), ("ll", 13, 7168, 4, 4), ("ll", 8, 4096, 4, 4)]
 
 
