@@ -528,6 +528,51 @@ def extra_router(dev, hpc):
     return {"router_n256_k4096_top8": out}
 
 
+def extra_moe_presets(dev, hpc, presets=("qwen3-235b", "deepseek-v3"), batches=(64, 4096)):
+    """The reference MoE benchmark's model presets through the call its driver makes
+    (benchmark/fused_moe/benchmark_fuse_moe.py:44-50; backends/hpcops.py:49-57: scaled_fp8_quant of the bf16
+    activations + hpc.fuse_moe(..., use_bf16_mul=True), per-tensor scales, TP = EP = 1, inputs generated like
+    backends/base.py:93-178).  FLOPs = 2 * T * topk * 3 * I * H."""
+    table = {"qwen3-235b": (128, 8, 4096, 1536), "hunyuan-v1": (64, 8, 4096, 3072), "hunyuan-v2": (128, 8, 4096, 4096),
+             "hunyuan-v3": (192, 8, 4096, 1536), "deepseek-v3": (256, 8, 7168, 2048)}
+    out = {}
+    for name in presets:
+        E, k, H, I = table[name]
+        g = torch.Generator(device=dev).manual_seed(0)
+        w1 = torch.empty(E, 2 * I, H, dtype=torch.float8_e4m3fn, device=dev)
+        w2 = torch.empty(E, H, I, dtype=torch.float8_e4m3fn, device=dev)
+        s1, s2 = torch.empty(E, device=dev), torch.empty(E, device=dev)
+        for e in range(E):  # per-expert dynamic per-tensor quantisation (backends/base.py:120-128)
+            h1 = torch.randn(2 * I, H, device=dev, generator=g).bfloat16()
+            h2 = torch.randn(H, I, device=dev, generator=g).bfloat16()
+            s1[e], s2[e] = h1.float().abs().max() / 448.0, h2.float().abs().max() / 448.0
+            w1[e], w2[e] = (h1.float() / s1[e]).to(torch.float8_e4m3fn), (h2.float() / s2[e]).to(torch.float8_e4m3fn)
+        a_scale = torch.full((1,), 1e-2, device=dev)
+        act_scale = torch.ones(1, device=dev)
+        gus = s1 * a_scale
+        row = {}
+        for T in batches:
+            ids = torch.stack([torch.sort(torch.randperm(E, device=dev, generator=g)[:k].to(torch.int32)).values for _ in range(min(T, 512))])
+            ids = ids.repeat((T + ids.size(0) - 1) // ids.size(0), 1)[:T].contiguous()
+            tw = torch.softmax(torch.randn(T, k, device=dev, generator=g), dim=-1)
+            a_half = torch.randn(T, H, device=dev, generator=g).bfloat16() / 10
+
+            def call():
+                x8 = hpc.scaled_fp8_quant(a_half, a_scale)
+                x8 = x8[0] if isinstance(x8, (tuple, list)) else x8
+                return hpc.fuse_moe(x8, w1, w2, gus, s2, act_scale, ids, tw, 0, E, use_bf16_mul=True)
+
+            us = timed(call, iters=10, warm=2, graph=True)
+            flops = 2.0 * T * k * 3 * I * H
+            hit = int(torch.unique(ids).numel())
+            row[f"T{T}"] = {"us": round(us, 1), "TFLOPS": round(flops / us / 1e6, 1),
+                            "weight_GBps": round(hit * 3 * I * H / us / 1e3, 1)}
+        out[name] = dict(row, experts=E, hidden=H, inter=I)
+        del w1, w2
+        torch.cuda.empty_cache()
+    return {"fuse_moe_reference_presets_pertensor_bf16mul": out}
+
+
 # ================================================================================ AllReduce (N >= 1)
 def extra_host_overhead(dev, hpc, calls=200):
     """EAGER per-call host cost of the hot-path ops (no hipGraph): `enqueue_us` = host wall time per call over
@@ -913,7 +958,7 @@ def main():
                 second = {"error": repr(e)[:300]}
             torch.cuda.empty_cache()
         if not args.no_extras:  # N-independent single-GPU numbers: reported at N=1
-            for fn in (extra_decode, extra_rope, extra_router, extra_sampler, extra_prefill, extra_host_overhead):
+            for fn in (extra_decode, extra_moe_presets, extra_rope, extra_router, extra_sampler, extra_prefill, extra_host_overhead):
                 try:
                     r = fn(dev, hpc)
                     extras.update({"eager_host_overhead": r} if fn is extra_host_overhead else r)

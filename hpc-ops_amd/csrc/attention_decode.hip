@@ -816,7 +816,6 @@ extern "C" int hpc_attention_decode_fp8_async(
     b.ks_head_stride = kscale_head_stride;
     b.scale_log2 = a.scale_log2;
     b.prof = g_decode_prof;
-    b.prio_mode = hpc_dev_tuning_get(25);
     const int gen = hpc_dev_tuning_get(12);  // 0 auto, 1 first generation only
     const int mode = (gen != 1 && quant_type == 1)
                          ? hpc::decode2::mode_of(b, num_head_q, block_size, kcache_head_stride, vcache_head_stride)

@@ -30,7 +30,6 @@ struct Args {
   long v_block_stride, v_token_stride;
   long ks_block_stride, ks_row_stride, ks_head_stride;  // bytes
   float scale_log2;
-  int prio_mode;  // development key 25: 1 = the two workgroups of a CU alternate wave priority per trip, 2 = the younger one keeps it
   void* prof;  // development: per-wave timing sums [workgroups][4][12] uint64 (null = off)
 };
 

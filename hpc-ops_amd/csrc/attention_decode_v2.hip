@@ -636,7 +636,6 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   step(p2_tok, p2_fl, p2_pid0, p2_pid1);
 
   // ---- main loop: one wave-iteration per trip -------------------------------------------------------------
-  int trip = 0;
   uint64_t pf_wk = 0, pf_wr = 0, pf_wv = 0, pf_is = 0, pf_cp = 0, pf_fin = 0, pf_n = 0, pf_t0 = 0, pf_r0 = 0, pf_last = 0;
   auto now = [&]() __attribute__((always_inline)) -> uint64_t { return kProf ? __builtin_amdgcn_s_memtime() : 0; };
   if constexpr (kProf) {
@@ -647,14 +646,6 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     const int d_tok = p1_tok, d_fl = p1_fl;  // the WI whose loads are landing
     if (!(d_fl & kFValid)) break;
     pf_last = now();
-    if (a.prio_mode) {  // development key 25: the first-dispatched workgroup of a CU outruns the second (arbitration by age)
-      const bool hi = a.prio_mode == 2 ? wg >= (nwg >> 1) : (((trip ^ (wg >= (nwg >> 1) ? 1 : 0)) & 1) != 0);
-      if (hi)
-        __builtin_amdgcn_s_setprio(1);
-      else
-        __builtin_amdgcn_s_setprio(0);
-      ++trip;
-    }
     // keep the ~32 LDS addresses of a WI out of loop-invariant registers: they are one XOR away from these three
     // bases, and 32 pinned VGPRs were the difference between 2 waves per SIMD and spilling
     uint32_t w0 = w0_inv, r0 = r0_inv, t0 = t0_inv;

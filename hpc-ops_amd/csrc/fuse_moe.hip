@@ -31,6 +31,12 @@ int hpc_group_gemm_blockwise_fp8_act(void* act_out, void* act_scale, const void*
                                      int k, int num_block_k_pad4, int64_t xscale_row_stride, int64_t xscale_kb_stride,
                                      const void* cu_tiles128_ptr, hipStream_t stream);
 
+int hpc_group_gemm_pertensor_fp8_act(void* act_out, const void* x_ptr, const void* w_ptr, const void* seqlens_ptr,
+                                     const void* cu_seqlens_ptr, const void* yscale_ptr, const void* row_index_ptr,
+                                     const void* act_mul_scale_ptr, int use_bf16_mul, int num_group, int m, int x_rows,
+                                     int n, int k, const void* cu_tiles128_ptr, hipStream_t stream);
+bool hpc_ggemm_p8_selected(int num_group, int m, int n, int k, const void* cu_tiles128);
+
 extern "C" int hpc_group_gemm_pertensor_fp8_async(void* y_ptr, const void* x_ptr, const void* w_ptr,
                                                   const void* seqlens_ptr, const void* cu_seqlens_ptr,
                                                   const void* yscale_ptr, const void* row_index_ptr,
@@ -639,15 +645,27 @@ extern "C" int hpc_fuse_moe_pertensor_async(
                                         ws + w.seqlens, ws + w.cu_seqlens, ws + w.tiles,
                                         ws + w.cu_tiles, ws + w.topk_pos, ws + w.row_index, stream);
   if (rc) return rc;
-  rc = hpc_group_gemm_pertensor_fp8_async(ws + w.gate_up_out, x_ptr, gate_up_weight_ptr, ws + w.seqlens,
-                                          ws + w.cu_seqlens, gate_up_scale_ptr, ws + w.row_index,
-                                          num_expert, m, num_tokens, intermediate_size2, hidden_size,
-                                          ws + w.cu_tiles, stream);
-  if (rc) return rc;
-  rc = hpc_act_mul_and_quant_async(ws + w.down_in, ws + w.gate_up_out, act_and_mul_scale_ptr,
-                                   reinterpret_cast<const int*>(ws + w.cu_seqlens) + num_expert, m, inter,
-                                   use_bf16_mul, stream);
-  if (rc) return rc;
+  // With the 256 x 256 tile kernel the activation + quantisation runs in the gate-up GEMM's epilogue (a tile = 128
+  // gate rows + the 128 up rows of the same columns): the bf16 gate-up matrix is never written (development key
+  // 19 = 1 keeps the two kernels apart)
+  if ((inter & 127) == 0 && (hidden_size & 127) == 0 && hpc_dev_tuning_get(19) != 1 &&
+      hpc_ggemm_p8_selected(num_expert, m, intermediate_size2, hidden_size, ws + w.cu_tiles)) {
+    rc = hpc_group_gemm_pertensor_fp8_act(ws + w.down_in, x_ptr, gate_up_weight_ptr, ws + w.seqlens, ws + w.cu_seqlens,
+                                          gate_up_scale_ptr, ws + w.row_index, act_and_mul_scale_ptr, use_bf16_mul,
+                                          num_expert, m, num_tokens, intermediate_size2, hidden_size, ws + w.cu_tiles,
+                                          stream);
+    if (rc) return rc;
+  } else {
+    rc = hpc_group_gemm_pertensor_fp8_async(ws + w.gate_up_out, x_ptr, gate_up_weight_ptr, ws + w.seqlens,
+                                            ws + w.cu_seqlens, gate_up_scale_ptr, ws + w.row_index,
+                                            num_expert, m, num_tokens, intermediate_size2, hidden_size,
+                                            ws + w.cu_tiles, stream);
+    if (rc) return rc;
+    rc = hpc_act_mul_and_quant_async(ws + w.down_in, ws + w.gate_up_out, act_and_mul_scale_ptr,
+                                     reinterpret_cast<const int*>(ws + w.cu_seqlens) + num_expert, m, inter,
+                                     use_bf16_mul, stream);
+    if (rc) return rc;
+  }
   rc = hpc_group_gemm_pertensor_fp8_async(ws + w.down_out, ws + w.down_in, down_weight_ptr, ws + w.seqlens,
                                           ws + w.cu_seqlens, down_scale_ptr, nullptr, num_expert, m, m,
                                           hidden_size, inter, ws + w.cu_tiles, stream);

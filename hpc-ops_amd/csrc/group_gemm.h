@@ -26,6 +26,10 @@ struct Args {
   // act_scale f32 [M, inter / 128]; y is not written
   uint8_t* act_out = nullptr;
   float* act_scale = nullptr;
+  // per-tensor form of the same epilogue (act_scale == nullptr): out = e4m3(silu(gate) * up * act_mul_scale[0]), with
+  // the bf16-rounded multiply of the reference when use_bf16_mul (reference src/activation/activation.cu:19-75)
+  const float* act_mul_scale = nullptr;
+  int use_bf16_mul = 0;
 };
 
 }  // namespace ggemm

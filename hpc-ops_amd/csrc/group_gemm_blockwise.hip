@@ -379,6 +379,42 @@ extern "C" int hpc_group_gemm_pertensor_fp8_async(void* y_ptr, const void* x_ptr
   return launch_stream_gemm(a, num_group, m, n, cu_tiles128_ptr, stream);
 }
 
+// Gate-up GEMM of the per-tensor fused MoE with out = e4m3(silu(gate) * up * act_mul_scale[0]) in its epilogue (256 x 256
+// tile kernel; the caller has checked hpc_ggemm_p8_selected, inter % 128 == 0 and k % 128 == 0).  Same arguments as
+// hpc_group_gemm_pertensor_fp8_async with n = 2 * inter; writes act_out e4m3 [m, inter].
+int hpc_group_gemm_pertensor_fp8_act(void* act_out, const void* x_ptr, const void* w_ptr, const void* seqlens_ptr,
+                                     const void* cu_seqlens_ptr, const void* yscale_ptr, const void* row_index_ptr,
+                                     const void* act_mul_scale_ptr, int use_bf16_mul, int num_group, int m, int x_rows,
+                                     int n, int k, const void* cu_tiles128_ptr, hipStream_t stream) {
+  using namespace hpc::ggemm;
+  if (static_cast<int64_t>(x_rows) * k > 0xfffffe00ll || static_cast<int64_t>(n) * k > 0xfffffe00ll) return HPC_ERR_UNSUPPORTED;
+  Args a;
+  a.x = static_cast<const uint8_t*>(x_ptr);
+  a.w = static_cast<const uint8_t*>(w_ptr);
+  a.xs = static_cast<const float*>(yscale_ptr);
+  a.ws = static_cast<const float*>(yscale_ptr);
+  a.y = nullptr;
+  a.seqlens = static_cast<const int*>(seqlens_ptr);
+  a.cu_seqlens = static_cast<const int*>(cu_seqlens_ptr);
+  a.row_index = static_cast<const int*>(row_index_ptr);
+  a.col_base = nullptr;
+  a.N = n;
+  a.K = k;
+  a.KB = k / 128;
+  a.tile_m = 16;
+  a.ws_group_stride = 1;
+  a.ws_ntile_stride = 0;
+  a.ws_kb_stride = 0;
+  a.has_xs = 0;
+  a.x_bytes = static_cast<unsigned>(static_cast<int64_t>(x_rows) * k);
+  a.xs_row_stride = 0;
+  a.xs_kb_stride = 0;
+  a.act_out = static_cast<uint8_t*>(act_out);
+  a.act_mul_scale = static_cast<const float*>(act_mul_scale_ptr);
+  a.use_bf16_mul = use_bf16_mul;
+  return hpc_ggemm_launch_p8(a, static_cast<const int*>(cu_tiles128_ptr), num_group, m, n, stream);
+}
+
 // Gate-up GEMM of the fused MoE with SiLU(gate) * up + 128-block quantisation in its epilogue (256 x 256 tile kernel;
 // the caller has checked hpc_ggemm_p8_selected and inter % 128 == 0).  Same arguments as
 // hpc_group_gemm_blockwise_fp8_async with n = 2 * inter; writes act_out e4m3 [m, inter] and act_scale f32 [m, inter/128].

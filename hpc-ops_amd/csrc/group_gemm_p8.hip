@@ -441,6 +441,32 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
       for (int jj = 0; jj < 2; ++jj) {
         const int j = j0 + jj;
         const int slot = mt0 + wm * 64 + j * 16 + r16;
+        if constexpr (!kHasXs) {
+          // per-tensor API: a = silu(g) * u (bf16-rounded factors and product when use_bf16_mul), times one scale -
+          // the arithmetic of act_mul_quant_kernel (csrc/fuse_moe.hip), value for value
+          const float sc = a.act_mul_scale[0];
+          uint8_t* orow = a.act_out + static_cast<long>(m0 + slot) * inter + col0 + g4 * 4;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const u32x2 ov = *reinterpret_cast<const u32x2*>(xch + (i * 2 + jj) * 128);
+            const uint32_t m01 = pack_bf16x2(tot[i][j][0], tot[i][j][1]), m23 = pack_bf16x2(tot[i][j][2], tot[i][j][3]);
+            const float mine[4] = {bf16lo_to_f32(m01), bf16hi_to_f32(m01), bf16lo_to_f32(m23), bf16hi_to_f32(m23)};
+            const float oth[4] = {bf16lo_to_f32(ov[0]), bf16hi_to_f32(ov[0]), bf16lo_to_f32(ov[1]), bf16hi_to_f32(ov[1])};
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float g = kGate ? mine[r] : oth[r], u = kGate ? oth[r] : mine[r];
+              float sv = g / (1.0f + __expf(-g));
+              if (a.use_bf16_mul)
+                sv = bf16_to_f32(f32_to_bf16(bf16_to_f32(f32_to_bf16(sv)) * u));
+              else
+                sv *= u;
+              v[r] = sv * sc;
+            }
+            if (slot < m_cnt) *reinterpret_cast<uint32_t*>(orow + i * 16) = quant_4xe4m3(v[0], v[1], v[2], v[3]);
+          }
+          continue;
+        }
         float amax = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -522,6 +548,8 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a, const int* cu_tiles, int num_
   dim3 grid(static_cast<unsigned>(items));
   if (a.has_xs && a.act_out)
     gemm_fp8_p8_kernel<true, false, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  else if (a.act_out)
+    gemm_fp8_p8_kernel<false, false, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else if (a.has_xs && hpc_dev_tuning_get(18) == 1)
     gemm_fp8_p8_kernel<true, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else if (a.has_xs && hpc_dev_tuning_get(18) == 2)

@@ -59,6 +59,7 @@ extern "C" int hpc_get_cu_count(int device_id) {
 
 // Development tuning registers: see csrc/hpc_dev.h (internal; not in include/hpc_amd.h).
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -70,6 +71,7 @@ struct Tuning {
   std::atomic<int> v[kKeys];
   Tuning() {
     for (auto& x : v) x.store(0, std::memory_order_relaxed);
+    bool seeded = false;
     const char* env = std::getenv("HPC_AMD_TUNING");  // "key=value,key=value"
     while (env && *env) {
       char* end = nullptr;
@@ -78,10 +80,19 @@ struct Tuning {
       env = end + 1;
       const long val = std::strtol(env, &end, 10);
       if (end == env) break;
-      if (k >= 0 && k < kKeys) v[k].store(static_cast<int>(val), std::memory_order_relaxed);
+      if (k >= 0 && k < kKeys) {
+        v[k].store(static_cast<int>(val), std::memory_order_relaxed);
+        seeded = seeded || val != 0;
+      }
       env = (*end == ',') ? end + 1 : end;
       if (*end != ',') break;
     }
+    // Not silent: some registers select timing-only kernel variants whose RESULTS ARE WRONG (15, 18) and the
+    // all-reduce ones (9, 10, 11) must agree on every rank.
+    if (seeded)
+      std::fprintf(stderr, "[hpc_amd] WARNING: development tuning registers set from HPC_AMD_TUNING=\"%s\" - kernel variants "
+                           "for A/B measurements are active; some give wrong results by design, the all-reduce ones must "
+                           "match on every rank.  Unset the variable in production.\n", std::getenv("HPC_AMD_TUNING"));
   }
 };
 Tuning& tuning() {

@@ -27,8 +27,11 @@ constexpr int kThreads = 256;
 constexpr int kWavesPerBlock = kThreads / 64;
 constexpr int kMaxTopk = 64;
 
+// Order-preserving integer key with torch.topk's conventions: -0.0 and +0.0 are EQUAL (the tie goes to the smaller
+// expert id, like every other tie) and every NaN - whatever its sign bit - ranks above +inf.
 __device__ __forceinline__ uint32_t key_of(float x) {
-  const uint32_t u = __float_as_uint(x);
+  uint32_t u = __float_as_uint(x + 0.0f);  // -0.0 + 0.0 = +0.0
+  if (x != x) u = 0x7fc00000u;             // canonical positive NaN
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // monotonic: larger float <-> larger key
 }
 

@@ -48,7 +48,8 @@ void* ptr(const c10::optional<at::Tensor>& t) { return t.has_value() ? t->data_p
 // lse / split_out per call and zeroes split_flag per call, src/attention/entry.cc:660-663, 690-694).
 at::Tensor decode_workspace(const at::Tensor& like, int64_t nbytes) {
   static std::mutex mu;
-  static std::map<std::pair<int, void*>, at::Tensor> cache;
+  // never destroyed: tensors must not be released during static destruction, after the allocator is gone
+  static auto& cache = *new std::map<std::pair<int, void*>, at::Tensor>();
   const auto key = std::make_pair(static_cast<int>(like.device().index()), static_cast<void*>(stream_of(like)));
   std::lock_guard<std::mutex> lock(mu);
   auto it = cache.find(key);

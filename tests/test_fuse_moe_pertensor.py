@@ -44,6 +44,40 @@ def test_fuse_moe_pertensor(num_seq, hidden, inter, num_expert, rank_ep, size_ep
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("use_bf16_mul", [False, True])
+@pytest.mark.parametrize("num_seq,hidden,inter,num_expert,topk", [(600, 512, 256, 4, 2), (1500, 512, 128, 8, 4), (257, 1024, 384, 2, 2)])
+def test_fuse_moe_pertensor_activation_epilogue(use_bf16_mul, num_seq, hidden, inter, num_expert, topk):
+    """Long groups (>= 192 rows per expert): the gate-up GEMM of the per-tensor fused op - the API the reference's
+    benchmark driver calls, benchmark/fused_moe/backends/hpcops.py:49-57 - runs on the 256 x 256 tile kernel with
+    silu(gate) * up * scale -> e4m3 in its epilogue.  Bit-equal to the same GEMM followed by the separate activation
+    kernel (development key 19 = 1) and within the reference tolerance of the oracle."""
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(11)
+    ids = torch.sort(torch.multinomial(torch.ones(num_seq, num_expert), topk, replacement=False).to(torch.int32), dim=1)[0]
+    assert num_seq * topk // num_expert >= 192
+    x = (torch.randn((num_seq, hidden)) / 100).to(F8)
+    guw = torch.randn((num_expert, inter * 2, hidden)).to(F8)
+    dw = torch.randn((num_expert, hidden, inter)).to(F8)
+    gus, ds, ams = torch.rand(num_expert) + 0.5, torch.rand(num_expert) + 0.5, torch.rand(1) + 0.5
+    sc = torch.rand((num_seq, topk)) / topk
+    gt = omoe.fuse_moe_pertensor_fp8(x, guw, dw, gus, ds, ams, ids, sc, 0, None, use_bf16_mul)
+    c = lambda t: t.cuda()  # noqa: E731
+    run = lambda: hpc.fuse_moe_pertensor_fp8(c(x), c(guw), c(dw), c(gus), c(ds), c(ams), c(ids), c(sc), 0, num_expert,  # noqa: E731
+                                             use_bf16_mul=use_bf16_mul)
+    fused = run()
+    hpc._C.lib.hpc_dev_tuning_set(19, 1)
+    try:
+        apart = run()
+        torch.cuda.synchronize()
+    finally:
+        hpc._C.lib.hpc_dev_tuning_set(19, 0)
+    assert torch.equal(fused, apart)
+    assert allclose(gt.float(), fused.cpu().float(), rtol=0.08, atol=0.1)
+
+
+@pytest.mark.gpu
 def test_count_and_gather_bit_exact():
     import hpc
     from oracle import fuse_moe as omoe

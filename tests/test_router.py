@@ -71,6 +71,33 @@ def test_topk_router_ties_go_to_the_smaller_expert_id_and_padded_rows():
 
 
 @pytest.mark.gpu
+def test_topk_router_signed_zeros_and_nans():
+    """torch.topk's conventions the integer keys must reproduce: -0.0 == +0.0 (the tie goes to the smaller expert id)
+    and every NaN, whatever its sign bit, ranks above +inf."""
+    import hpc
+    from oracle import router as orouter
+
+    torch.manual_seed(3)
+    lg = torch.randn(6, 64) - 3.0
+    lg[0, [5, 9, 40]] = torch.tensor([-0.0, 0.0, -0.0])          # zeros are the row maximum: ids 5, 9, 40 in id order
+    lg[1, [7, 3]] = torch.tensor([0.0, -0.0])
+    neg_nan = torch.tensor([0xFFC00001], dtype=torch.uint32).view(torch.float32)[0]
+    lg[2, 11], lg[2, 30] = neg_nan, float("inf")                  # a negative-sign NaN above +inf
+    lg[3, 2], lg[3, 50] = float("nan"), neg_nan                   # two NaNs: the smaller id first
+    lg[4, :] = 0.0
+    lg[4, ::2] = -0.0                                             # a whole row of signed zeros
+    for renorm in (False, True):
+        rid, rw = orouter.ref_topk_router(lg, 8, renorm)
+        mid, mw = hpc.topk_router(lg.cuda(), 8, renorm)
+        assert torch.equal(mid.cpu(), rid.to(torch.int32)), (mid.cpu(), rid)
+        fin = torch.isfinite(rw) & torch.isfinite(mw.cpu())
+        assert torch.allclose(mw.cpu()[fin], rw[fin], atol=1e-6)
+    assert mid[0, :3].tolist() == [5, 9, 40] and mid[1, :2].tolist() == [3, 7]
+    assert mid[2, :2].tolist() == [11, 30] and mid[3, :2].tolist() == [2, 50]
+    assert mid[4].tolist() == list(range(8))
+
+
+@pytest.mark.gpu
 def test_topk_router_error_paths():
     import hpc
 

@@ -114,9 +114,10 @@ ym = hpc.fuse_moe_blockwise_fp8(xm.to(dev), xs.to(dev), guw.to(dev), guws.to(dev
 errs = []
 for bad in (lambda: hpc.attention_decode_fp8(q8.to(dev).view(torch.uint8).to(torch.bfloat16), kv[:, 0], kv[:, 1], bid.to(dev), lens_d, qs.to(dev),
                                              torch.tensor([0.7], device=dev), torch.tensor([1.3], device=dev), mtp=0, new_kv_included=True,
-                                             quant_type=1, splitk=True, task_map=tm),
+                                             quant_type=hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, splitk=True, task_map=tm),
             lambda: hpc.attention_decode_fp8(q8.to(dev), kv[:, 0], kv[:, 1], bid.to(dev), lens_d, qs.to(dev), torch.tensor([0.7], device=dev),
-                                             torch.tensor([1.3], device=dev), mtp=2, new_kv_included=True, quant_type=1, splitk=True, task_map=tm)):
+                                             torch.tensor([1.3], device=dev), mtp=2, new_kv_included=True,
+                                             quant_type=hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, splitk=True, task_map=tm)):
     try:
         bad(); errs.append("no error")
     except RuntimeError as e:

@@ -135,6 +135,11 @@ def main():
     out["fuse_moe_pertensor_fp8_E64_top8_H4096_I11008"] = res
     print(res, flush=True)
     del guw, dw
+    torch.cuda.empty_cache()
+    # ---- the reference MoE benchmark's model presets through hpc.fuse_moe(..., use_bf16_mul=True) ----
+    out.update(bench.extra_moe_presets(dev, hpc, presets=("qwen3-235b", "hunyuan-v3", "deepseek-v3") if not quick else ("qwen3-235b",),
+                                       batches=(16, 256, 4096, 16384) if not quick else (256,)))
+    print(out["fuse_moe_reference_presets_pertensor_bf16mul"], flush=True)
     # ---- C1: RMSNorm + fp8 quant ----
     torch.manual_seed(0)
     x = torch.randn(1024, 4096, device=dev).bfloat16()
