@@ -16,13 +16,12 @@ struct Args {
   uint16_t* y;
   float* part_o;         // [workgroups][2][2 heads][16][128]
   float* part_lse;       // [workgroups][2][2 heads][16]
-  int* arrive;           // [pairs * B] epoch-tagged arrival counters of split requests (zero before, left zero)
+  int* arrive;           // [pairs * B] arrival counters of split requests (zero before the call, left zero)
   const float* qscale;   // [B * Sq, qscale_stride]
   const float* kscale;   // [1] or the K-scale tail rows of the cache
   const float* vscale;   // [1] or [Hkv]
   int num_batch, num_seq_q, num_head_kv, g_shift, page_shift, max_blocks;
   int ldq, ldy, qscale_stride, new_kv_included;
-  int epoch;              // 1..32767, tags the arrival counters of this launch
   int in_kernel_combine;  // 1: the last-arriving chunk of a split request merges it; 0: second kernel
   int min_range_cost;  // smallest range of the in-kernel plan, in cost units (64-token tiles + 2 per request)
   int dev_nomem;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing; results are wrong)

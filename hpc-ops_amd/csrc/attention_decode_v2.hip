@@ -41,8 +41,9 @@
 //    does the same, static_splitk_kernels.cuh:362-377) - no second kernel, no launch boundary.  That merge is
 //    spread over the workgroup: wave w folds chunks w, w+4, ... into a partial in the same (max, sum, O) form the
 //    per-task merge uses, and the per-task combine code finishes it.  The counters live at the start of the
-//    call's scratch (a fixed 64 KB region that must be zero on first use and is left zero), tagged with a
-//    per-launch epoch as a second line of defence.  Two workgroups per CU.
+//    call's scratch: a fixed 64 KB region that must be zero on first use and is left zero by every call (one
+//    atomic add per arrival; round 2 tagged them with a launch epoch instead of requiring zeros, which cost a
+//    second round trip per split task and could misread stale words).  Two workgroups per CU.
 //  * fp8 numerics as in the first generation / the reference kernels.
 #include <atomic>
 #include <type_traits>
@@ -507,14 +508,10 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my partial stores have reached memory
       __syncthreads();
       if (tid == 0) {
-        // arrival count tagged with this launch's epoch (second line of defence: the counter region is zero on
-        // first use and the last arriver leaves 0 behind, which no epoch matches)
-        int cur = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), next;
-        do {
-          next = (cur >> 16) == a.epoch ? cur + 1 : ((a.epoch << 16) | 1);
-        } while (!__hip_atomic_compare_exchange_strong(cnt, &cur, next, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT));
-        s_ticket = next & 0xffff;
+        // one atomic add = one round trip (the epoch-tagged compare-and-swap loop of round 2 cost two on the
+        // critical path of every split task): the counter region is zero on first use - the contract of
+        // hpc_attention_decode_workspace_zero_bytes() - and the last arriver puts the zero back
+        s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
       }
       __syncthreads();
       if (s_ticket == nchunks) {
@@ -848,8 +845,6 @@ int launch(Args a, void* counters, void* partials, int num_wg, int /*mode*/, hip
   ws += static_cast<int64_t>(num_wg) * 2 * 2 * 16 * 128 * 4;
   a.part_lse = reinterpret_cast<float*>(ws);
   a.arrive = static_cast<int*>(counters);
-  static std::atomic<int> epoch{0};
-  a.epoch = (epoch.fetch_add(1, std::memory_order_relaxed) % 32767) + 1;  // 1 .. 32767, frozen inside a captured graph
   if (a.prof)  // development: per-wave s_memtime sums (hpc_dev_decode_prof_buffer)
     decode2_kernel<2, true><<<num_wg, kThreads, 0, stream>>>(a);
   else if (hpc_dev_tuning_get(0) == 1)
