@@ -732,10 +732,38 @@ extern "C" int hpc_dev_decode_prof_buffer(void* p) {
   return 0;
 }
 
+// Second generation (attention_decode_v2.hip: head pairs per load, deep prefetch, in-kernel plan and merge) when the
+// layout allows it.  Returns HPC_OK when it launched, 1 when the call is not its case (the caller goes on to the
+// first generation), a negative code on a launch error.  Strides in `b` are BYTES.
+static int try_second_generation(hpc::decode2::Args& b, void* workspace, int num_bins, int num_batch, int num_seq_q,
+                                 int num_head_q, int num_head_kv, int block_size, int64_t k_head_stride_bytes,
+                                 int64_t v_head_stride_bytes, hipStream_t stream) {
+  b.part_o = b.part_lse = nullptr;
+  b.arrive = nullptr;
+  b.dev_nomem = hpc_dev_tuning_get(15);
+  b.min_range_cost = hpc_dev_tuning_get(20) > 0 ? hpc_dev_tuning_get(20) : 8;  // development key 20 overrides (15 x 64 + 1 x 16k tokens: 87 us without a floor, 47 / 49 / 61 / 105 us at 8 / 16 / 32 / 64)
+  b.prof = g_decode_prof;
+  if (hpc_dev_tuning_get(12) == 1) return 1;  // development key 12 = 1: first generation only
+  const int mode = hpc::decode2::mode_of(b, num_head_q, block_size, k_head_stride_bytes, v_head_stride_bytes);
+  int dev = 0;
+  if (mode == 0 || hipGetDevice(&dev) != hipSuccess) return 1;
+  const int unit = num_head_kv / 2;  // workgroup = (token range, head pair)
+  int num_wg = 2 * hpc_get_cu_count(dev);  // two 4-wave workgroups per CU (<= 256 registers, 65 KB of LDS each)
+  const int wg_dev = hpc_dev_tuning_get(14);
+  if (wg_dev > 0) num_wg = wg_dev;
+  if (num_wg > num_bins) num_wg = num_bins;  // the scratch is sized for num_bins workgroups
+  num_wg -= num_wg % unit;
+  if (num_wg <= 0) return 1;  // fewer bins than head pairs: the first generation takes it
+  char* base = static_cast<char*>(workspace);
+  char* part = base + hpc::decode2::kCounterBytes +
+               v1_workspace_bytes(num_bins, num_batch, num_head_kv, num_seq_q, num_head_q / num_head_kv);
+  return hpc::decode2::launch(b, base, part, num_wg, mode, stream);
+}
+
 extern "C" int hpc_attention_decode_bf16_async(
     void* y_ptr, void* workspace, const int* task_map_ptr, const void* q_ptr, const void* kcache_ptr,
-    const void* vcache_ptr, const int* block_ids_ptr, int num_bins, int num_batch, int num_seq_q,
-    int num_head_q, int num_head_kv, int num_dim_qk, int num_dim_v, int block_size,
+    const void* vcache_ptr, const int* block_ids_ptr, const int* num_seq_kvcache_ptr, int new_kv_included, int num_bins,
+    int num_batch, int num_seq_q, int num_head_q, int num_head_kv, int num_dim_qk, int num_dim_v, int block_size,
     int num_seq_max_blocks, int ldY, int ldQ, int64_t kcache_block_stride,
     int64_t kcache_token_stride, int64_t kcache_head_stride, int64_t vcache_block_stride,
     int64_t vcache_token_stride, int64_t vcache_head_stride, hipStream_t stream) {
@@ -748,6 +776,36 @@ extern "C" int hpc_attention_decode_bf16_async(
                                kcache_head_stride, vcache_block_stride, vcache_token_stride,
                                vcache_head_stride, 8);
   if (c.code != HPC_OK) return c.code;
+  if (num_seq_kvcache_ptr && hpc_dev_tuning_get(28) != 1) {  // development key 28 = 1: bf16 on the first generation only
+    hpc::decode2::Args b;
+    b.q = q_ptr;
+    b.kcache = kcache_ptr;
+    b.vcache = vcache_ptr;
+    b.block_ids = block_ids_ptr;
+    b.lens = num_seq_kvcache_ptr;
+    b.y = static_cast<uint16_t*>(y_ptr);
+    b.qscale = b.kscale = b.vscale = nullptr;
+    b.num_batch = num_batch;
+    b.num_seq_q = num_seq_q;
+    b.num_head_kv = num_head_kv;
+    b.g_shift = a.g_shift;
+    b.page_shift = a.page_shift;
+    b.max_blocks = num_seq_max_blocks;
+    b.ldq = ldQ * 2;  // bytes
+    b.ldy = ldY;
+    b.qscale_stride = 0;
+    b.new_kv_included = new_kv_included;
+    b.bf16 = 1;
+    b.k_block_stride = kcache_block_stride * 2;
+    b.k_token_stride = kcache_token_stride * 2;
+    b.v_block_stride = vcache_block_stride * 2;
+    b.v_token_stride = vcache_token_stride * 2;
+    b.ks_block_stride = b.ks_row_stride = b.ks_head_stride = 0;
+    b.scale_log2 = a.scale_log2;
+    const int rc = try_second_generation(b, workspace, num_bins, num_batch, num_seq_q, num_head_q, num_head_kv, block_size,
+                                         kcache_head_stride * 2, vcache_head_stride * 2, stream);
+    if (rc <= 0) return rc;
+  }
   return launch<false, 1>(a, num_bins, c.num_nb, stream);
 }
 
@@ -789,8 +847,6 @@ extern "C" int hpc_attention_decode_fp8_async(
     b.block_ids = block_ids_ptr;
     b.lens = num_seq_kvcache_ptr;
     b.y = static_cast<uint16_t*>(y_ptr);
-    b.part_o = b.part_lse = nullptr;
-    b.arrive = nullptr;
     b.qscale = qscale_ptr;
     b.kscale = static_cast<const float*>(kscale_ptr);
     b.vscale = vscale_ptr;
@@ -804,9 +860,7 @@ extern "C" int hpc_attention_decode_fp8_async(
     b.ldy = ldY;
     b.qscale_stride = qscale_pad_stride;
     b.new_kv_included = new_kv_included;
-    b.dev_nomem = hpc_dev_tuning_get(15);
-    b.min_range_cost = hpc_dev_tuning_get(20) > 0 ? hpc_dev_tuning_get(20) : 8;  // development key 20 overrides (15 x 64 + 1 x 16k tokens: 87 us without a floor, 47 / 49 / 61 / 105 us at 8 / 16 / 32 / 64)
-    b.in_kernel_combine = hpc_dev_tuning_get(17) == 2 ? 0 : 1;  // key 17 = 2: merge split requests in a second kernel
+    b.bf16 = 0;
     b.k_block_stride = kcache_block_stride;
     b.k_token_stride = kcache_token_stride;
     b.v_block_stride = vcache_block_stride;
@@ -815,26 +869,10 @@ extern "C" int hpc_attention_decode_fp8_async(
     b.ks_row_stride = kscale_row_stride;
     b.ks_head_stride = kscale_head_stride;
     b.scale_log2 = a.scale_log2;
-    b.prof = g_decode_prof;
-    const int gen = hpc_dev_tuning_get(12);  // 0 auto, 1 first generation only
-    const int mode = (gen != 1 && quant_type == 1)
-                         ? hpc::decode2::mode_of(b, num_head_q, block_size, kcache_head_stride, vcache_head_stride)
-                         : 0;
-    int dev = 0;
-    if (mode != 0 && hipGetDevice(&dev) == hipSuccess) {
-      const int unit = num_head_kv / 2;  // workgroup = (token range, head pair)
-      int num_wg = 2 * hpc_get_cu_count(dev);  // two 4-wave workgroups per CU (<= 256 registers, 65 KB of LDS each)
-      const int wg_dev = hpc_dev_tuning_get(14);
-      if (wg_dev > 0) num_wg = wg_dev;
-      if (num_wg > num_bins) num_wg = num_bins;  // the scratch is sized for num_bins workgroups
-      num_wg -= num_wg % unit;
-      // (a grid that rounds down to nothing - fewer bins than head pairs - falls through to the first generation)
-      if (num_wg > 0) {
-        char* base = static_cast<char*>(workspace);
-        char* part = base + hpc::decode2::kCounterBytes +
-                     v1_workspace_bytes(num_bins, num_batch, num_head_kv, num_seq_q, num_head_q / num_head_kv);
-        return hpc::decode2::launch(b, base, part, num_wg, mode, stream);
-      }
+    if (quant_type == 1) {
+      const int rc = try_second_generation(b, workspace, num_bins, num_batch, num_seq_q, num_head_q, num_head_kv, block_size,
+                                           kcache_head_stride, vcache_head_stride, stream);
+      if (rc <= 0) return rc;
     }
   }
   if (quant_type == 1) return launch<true, 1>(a, num_bins, c.num_nb, stream);

@@ -22,8 +22,8 @@ struct Args {
   const float* vscale;   // [1] or [Hkv]
   int num_batch, num_seq_q, num_head_kv, g_shift, page_shift, max_blocks;
   int ldq, ldy, qscale_stride, new_kv_included;
-  int in_kernel_combine;  // 1: the last-arriving chunk of a split request merges it; 0: second kernel
   int min_range_cost;  // smallest range of the in-kernel plan, in cost units (64-token tiles + 2 per request)
+  int bf16;       // 1: bf16 q / K / V (no scales; ldq and every stride in BYTES), 0: fp8 e4m3
   int dev_nomem;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing; results are wrong)
   long k_block_stride, k_token_stride;  // bytes
   long v_block_stride, v_token_stride;
@@ -36,8 +36,8 @@ struct Args {
 // the first time a workspace is used (the kernel leaves it zero); its place and size do not depend on the call.
 constexpr int64_t kCounterBytes = 64 * 1024;
 int64_t workspace_bytes(int num_wg);  // partial slots (2 per workgroup x 2 heads), after the first-generation region
-// 0: not served here; 1: served (NHD pages with adjacent heads 128 B apart, 2 / 4 / 8 / 16 kv heads, <= 16 q rows per
-// kv head, <= 1024 requests).
+// 0: not served here; 1: served (NHD pages with adjacent heads contiguous - 128 B apart for fp8, 256 B for bf16 -, an
+// even number of kv heads, <= 16 q rows per kv head, <= 1024 requests).
 int mode_of(const Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride);
 int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStream_t stream);
 

@@ -66,6 +66,8 @@ constexpr int kVOff = kRows * kRow;                   // V half of a wave's stag
 constexpr int kWaveLds = 2 * kRows * kRow;            // 16 KB: K + V of one WI; the merge buffer s_o[2][16][128] aliases it
 typedef int v2i32 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) v2i32 lds_v2i32;
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
 
 __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
   return static_cast<long>(static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32));
@@ -113,6 +115,20 @@ __device__ __forceinline__ void ld_q3(u32x4 (&q)[2], uint32_t& sc, int voff_q, i
                : "=&v"(q[0]), "=&v"(q[1]), "=&v"(sc)
                : "v"(voff_q), "s"(rq), "v"(voff_s), "s"(rsc));
 }
+// bf16 Q fragments of one head: the four 16-byte chunks g, g + 4, g + 8, g + 12 of the 256-byte row (k-step j = chunk 4 j + g)
+__device__ __forceinline__ void ld_q4(u32x4 (&q)[4], int voff_q, i32x4 rq_in) {
+  const i32x4 rq = pin(rq_in);
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %4, %5, 0 offen\n\tbuffer_load_dwordx4 %1, %4, %5, 0 offen offset:64\n\t"
+               "buffer_load_dwordx4 %2, %4, %5, 0 offen offset:128\n\tbuffer_load_dwordx4 %3, %4, %5, 0 offen offset:192"
+               : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3])
+               : "v"(voff_q), "s"(rq));
+}
+template <int N>
+__device__ __forceinline__ void wait_q8(u32x4 (&q0)[4], u32x4 (&q1)[4]) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3]), "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q1[3])
+               : "n"(N < 63 ? N : 63));
+}
 // "wait until at most N loads are outstanding", tied to the registers it makes valid
 template <int N>
 __device__ __forceinline__ void wait_x4x4(u32x4 (&k)[4]) {
@@ -151,15 +167,23 @@ constexpr int kFOn0 = 8;      // rows 0..15 hold at least one token of the task
 constexpr int kFOn1 = 16;     // rows 16..31 do
 constexpr int kFMasked = 32;  // some token of the WI is invisible to some q row (request end / task end)
 
+// kBf16: bf16 K / V / Q (BASELINE configs[1]).  A head pair's row is then 512 B; a wave-iteration is 16 tokens (the
+//        same 8 KB of K + 8 KB of V in flight per wave), QK^T = four v_mfma_f32_16x16x32_bf16 per head, P is rounded to
+//        bf16 (reference numerics: softmax in fp32, P.to(bf16) before P V), V^T comes out of LDS through
+//        ds_read_b64_tr_b16 (lanes 4j .. 4j+3 of a 16-lane group supply row j of a 4 x 16 tile, lane i gets column i:
+//        tools/probes/probe_tr16.hip) into v_mfma_f32_16x16x16_bf16; no scales.  All byte strides in Args.
 // kProf: development build that accumulates s_memtime deltas per wave (tools/prof_decode.py reads them)
-template <int kAux, bool kProf = false>
+template <int kAux, bool kBf16 = false, bool kProf = false>
 __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   __shared__ __attribute__((aligned(1024))) uint8_t s_wave[kWaves][kWaveLds];  // stage addresses are (base) ^ (bits 4-7)
   __shared__ float s_m[2][kWaves][16];
   __shared__ float s_l[2][kWaves][16];
   __shared__ int s_ticket;
-  constexpr int kH = 2;    // kv heads per workgroup
-  constexpr int kW = 32;   // tokens per wave-iteration
+  constexpr int kH = 2;                      // kv heads per workgroup
+  constexpr int kW = kBf16 ? 16 : 32;        // tokens (= stage rows) per wave-iteration
+  constexpr int kRowB = kBf16 ? 512 : 256;   // bytes of a stage row: the pair's two heads of a token
+  constexpr int kRpi = kBf16 ? 2 : 4;        // rows per load instruction (64 lanes x 16 B = 1 KB)
+  constexpr int kCpr = 64 / kRpi;            // 16-byte chunks per row
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -330,15 +354,15 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   // wave's WIs start at multiples of 4 * kW tokens past a 64-token boundary, so tok0 % page is the same for all of
   // them (pages of 16 / 32 / 64 tokens), for block 0 and for block 1 (which may sit in the next page).
   const uint32_t k_rs = static_cast<uint32_t>(a.k_token_stride), v_rs = static_cast<uint32_t>(a.v_token_stride);
-  const int in0 = (wave * kW) & page_mask;                                             // in-page row of block 0
-  const int in1 = blk1_same_page ? in0 + 16 : ((wave * kW + kW / 2) & page_mask);      // ... of block 1
-  const int lane_off = (lane & 15) * 16;
-  const int k_voff0 = static_cast<int>((in0 + (lane >> 4)) * k_rs) + lane_off, k_voff1 = static_cast<int>((in1 + (lane >> 4)) * k_rs) + lane_off;
-  const int v_voff0 = static_cast<int>((in0 + (lane >> 4)) * v_rs) + lane_off, v_voff1 = static_cast<int>((in1 + (lane >> 4)) * v_rs) + lane_off;
-  const int ks1 = sgpr(4 * k_rs), ks2 = sgpr(8 * k_rs), ks3 = sgpr(12 * k_rs);
-  const int vs1 = sgpr(4 * v_rs), vs2 = sgpr(8 * v_rs), vs3 = sgpr(12 * v_rs);
-  const uint64_t kbase_h = reinterpret_cast<uint64_t>(a.kcache) + static_cast<uint64_t>(pr) * (kH * 128);
-  const uint64_t vbase_h = reinterpret_cast<uint64_t>(a.vcache) + static_cast<uint64_t>(pr) * (kH * 128);
+  const int in0 = (wave * kW) & page_mask;                                               // in-page row of block 0
+  const int in1 = blk1_same_page ? in0 + kW / 2 : ((wave * kW + kW / 2) & page_mask);    // ... of block 1 (the second half of the rows)
+  const int lane_off = (lane % kCpr) * 16;
+  const int k_voff0 = static_cast<int>((in0 + lane / kCpr) * k_rs) + lane_off, k_voff1 = static_cast<int>((in1 + lane / kCpr) * k_rs) + lane_off;
+  const int v_voff0 = static_cast<int>((in0 + lane / kCpr) * v_rs) + lane_off, v_voff1 = static_cast<int>((in1 + lane / kCpr) * v_rs) + lane_off;
+  const int ks1 = sgpr(kRpi * k_rs), ks2 = sgpr(2 * kRpi * k_rs), ks3 = sgpr(3 * kRpi * k_rs);
+  const int vs1 = sgpr(kRpi * v_rs), vs2 = sgpr(2 * kRpi * v_rs), vs3 = sgpr(3 * kRpi * v_rs);
+  const uint64_t kbase_h = reinterpret_cast<uint64_t>(a.kcache) + static_cast<uint64_t>(pr) * kRowB;
+  const uint64_t vbase_h = reinterpret_cast<uint64_t>(a.vcache) + static_cast<uint64_t>(pr) * kRowB;
   const uint32_t kbs = static_cast<uint32_t>(a.k_block_stride), vbs = static_cast<uint32_t>(a.v_block_stride);  // < 4 GB (eligible())
   const bool mem = a.dev_nomem == 0;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing)
   i32x4 dk0, dk1, dv0, dv1;  // descriptors of the WI being issued
@@ -370,18 +394,28 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   uint8_t* my_lds = s_wave[wave];
   float* my_so = reinterpret_cast<float*>(my_lds);
   const uint32_t lds0 = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8*)my_lds));  // LDS byte address of the stage
-  // writes: lane (r4 = lane / 16, c = lane % 16) of instruction (tb, q) holds chunk c of row tb * 16 + q * 4 + r4
-  const uint32_t w0_inv = lds0 + (lane >> 4) * kRow + (((lane & 15) ^ (lane >> 4)) * 16);
-  // K reads: lane (n, g), row tb * 16 + n, chunk hh * 8 + g + 4 c
-  const uint32_t r0_inv = lds0 + n * kRow + ((g ^ n) * 16);
-  // V transpose reads: lane (i = lane % 16, g): row j = i / 2 of the 8 x 16 tile is stage row 16 (j / 4) + 4 g + (j % 4)
-  // (the k-slot order of P: slot hb * 4 + r <-> row 16 hb + 4 g + r), 8-byte half i % 2, chunk hh * 8 + jj
+  // fp8: writes: lane (r4 = lane / 16, c = lane % 16) of instruction (tb, q) holds chunk c of row tb * 16 + q * 4 + r4
+  //      K reads: lane (n, g), row tb * 16 + n, chunk hh * 8 + g + 4 c
+  //      V transpose reads: lane (i = lane % 16, g): row j = i / 2 of the 8 x 16 tile is stage row 16 (j / 4) + 4 g + (j % 4)
+  //      (the k-slot order of P: slot hb * 4 + r <-> row 16 hb + 4 g + r), 8-byte half i % 2, chunk hh * 8 + jj
+  // bf16 (16 rows of 512 B = 32 chunks; K stage key(t) = t, V stage key(t) = rotl4(t) = 2 t % 16 | t / 8 - the 32 lanes of
+  //      a transpose read are 8 rows x 2 chunks x 2 halves and must fall on 32 different 8-byte bank pairs):
+  //      writes: lane (r2 = lane / 32, c = lane % 32) of instruction (h, q) holds chunk c of row h * 8 + q * 2 + r2
+  //      K reads: lane (n, g), row n, chunk hh * 16 + j * 4 + g of k-step j
+  //      V transpose reads: lane (i, g): row 4 g + i / 4, 8-byte piece i % 4 of the 32 bytes of dims jj * 16 .. + 15
   const int tj = (lane & 15) >> 1;
   const int ttok = 16 * (tj >> 2) + 4 * g + (tj & 3);
-  const uint32_t t0_inv = lds0 + kVOff + ttok * kRow + ((((ttok & 15) ^ ((ttok >> 4) << 3))) * 16) + (lane & 1) * 8;
+  const int btok = 4 * g + ((lane & 15) >> 2);                      // bf16 transpose reads: stage row of this lane
+  const int bkey = ((btok << 1) & 15) | (btok >> 3);
+  const uint32_t w0_inv = kBf16 ? lds0 + (lane >> 5) * kRowB + (((lane & 31) ^ (lane >> 5)) * 16)
+                                : lds0 + (lane >> 4) * kRowB + (((lane & 15) ^ (lane >> 4)) * 16);
+  const uint32_t w1_inv = lds0 + kVOff + (lane >> 5) * kRowB + (((lane & 31) ^ ((lane >> 5) << 1)) * 16);  // bf16 V stage
+  const uint32_t r0_inv = lds0 + n * kRowB + ((g ^ n) * 16);
+  const uint32_t t0_inv = kBf16 ? lds0 + kVOff + btok * kRowB + (((((lane & 3) >> 1) ^ bkey)) * 16) + (lane & 1) * 8
+                                : lds0 + kVOff + ttok * kRowB + ((((ttok & 15) ^ ((ttok >> 4) << 3))) * 16) + (lane & 1) * 8;
 
   // ---- per-task state ----------------------------------------------------------------------------------------
-  u32x4 qf[2][2];        // fp8 Q fragments: 16-byte chunks g and g + 4 of row n (token-pair form: [0] only)
+  u32x4 qf[2][kBf16 ? 4 : 2];  // Q fragments of row n: fp8 16-byte chunks g and g + 4; bf16 chunks g, g + 4, g + 8, g + 12
   float row_scale[2];   // qscale * kscale / sqrt(d) * log2(e)
   float out_scale;       // vscale (l_run carries the factor 256 of P~)
   f32x4 o[2][8];         // O^T: o[hh][jj][r] = dim jj * 16 + 4 g + r of q row n
@@ -392,14 +426,24 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   // workgroup's q heads - the kH * G q heads of its kv heads are contiguous - bounded to
   // the request's Sq rows: lanes of the rows past rows_valid read zeros.
   auto load_q = [&](int db) __attribute__((always_inline)) {
+    if constexpr (kBf16) {  // a.ldq in bytes; one descriptor for the pair's 2 G q heads (256 B each)
+      const int q_voff = (n >> a.g_shift) * a.ldq + (n & (G - 1)) * 256 + g * 16;
+      const i32x4 rq = srd_of(qbase + static_cast<long>(db) * Sq * a.ldq + ((pr * kH) << a.g_shift) * 256,
+                              static_cast<unsigned>((Sq - 1) * a.ldq + kH * G * 256));
+      ld_q4(qf[0], q_voff, rq);
+      ld_q4(qf[1], q_voff + G * 256, rq);
+      return;
+    }
     const int q_voff = (n >> a.g_shift) * a.ldq + (n & (G - 1)) * 128 + g * 16;
     const int s_voff = ((n >> a.g_shift) * a.qscale_stride + (n & (G - 1))) * 4;
     const i32x4 rq = srd_of(qbase + static_cast<long>(db) * Sq * a.ldq + ((pr * kH) << a.g_shift) * 128,
                             static_cast<unsigned>((Sq - 1) * a.ldq + kH * G * 128));
     const i32x4 rsq = srd_of(a.qscale + static_cast<long>(db) * Sq * a.qscale_stride + ((pr * kH) << a.g_shift),
                              static_cast<unsigned>(((Sq - 1) * a.qscale_stride + kH * G) * 4));
-    ld_q3(qf[0], qsc[0], q_voff, rq, s_voff, rsq);
-    ld_q3(qf[1], qsc[1], q_voff + G * 128, rq, s_voff + G * 4, rsq);
+    if constexpr (!kBf16) {
+      ld_q3(reinterpret_cast<u32x4(&)[2]>(qf[0]), qsc[0], q_voff, rq, s_voff, rsq);
+      ld_q3(reinterpret_cast<u32x4(&)[2]>(qf[1]), qsc[1], q_voff + G * 128, rq, s_voff + G * 4, rsq);
+    }
   };
   auto reset_state = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -495,7 +539,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc[4] * inv), __float_as_uint(acc[5] * inv), __float_as_uint(acc[6] * inv),
                                                          __float_as_uint(acc[7] * inv)}, part_rs, off + 16, 0, 16);
             if (c8 == 0)
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(L > 0.f ? M + __builtin_amdgcn_logf(L) - 8.0f : kNegInf),
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(L > 0.f ? M + __builtin_amdgcn_logf(L) - (kBf16 ? 0.0f : 8.0f) : kNegInf),
                                                     lse_rs, static_cast<int>((slot * 16 + row16) * 4), 0, 16);
           }
         }
@@ -614,7 +658,8 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   reset_state();
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
-    qf[hh][0] = qf[hh][1] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int c = 0; c < (kBf16 ? 4 : 2); ++c) qf[hh][c] = u32x4{0u, 0u, 0u, 0u};
     qsc[hh] = 0u;
   }
 #pragma unroll
@@ -645,31 +690,45 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     pf_last = now();
     // keep the ~32 LDS addresses of a WI out of loop-invariant registers: they are one XOR away from these three
     // bases, and 32 pinned VGPRs were the difference between 2 waves per SIMD and spilling
-    uint32_t w0 = w0_inv, r0 = r0_inv, t0 = t0_inv;
-    asm volatile("" : "+v"(w0), "+v"(r0), "+v"(t0));
+    uint32_t w0 = w0_inv, w1 = w1_inv, r0 = r0_inv, t0 = t0_inv;
+    asm volatile("" : "+v"(w0), "+v"(w1), "+v"(r0), "+v"(t0));
     // the next WI's descriptors (its page ids were requested a whole iteration ago)
     make_descs(p2_fl, sgpr(p2_pid0), sgpr(p2_pid1));
     p1_tok = p2_tok;
     p1_fl = p2_fl;
     auto write_k = [&](int tb) __attribute__((always_inline)) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q << 2) ^ (tb << 3)) * 16)) + (tb * 16 + q * 4) * kRow)) = kr[tb][q];
+      for (int q = 0; q < 4; ++q) {
+        if constexpr (kBf16)
+          *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q << 1) ^ (tb << 3)) * 16)) + (tb * 8 + q * 2) * kRowB)) = kr[tb][q];
+        else
+          *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q << 2) ^ (tb << 3)) * 16)) + (tb * 16 + q * 4) * kRowB)) = kr[tb][q];
+      }
     };
     auto write_v = [&](int tb) __attribute__((always_inline)) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q << 2) ^ (tb << 3)) * 16)) + kVOff + (tb * 16 + q * 4) * kRow)) = vr[tb][q];
+      for (int q = 0; q < 4; ++q) {
+        if constexpr (kBf16)
+          *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w1 ^ (((q << 2) ^ tb) * 16)) + (tb * 8 + q * 2) * kRowB)) = vr[tb][q];
+        else
+          *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q << 2) ^ (tb << 3)) * 16)) + kVOff + (tb * 16 + q * 4) * kRowB)) = vr[tb][q];
+      }
     };
     auto q_ready = [&]() __attribute__((always_inline)) {
       // first WI of a task: its Q loads are older than everything issued in this trip
       // (rows past rows_valid came back as zeros from the bounded descriptors)
       if (d_fl & kFFirst) {
-        wait_q<0>(qf[0], qf[1], qsc[0], qsc[1]);
-        const float kmul = as_constf(a.kscale)[0];
+        if constexpr (kBf16) {
+          wait_q8<0>(qf[0], qf[1]);
+          row_scale[0] = row_scale[1] = a.scale_log2;
+          out_scale = 1.0f;
+        } else {
+          wait_q<0>(reinterpret_cast<u32x4(&)[2]>(qf[0]), reinterpret_cast<u32x4(&)[2]>(qf[1]), qsc[0], qsc[1]);
+          const float kmul = as_constf(a.kscale)[0];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) row_scale[hh] = a.scale_log2 * __uint_as_float(qsc[hh]) * kmul;
-        out_scale = as_constf(a.vscale)[0];  // the 1/256 of the reference formula cancels: l = 256 sum p
+          for (int hh = 0; hh < 2; ++hh) row_scale[hh] = a.scale_log2 * __uint_as_float(qsc[hh]) * kmul;
+          out_scale = as_constf(a.vscale)[0];  // the 1/256 of the reference formula cancels: l = 256 sum p
+        }
       }
     };
     // registers -> the wave's LDS stage (rows of 256 B, chunks swizzled); a register set is free again as soon as
@@ -694,104 +753,172 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     step(p2_tok, p2_fl, p2_pid0, p2_pid1);  // the WI after the one just issued: its page ids are on their way while this one computes
     if constexpr (kProf) { const uint64_t t = now(); pf_is += t - pf_last; pf_last = t; }
 
-    // S^T = K Q^T: one K = 128 MFMA per 16-row block and 128-byte half (lane (n, g) supplies chunks g and g + 4 of its
-    // row on both sides - a dot product does not care which lane slot a dim sits in)
-    f32x4 sacc[2][2];
-#pragma unroll
-    for (int tb = 0; tb < 2; ++tb)
+    if constexpr (kBf16) {
+      // S^T = K Q^T: four K = 32 MFMAs per head (lane (n, g): 8 dims of row n per k-step on both sides)
+      f32x4 sacc[2];
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
-        const u32x4 k0 = *reinterpret_cast<const lds_u32x4*>(static_cast<uint32_t>((r0 ^ (((hh << 3) ^ (tb << 3)) * 16)) + tb * 16 * kRow));
-        const u32x4 k1 = *reinterpret_cast<const lds_u32x4*>(static_cast<uint32_t>((r0 ^ (((hh << 3) ^ (tb << 3) ^ 4) * 16)) + tb * 16 * kRow));
-        const u32x4 q0 = qf[hh][0], q1 = qf[hh][1];
-        const i32x8 kv8 = {static_cast<int>(k0[0]), static_cast<int>(k0[1]), static_cast<int>(k0[2]), static_cast<int>(k0[3]),
-                           static_cast<int>(k1[0]), static_cast<int>(k1[1]), static_cast<int>(k1[2]), static_cast<int>(k1[3])};
-        const i32x8 qv8 = {static_cast<int>(q0[0]), static_cast<int>(q0[1]), static_cast<int>(q0[2]), static_cast<int>(q0[3]),
-                           static_cast<int>(q1[0]), static_cast<int>(q1[1]), static_cast<int>(q1[2]), static_cast<int>(q1[3])};
-        sacc[hh][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(kv8, qv8, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32x4 kk = *reinterpret_cast<const lds_u32x4*>(static_cast<uint32_t>(r0 ^ (((hh << 4) ^ (j << 2)) * 16)));
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kk), __builtin_bit_cast(bf16x8, qf[hh][j]), acc, 0, 0, 0);
+        }
+        sacc[hh] = acc;
       }
-
-    // online softmax in base 2; lane (n, g) holds rows 16 tb + 4 g + r of q row n.
-    // P~ = e4m3(256 p) is computed as exp2(x - m + 8) (<= 256 < 448: no clamp needed) and the row sum is kept in
-    // the same units (l = 256 sum p; the 1/256 of the reference formula is folded into the final scale).
-    uint32_t pf[2][2];
+      // online softmax in base 2, per head; lane (n, g) holds tokens 4 g + r of q row n; P is rounded to bf16 for P V,
+      // the row sum uses the unrounded p (reference tests/test_attention_decode_bf16.py:15-59, kernels alike)
+      v4i16 pf[2];
 #pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const float rsc = row_scale[hh];
+      for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-      for (int tb = 0; tb < 2; ++tb)
+        for (int r = 0; r < 4; ++r) sacc[hh][r] *= row_scale[hh];
+      }
+      if (d_fl & kFMasked) {  // wave-uniform: only the WIs that hold a request's last tokens
+        const int sq_row = n >> a.g_shift;
+        const int lim = (q0_end - 1 < q0_ltot - Sq + sq_row) ? q0_end - 1 : q0_ltot - Sq + sq_row;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sacc[hh][tb][r] *= rsc;
-    }
-    if (d_fl & kFMasked) {  // wave-uniform: only the WIs that hold a request's last tokens
-      const int sq_row = n >> a.g_shift;
-      const int lim = (q0_end - 1 < q0_ltot - Sq + sq_row) ? q0_end - 1 : q0_ltot - Sq + sq_row;
+        for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
+          for (int r = 0; r < 4; ++r) sacc[hh][r] = (d_tok + g * 4 + r) <= lim ? sacc[hh][r] : kNegInf;
+      }
 #pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = tb * 16 + g * 4 + r;
-            const int tk = d_tok + row;
-            sacc[hh][tb][r] = tk <= lim ? sacc[hh][tb][r] : kNegInf;
-          }
-    }
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      float mt = __builtin_fmaxf(__builtin_fmaxf(sacc[hh][0][0], sacc[hh][0][1]), sacc[hh][0][2]);
-      mt = __builtin_fmaxf(__builtin_fmaxf(mt, sacc[hh][0][3]), sacc[hh][1][0]);
-      mt = __builtin_fmaxf(__builtin_fmaxf(mt, sacc[hh][1][1]), sacc[hh][1][2]);
-      mt = __builtin_fmaxf(mt, sacc[hh][1][3]);
-      mt = row4_max(mt);
-      const float m_new = fmaxf(m_run[hh], mt);
-      const float m_use = m_new == kNegInf ? 0.f : m_new;
-      const float m8 = m_use - 8.0f;
-      float psum = 0.f;
-#pragma unroll
-      for (int tb = 0; tb < 2; ++tb) {
-        float prb[4];
+      for (int hh = 0; hh < 2; ++hh) {
+        float mt = __builtin_fmaxf(__builtin_fmaxf(sacc[hh][0], sacc[hh][1]), __builtin_fmaxf(sacc[hh][2], sacc[hh][3]));
+        mt = row4_max(mt);
+        const float m_new = fmaxf(m_run[hh], mt);
+        const float m_use = m_new == kNegInf ? 0.f : m_new;
+        float prb[4], psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          prb[r] = __builtin_amdgcn_exp2f(sacc[hh][tb][r] - m8);
+          prb[r] = __builtin_amdgcn_exp2f(sacc[hh][r] - m_use);
           psum += prb[r];
         }
-        int w = __builtin_amdgcn_cvt_pk_fp8_f32(prb[0], prb[1], 0, false);
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(prb[2], prb[3], w, true);
-        pf[hh][tb] = static_cast<uint32_t>(w);
-      }
-      // rescale only when some row's maximum moved (after the first few WIs of a long request it rarely does)
-      if (__builtin_amdgcn_ballot_w64(m_new != m_run[hh]) != 0) {
-        const float alpha = __builtin_amdgcn_exp2f(m_run[hh] - m_use);
-        l_run[hh] *= alpha;
+        const uint32_t p01 = pack_bf16x2(prb[0], prb[1]), p23 = pack_bf16x2(prb[2], prb[3]);
+        pf[hh] = __builtin_bit_cast(v4i16, u32x2{p01, p23});
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run[hh]) != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(m_run[hh] - m_use);
+          l_run[hh] *= alpha;
 #pragma unroll
-        for (int jj = 0; jj < 8; ++jj) o[hh][jj] *= alpha;
-        m_run[hh] = m_new;
+          for (int jj = 0; jj < 8; ++jj) o[hh][jj] *= alpha;
+          m_run[hh] = m_new;
+        }
+        l_run[hh] += psum;
       }
-      l_run[hh] += psum;
-    }
+      // O^T += V^T P^T: one transpose read per 16 dims (4 tokens x 16 dims per 16-lane group) and one K = 16 MFMA
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        v4i16 vt[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          vt[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              reinterpret_cast<lds_v4i16*>(static_cast<uint32_t>(t0 ^ (((hh << 4) ^ (u << 1)) * 16))));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          o[hh][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt[u], pf[hh], o[hh][u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // S^T = K Q^T: one K = 128 MFMA per 16-row block and 128-byte half (lane (n, g) supplies chunks g and g + 4 of its
+      // row on both sides - a dot product does not care which lane slot a dim sits in)
+      f32x4 sacc[2][2];
+  #pragma unroll
+      for (int tb = 0; tb < 2; ++tb)
+  #pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const u32x4 k0 = *reinterpret_cast<const lds_u32x4*>(static_cast<uint32_t>((r0 ^ (((hh << 3) ^ (tb << 3)) * 16)) + tb * 16 * kRowB));
+          const u32x4 k1 = *reinterpret_cast<const lds_u32x4*>(static_cast<uint32_t>((r0 ^ (((hh << 3) ^ (tb << 3) ^ 4) * 16)) + tb * 16 * kRowB));
+          const u32x4 q0 = qf[hh][0], q1 = qf[hh][1];
+          const i32x8 kv8 = {static_cast<int>(k0[0]), static_cast<int>(k0[1]), static_cast<int>(k0[2]), static_cast<int>(k0[3]),
+                             static_cast<int>(k1[0]), static_cast<int>(k1[1]), static_cast<int>(k1[2]), static_cast<int>(k1[3])};
+          const i32x8 qv8 = {static_cast<int>(q0[0]), static_cast<int>(q0[1]), static_cast<int>(q0[2]), static_cast<int>(q0[3]),
+                             static_cast<int>(q1[0]), static_cast<int>(q1[1]), static_cast<int>(q1[2]), static_cast<int>(q1[3])};
+          sacc[hh][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(kv8, qv8, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
+        }
 
-    // O^T += V^T P^T: the transpose read hands every lane one dim (column) of an 8-row x 16-dim tile.
-    constexpr int kTrBatch = 8;
-    // Reads go out eight at a time ahead of their MFMAs (hipcc, left alone, reuses one register pair and
-    // serialises read -> lgkmcnt(0) -> MFMA sixteen times: sixteen exposed LDS round trips per WI).
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-      for (int j4 = 0; j4 < 8; j4 += kTrBatch) {
-        v2i32 vt[kTrBatch];
-#pragma unroll
-        for (int u = 0; u < kTrBatch; ++u)
-          vt[u] = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
-              reinterpret_cast<lds_v2i32*>(static_cast<uint32_t>(t0 ^ (((hh << 3) | (j4 + u)) * 16))));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < kTrBatch; ++u)
-          o[hh][j4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
-              pack64(static_cast<uint32_t>(vt[u][0]), static_cast<uint32_t>(vt[u][1])), pack64(pf[hh][0], pf[hh][1]),
-              o[hh][j4 + u], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+      // online softmax in base 2; lane (n, g) holds rows 16 tb + 4 g + r of q row n.
+      // P~ = e4m3(256 p) is computed as exp2(x - m + 8) (<= 256 < 448: no clamp needed) and the row sum is kept in
+      // the same units (l = 256 sum p; the 1/256 of the reference formula is folded into the final scale).
+      uint32_t pf[2][2];
+  #pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const float rsc = row_scale[hh];
+  #pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) sacc[hh][tb][r] *= rsc;
       }
+      if (d_fl & kFMasked) {  // wave-uniform: only the WIs that hold a request's last tokens
+        const int sq_row = n >> a.g_shift;
+        const int lim = (q0_end - 1 < q0_ltot - Sq + sq_row) ? q0_end - 1 : q0_ltot - Sq + sq_row;
+  #pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+  #pragma unroll
+          for (int tb = 0; tb < 2; ++tb)
+  #pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int row = tb * 16 + g * 4 + r;
+              const int tk = d_tok + row;
+              sacc[hh][tb][r] = tk <= lim ? sacc[hh][tb][r] : kNegInf;
+            }
+      }
+  #pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float mt = __builtin_fmaxf(__builtin_fmaxf(sacc[hh][0][0], sacc[hh][0][1]), sacc[hh][0][2]);
+        mt = __builtin_fmaxf(__builtin_fmaxf(mt, sacc[hh][0][3]), sacc[hh][1][0]);
+        mt = __builtin_fmaxf(__builtin_fmaxf(mt, sacc[hh][1][1]), sacc[hh][1][2]);
+        mt = __builtin_fmaxf(mt, sacc[hh][1][3]);
+        mt = row4_max(mt);
+        const float m_new = fmaxf(m_run[hh], mt);
+        const float m_use = m_new == kNegInf ? 0.f : m_new;
+        const float m8 = m_use - 8.0f;
+        float psum = 0.f;
+  #pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+          float prb[4];
+  #pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            prb[r] = __builtin_amdgcn_exp2f(sacc[hh][tb][r] - m8);
+            psum += prb[r];
+          }
+          int w = __builtin_amdgcn_cvt_pk_fp8_f32(prb[0], prb[1], 0, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(prb[2], prb[3], w, true);
+          pf[hh][tb] = static_cast<uint32_t>(w);
+        }
+        // rescale only when some row's maximum moved (after the first few WIs of a long request it rarely does)
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run[hh]) != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(m_run[hh] - m_use);
+          l_run[hh] *= alpha;
+  #pragma unroll
+          for (int jj = 0; jj < 8; ++jj) o[hh][jj] *= alpha;
+          m_run[hh] = m_new;
+        }
+        l_run[hh] += psum;
+      }
+
+      // O^T += V^T P^T: the transpose read hands every lane one dim (column) of an 8-row x 16-dim tile.
+      constexpr int kTrBatch = 8;
+      // Reads go out eight at a time ahead of their MFMAs (hipcc, left alone, reuses one register pair and
+      // serialises read -> lgkmcnt(0) -> MFMA sixteen times: sixteen exposed LDS round trips per WI).
+  #pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+  #pragma unroll
+        for (int j4 = 0; j4 < 8; j4 += kTrBatch) {
+          v2i32 vt[kTrBatch];
+  #pragma unroll
+          for (int u = 0; u < kTrBatch; ++u)
+            vt[u] = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+                reinterpret_cast<lds_v2i32*>(static_cast<uint32_t>(t0 ^ (((hh << 3) | (j4 + u)) * 16))));
+          __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+          for (int u = 0; u < kTrBatch; ++u)
+            o[hh][j4 + u] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                pack64(static_cast<uint32_t>(vt[u][0]), static_cast<uint32_t>(vt[u][1])), pack64(pf[hh][0], pf[hh][1]),
+                o[hh][j4 + u], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     if constexpr (kProf) {
       asm volatile("s_nop 0" ::"v"(o[0][0]), "v"(o[1][7]));  // the MFMAs have been issued (not retired)
       const uint64_t t = now();
@@ -830,8 +957,9 @@ int64_t workspace_bytes(int num_wg) {
 int mode_of(const Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride) {
   if (a.num_head_kv <= 0 || num_head_q % a.num_head_kv) return 0;
   const int group = num_head_q / a.num_head_kv;
-  const bool ok = a.lens != nullptr && (a.num_head_kv % 2) == 0 && a.num_seq_q * group <= 16 && k_head_stride == 128 &&
-                  v_head_stride == 128 && (block_size == 64 || block_size == 32 || block_size == 16) &&
+  const int head_bytes = a.bf16 ? 256 : 128;  // strides in BYTES: adjacent kv heads of a token must be contiguous (NHD pages)
+  const bool ok = a.lens != nullptr && (a.num_head_kv % 2) == 0 && a.num_seq_q * group <= 16 && k_head_stride == head_bytes &&
+                  v_head_stride == head_bytes && (block_size == 64 || block_size == 32 || block_size == 16) &&
                   (a.k_token_stride % 16) == 0 && (a.v_token_stride % 16) == 0 && (a.k_block_stride % 16) == 0 &&
                   (a.v_block_stride % 16) == 0 && a.k_block_stride > 0 && a.v_block_stride > 0 &&
                   a.k_block_stride < (1ll << 32) && a.v_block_stride < (1ll << 32) && a.num_batch <= 64 * 16 &&
@@ -845,12 +973,19 @@ int launch(Args a, void* counters, void* partials, int num_wg, int /*mode*/, hip
   ws += static_cast<int64_t>(num_wg) * 2 * 2 * 16 * 128 * 4;
   a.part_lse = reinterpret_cast<float*>(ws);
   a.arrive = static_cast<int*>(counters);
-  if (a.prof)  // development: per-wave s_memtime sums (hpc_dev_decode_prof_buffer)
-    decode2_kernel<2, true><<<num_wg, kThreads, 0, stream>>>(a);
-  else if (hpc_dev_tuning_get(0) == 1)
+  const bool temporal = hpc_dev_tuning_get(0) == 1;
+  if (a.bf16) {
+    if (temporal)
+      decode2_kernel<0, true><<<num_wg, kThreads, 0, stream>>>(a);
+    else
+      decode2_kernel<2, true><<<num_wg, kThreads, 0, stream>>>(a);
+  } else if (a.prof) {  // development: per-wave s_memtime sums (hpc_dev_decode_prof_buffer)
+    decode2_kernel<2, false, true><<<num_wg, kThreads, 0, stream>>>(a);
+  } else if (temporal) {
     decode2_kernel<0><<<num_wg, kThreads, 0, stream>>>(a);
-  else
+  } else {
     decode2_kernel<2><<<num_wg, kThreads, 0, stream>>>(a);
+  }
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }

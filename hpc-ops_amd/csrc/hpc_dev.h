@@ -19,7 +19,7 @@
 //   key 12 decode fp8: 1 = never the head-pair kernel (attention_decode_v2.hip)
 //   key 14 decode fp8 v2: workgroup count override
 //   key 15 decode fp8 v2: 1 = no KV loads (compute-only timing)
-//   key 17 decode fp8 v2: 2 = merge split requests in a second kernel
+//   key 28 decode bf16: 1 = never the head-pair kernel (attention_decode_v2.hip, bf16 form)
 //   key 18 256x256 grouped GEMM: 1 = no DMA in the k-loop (timing only)
 //   others: see the launchers that read them
 #pragma once

@@ -195,7 +195,9 @@ at::Tensor attention_decode_bf16(const at::Tensor& q, at::Tensor& kcache, at::Te
   at::Tensor ws = decode_workspace(q, ws_bytes);
   const int rc = hpc_attention_decode_bf16_async(
       ptr(y), ptr(ws), static_cast<const int*>(task_map.data_ptr()), ptr(q), ptr(kcache), ptr(vcache),
-      static_cast<const int*>(block_ids.data_ptr()), bins, c.num_batch, c.num_seq_q, static_cast<int>(num_head_q),
+      static_cast<const int*>(block_ids.data_ptr()),
+      num_seq_kvcache.is_cuda() ? static_cast<const int*>(num_seq_kvcache.data_ptr()) : nullptr, new_kv_included ? 1 : 0, bins,
+      c.num_batch, c.num_seq_q, static_cast<int>(num_head_q),
       static_cast<int>(num_head_kv), static_cast<int>(q.size(2)), static_cast<int>(vcache.size(3)), static_cast<int>(block_size),
       static_cast<int>(block_ids.size(1)), static_cast<int>(y.stride(0)), static_cast<int>(q.stride(0)), kcache.stride(0),
       kcache.stride(1), kcache.stride(2), vcache.stride(0), vcache.stride(1), vcache.stride(2), stream_of(q));

@@ -51,7 +51,7 @@ _sig("hpc_assign_attention_decode_task_sync", I, IP, I, I, I, I, I, I, IP, I)
 _sig("hpc_assign_attention_decode_task_async", I, IP, IP, I, I, I, I, I, I, P)
 _sig("hpc_attention_decode_workspace_bytes", L, I, I, I, I, I)
 _sig("hpc_attention_decode_workspace_zero_bytes", L)
-_sig("hpc_attention_decode_bf16_async", I, P, P, IP, P, P, P, IP, I, I, I, I, I, I, I, I, I, I, I,
+_sig("hpc_attention_decode_bf16_async", I, P, P, IP, P, P, P, IP, IP, I, I, I, I, I, I, I, I, I, I, I, I,
      L, L, L, L, L, L, P)
 _sig("hpc_attention_decode_fp8_async", I, P, P, IP, P, P, P, IP, IP, P, P, P, I, I, I, I, I, I, I, I, I, I, I,
      I, I, I, L, L, L, L, L, L, L, L, L, P)

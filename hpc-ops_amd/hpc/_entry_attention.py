@@ -196,7 +196,9 @@ def _attention_decode_bf16_entry(q, kcache, vcache, block_ids, num_seq_kvcache, 
     ws = _decode_workspace(q.device, ws_bytes)
     rc = _C.lib.hpc_attention_decode_bf16_async(
         _C.ptr(y), _C.ptr(ws), ctypes.cast(task_map.data_ptr(), _INT_P), _C.ptr(q), _C.ptr(kcache),
-        _C.ptr(vcache), ctypes.cast(block_ids.data_ptr(), _INT_P), bins, num_batch, num_seq_q,
+        _C.ptr(vcache), ctypes.cast(block_ids.data_ptr(), _INT_P),
+        ctypes.cast(num_seq_kvcache.data_ptr(), _INT_P) if num_seq_kvcache.is_cuda else None, int(bool(new_kv_included)),
+        bins, num_batch, num_seq_q,
         num_head_q, num_head_kv, q.size(2), vcache.size(3), block_size, block_ids.size(1),
         y.stride(0), q.stride(0), kcache.stride(0), kcache.stride(1), kcache.stride(2),
         vcache.stride(0), vcache.stride(1), vcache.stride(2), _C.stream_of(q),

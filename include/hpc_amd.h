@@ -91,13 +91,18 @@ int hpc_assign_attention_decode_task_async(int* task_map, const int* num_seq_kvc
  * slots per request).  One buffer must not be used by two calls that may run concurrently (two streams: two
  * buffers).  The split-KV combine runs inside the call: a second kernel on the same stream for the
  * first-generation kernels, the last-arriving chunk of a request for the second-generation FP8 kernel
- * (reference: static_splitk_kernels.cuh:362-377). */
+ * (reference: static_splitk_kernels.cuh:362-377).
+ * num_seq_kvcache_ptr (device int32 [num_batch]) / new_kv_included as in the reference launchers (decode.h:17-35): with
+ * them, NHD pages (adjacent kv heads contiguous) with an even head count and <= 16 q rows per kv head take the
+ * second-generation kernel (attention_decode_v2.hip), which plans from the lengths and does not read the task map;
+ * NULL lengths = the task map drives the first-generation kernel. */
 int64_t hpc_attention_decode_workspace_bytes(int num_bins, int num_batch, int num_head_kv,
                                              int num_seq_q, int heads_per_group);
 int64_t hpc_attention_decode_workspace_zero_bytes(void);
 int hpc_attention_decode_bf16_async(void* y_ptr, void* workspace, const int* task_map_ptr,
                                     const void* q_ptr, const void* kcache_ptr,
-                                    const void* vcache_ptr, const int* block_ids_ptr, int num_bins,
+                                    const void* vcache_ptr, const int* block_ids_ptr,
+                                    const int* num_seq_kvcache_ptr, int new_kv_included, int num_bins,
                                     int num_batch, int num_seq_q, int num_head_q, int num_head_kv,
                                     int num_dim_qk, int num_dim_v, int block_size,
                                     int num_seq_max_blocks, int ldY, int ldQ,

@@ -111,6 +111,27 @@ def test_attn_bf16_split_requests(lens):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("generation", ["head_pair", "first"])
+@pytest.mark.parametrize("num_batch,heads,num_seq_q,block_size", [(65, (8, 64), 1, 64), (300, (4, 16), 2, 32), (40, (2, 16), 2, 16)])
+def test_attn_bf16_head_pair_kernel(generation, num_batch, heads, num_seq_q, block_size):
+    """NHD pages with an even head count run the second-generation kernel in its bf16 form (512-byte head-pair rows,
+    16-token wave-iterations, ds_read_b64_tr_b16 V^T): more than 64 requests, mixed lengths incl. empty caches and a
+    request long enough to be split over many ranges, three page sizes; development key 28 = 1 sends the same inputs
+    through the first-generation kernel."""
+    import hpc
+
+    g = torch.Generator().manual_seed(num_batch)
+    lens = torch.randint(1, 1200, (num_batch,), dtype=torch.int32, generator=g)
+    lens[torch.randperm(num_batch, generator=g)[: num_batch // 8]] = 0
+    lens[0], lens[1] = 9000, 63
+    hpc._C.lib.hpc_dev_tuning_set(28, 1 if generation == "first" else 0)
+    try:
+        _run(num_batch, num_seq_q, lens, block_size, heads, False, False, True, "NHD")
+    finally:
+        hpc._C.lib.hpc_dev_tuning_set(28, 0)
+
+
+@pytest.mark.gpu
 def test_attn_bf16_errors():
     import hpc
 
