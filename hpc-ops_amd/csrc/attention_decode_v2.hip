@@ -172,17 +172,29 @@ constexpr int kFMasked = 32;  // some token of the WI is invisible to some q row
 //        bf16 (reference numerics: softmax in fp32, P.to(bf16) before P V), V^T comes out of LDS through
 //        ds_read_b64_tr_b16 (lanes 4j .. 4j+3 of a 16-lane group supply row j of a 4 x 16 tile, lane i gets column i:
 //        tools/probes/probe_tr16.hip) into v_mfma_f32_16x16x16_bf16; no scales.  All byte strides in Args.
+// kQuad: fp8, FOUR adjacent kv heads per workgroup (512 contiguous bytes per token and load row, the shape that streams
+//        best on NHD pages) for calls with <= 8 q rows per kv head (Sq * G <= 8: the graded decode shapes).  The 16
+//        columns of an MFMA tile then hold the q rows of TWO kv heads - columns 0..7 head 2p, 8..15 head 2p + 1:
+//          S^T: one K = 128 MFMA per head against the pair's packed Q^T; lane (n, g) keeps the result of the head its
+//               column belongs to (4 selects) -> ONE softmax per pair instead of one per head;
+//          O^T: the K = 32 fp8 MFMA takes k-slots 0..15 from head 2p's 16 tokens and 16..31 from head 2p + 1's:
+//               A = [V_2p^T | V_2p+1^T] (two heads' transpose reads), B = P^T with the other head's columns zeroed
+//               (v_permlane32_swap puts a column's 16 probabilities in the lane groups of its head, one v_and masks).
+//        Same MFMA count per byte as the pair form, half the accumulators (2 tiles x 32 registers for 4 heads), half
+//        the exponentials.  A wave-iteration is 16 tokens like the bf16 form (same 8 KB of K + 8 KB of V).
 // kProf: development build that accumulates s_memtime deltas per wave (tools/prof_decode.py reads them)
-template <int kAux, bool kBf16 = false, bool kProf = false>
+template <int kAux, bool kBf16 = false, bool kProf = false, bool kQuad = false>
 __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
+  static_assert(!(kBf16 && kQuad), "the quad form is fp8");
+  constexpr bool kWide = kBf16 || kQuad;     // 512-byte stage rows, 16-token wave-iterations
   __shared__ __attribute__((aligned(1024))) uint8_t s_wave[kWaves][kWaveLds];  // stage addresses are (base) ^ (bits 4-7)
   __shared__ float s_m[2][kWaves][16];
   __shared__ float s_l[2][kWaves][16];
   __shared__ int s_ticket;
-  constexpr int kH = 2;                      // kv heads per workgroup
-  constexpr int kW = kBf16 ? 16 : 32;        // tokens (= stage rows) per wave-iteration
-  constexpr int kRowB = kBf16 ? 512 : 256;   // bytes of a stage row: the pair's two heads of a token
-  constexpr int kRpi = kBf16 ? 2 : 4;        // rows per load instruction (64 lanes x 16 B = 1 KB)
+  constexpr int kH = kQuad ? 4 : 2;          // kv heads per workgroup
+  constexpr int kW = kWide ? 16 : 32;        // tokens (= stage rows) per wave-iteration
+  constexpr int kRowB = kWide ? 512 : 256;   // bytes of a stage row: the workgroup's heads of a token
+  constexpr int kRpi = kWide ? 2 : 4;        // rows per load instruction (64 lanes x 16 B = 1 KB)
   constexpr int kCpr = 64 / kRpi;            // 16-byte chunks per row
 
   const int tid = threadIdx.x;
@@ -194,6 +206,8 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   const int B = a.num_batch, Sq = a.num_seq_q;
   const int G = 1 << a.g_shift;
   const int rows_valid = Sq << a.g_shift;
+  // tile row (= MFMA column) r16 -> does it hold a q row?  quad: rows 0..7 head 2p, 8..15 head 2p + 1
+  auto row_ok = [&](int r16) __attribute__((always_inline)) { return (kQuad ? (r16 & 7) : r16) < rows_valid; };
   const int page_mask = (1 << a.page_shift) - 1;
   const cint_ptr lens = as_const(a.lens);
   const int add_new = a.new_kv_included ? 0 : Sq;
@@ -236,10 +250,30 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   // Workgroup -> (range r, pair p) with the pair index MINOR: workgroups r * npair .. r * npair + npair - 1 stream
   // the npair 256-byte slices of the same token rows at about the same time (identical work, started together).
   // The grid is a multiple of npair (launcher).
-  const int nrange = nwg / npair;
-  const int rng = wg / npair;
-  const int pr = wg % npair;  // this workgroup's head pair
-  const int lwg = rng * npair + pr;  // logical workgroup index: partial slots are addressed by (range, pair)
+  // The slices do not stream equally fast (measured per wave, tools/prof_decode.py dump: with 8 kv heads the slice at
+  // byte 256 of every 1 KB token row takes ~20 % longer per wave-iteration than those at 0 and 512, the one at 768 ~8 %,
+  // on every XCD), and the kernel ends with the slowest slice.  a.pair_wgs (when set: 4 slices) gives slice p its own
+  // number of ranges; the extra workgroups of the slow slices are the last ones of the grid.
+  int nrange = nwg / npair;
+  int rng = wg / npair;
+  int pr = wg % npair;  // this workgroup's head pair
+  int lwg = wg;         // logical workgroup index: partial slots are addressed by (slice offset + range)
+  int lwg0 = pr * nrange;  // first logical index of this slice
+  if (a.pair_wgs[0] > 0 && npair == 4) {
+    const int n0 = a.pair_wgs[0], n1 = a.pair_wgs[1], n2 = a.pair_wgs[2], n3 = a.pair_wgs[3];
+    const int nmin = min(min(n0, n1), min(n2, n3));
+    if (wg >= nmin * 4) {
+      int e = wg - nmin * 4;
+      pr = 0;
+      rng = nmin + e;
+      if (e >= n0 - nmin) { e -= n0 - nmin; pr = 1; rng = nmin + e;
+        if (e >= n1 - nmin) { e -= n1 - nmin; pr = 2; rng = nmin + e;
+          if (e >= n2 - nmin) { e -= n2 - nmin; pr = 3; rng = nmin + e; } } }
+    }
+    nrange = pr == 0 ? n0 : pr == 1 ? n1 : pr == 2 ? n2 : n3;
+    lwg0 = pr == 0 ? 0 : pr == 1 ? n0 : pr == 2 ? n0 + n1 : n0 + n1 + n2;
+  }
+  lwg = lwg0 + rng;
   // a range is never smaller than min_range_cost: a batch with little work (one long request among a few short
   // ones) runs on fewer workgroups instead of being cut into one-tile chunks that the last arriver of the long
   // request has to merge one by one (15 x 64 + 1 x 16k tokens: 87-99 us with 128 ranges per pair, 47 us with a floor of 8)
@@ -407,12 +441,19 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   const int ttok = 16 * (tj >> 2) + 4 * g + (tj & 3);
   const int btok = 4 * g + ((lane & 15) >> 2);                      // bf16 transpose reads: stage row of this lane
   const int bkey = ((btok << 1) & 15) | (btok >> 3);
-  const uint32_t w0_inv = kBf16 ? lds0 + (lane >> 5) * kRowB + (((lane & 31) ^ (lane >> 5)) * 16)
+  // quad (16 rows of 512 B, K and V stage key(t) = t): writes as bf16's K stage; K reads: lane (n, g), row n, chunks
+  //      hh * 8 + g and hh * 8 + g + 4; V transpose reads: lane (i, g) of the pair-p MFMA reads head 2p + g / 2, row j = i / 2
+  //      of its 8 x 16 tile = token 4 (g % 2) + j % 4 + 8 (j / 4) (the k-slot order permlane32_swap gives P), half i % 2 -
+  //      the 32 lanes of a pass cover all 16 tokens of one chunk: 16 different slots x 2 halves
+  const int qtok = 4 * (g & 1) + (tj & 3) + 8 * (tj >> 2);
+  const uint32_t w0_inv = kWide ? lds0 + (lane >> 5) * kRowB + (((lane & 31) ^ (lane >> 5)) * 16)
                                 : lds0 + (lane >> 4) * kRowB + (((lane & 15) ^ (lane >> 4)) * 16);
   const uint32_t w1_inv = lds0 + kVOff + (lane >> 5) * kRowB + (((lane & 31) ^ ((lane >> 5) << 1)) * 16);  // bf16 V stage
   const uint32_t r0_inv = lds0 + n * kRowB + ((g ^ n) * 16);
   const uint32_t t0_inv = kBf16 ? lds0 + kVOff + btok * kRowB + (((((lane & 3) >> 1) ^ bkey)) * 16) + (lane & 1) * 8
-                                : lds0 + kVOff + ttok * kRowB + ((((ttok & 15) ^ ((ttok >> 4) << 3))) * 16) + (lane & 1) * 8;
+                          : kQuad ? lds0 + kVOff + qtok * kRowB + ((((g >> 1) << 3) ^ qtok) * 16) + (lane & 1) * 8
+                                  : lds0 + kVOff + ttok * kRowB + ((((ttok & 15) ^ ((ttok >> 4) << 3))) * 16) + (lane & 1) * 8;
+  const uint32_t p_keep = (n >> 3) == (g >> 1) ? 0xffffffffu : 0u;  // quad: this lane group carries k-slots of the column's head
 
   // ---- per-task state ----------------------------------------------------------------------------------------
   u32x4 qf[2][kBf16 ? 4 : 2];  // Q fragments of row n: fp8 16-byte chunks g and g + 4; bf16 chunks g, g + 4, g + 8, g + 12
@@ -432,6 +473,20 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
                               static_cast<unsigned>((Sq - 1) * a.ldq + kH * G * 256));
       ld_q4(qf[0], q_voff, rq);
       ld_q4(qf[1], q_voff + G * 256, rq);
+      return;
+    }
+    if constexpr (kQuad) {
+      // column n of pair p's tile = q row n % 8 of kv head 2p + n / 8; columns past the call's q rows read nothing
+      const int r8 = n & 7, hl = n >> 3;
+      const bool okc = r8 < rows_valid;
+      const int q_voff = okc ? (r8 >> a.g_shift) * a.ldq + ((hl << a.g_shift) + (r8 & (G - 1))) * 128 + g * 16 : -256;
+      const int s_voff = okc ? ((r8 >> a.g_shift) * a.qscale_stride + (hl << a.g_shift) + (r8 & (G - 1))) * 4 : -256;
+      const i32x4 rq = srd_of(qbase + static_cast<long>(db) * Sq * a.ldq + ((pr * kH) << a.g_shift) * 128,
+                              static_cast<unsigned>((Sq - 1) * a.ldq + kH * G * 128));
+      const i32x4 rsq = srd_of(a.qscale + static_cast<long>(db) * Sq * a.qscale_stride + ((pr * kH) << a.g_shift),
+                               static_cast<unsigned>(((Sq - 1) * a.qscale_stride + kH * G) * 4));
+      ld_q3(reinterpret_cast<u32x4(&)[2]>(qf[0]), qsc[0], q_voff, rq, s_voff, rsq);
+      ld_q3(reinterpret_cast<u32x4(&)[2]>(qf[1]), qsc[1], okc ? q_voff + 2 * G * 128 : -256, rq, okc ? s_voff + 2 * G * 4 : -256, rsq);
       return;
     }
     const int q_voff = (n >> a.g_shift) * a.ldq + (n & (G - 1)) * 128 + g * 16;
@@ -489,9 +544,10 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     }
   };
   auto store_y = [&](int db, int hh, int row16, int c8, const float (&acc)[8], float inv) __attribute__((always_inline)) {
-    const int rs = row16 >> a.g_shift;
-    const int h = pr * kH + hh;
-    uint16_t* dst = a.y + (static_cast<long>(db) * Sq + rs) * a.ldy + ((h << a.g_shift) + (row16 & (G - 1))) * 128 + c8 * 8;
+    const int qrow = kQuad ? (row16 & 7) : row16;  // quad: tile hh = heads 2 hh, 2 hh + 1 of the workgroup
+    const int rs = qrow >> a.g_shift;
+    const int h = kQuad ? pr * kH + hh * 2 + (row16 >> 3) : pr * kH + hh;
+    uint16_t* dst = a.y + (static_cast<long>(db) * Sq + rs) * a.ldy + ((h << a.g_shift) + (qrow & (G - 1))) * 128 + c8 * 8;
     u32x4 pk;
 #pragma unroll
     for (int i = 0; i < 4; ++i) pk[i] = pack_bf16x2(acc[2 * i] * inv, acc[2 * i + 1] * inv);
@@ -507,7 +563,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     const int nchunks = (q0_cc + kOvh + d_tiles - 1) / per - first_rng + 1;
     const int ichunk = rng - first_rng;
 #pragma unroll
-    for (int hh = 0; hh < kH; ++hh) {
+    for (int hh = 0; hh < 2; ++hh) {
       const float l = row4_sum(l_run[hh]);
       if (g == 0) {
         s_m[hh][wave][n] = m_run[hh];
@@ -521,11 +577,11 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     {
       const int row16 = tid >> 4, c8 = tid & 15;
 #pragma unroll
-      for (int hh = 0; hh < kH; ++hh) {
+      for (int hh = 0; hh < 2; ++hh) {
         float acc[8], M, L;
         combine4(hh, row16, c8, acc, M, L);
         const float inv = (L > 0.f ? 1.0f / L : 0.f) * out_scale;
-        if (row16 < rows_valid) {
+        if (row_ok(row16)) {
           if (nchunks == 1) {
             store_y(db, hh, row16, c8, acc, inv);
           } else {
@@ -564,14 +620,14 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
         // per-task combine finishes.  lane (r4 = lane / 16, c8 = lane % 16): rows r4 + 4 i, dims c8 * 8 .. + 8.
         const int r4 = lane >> 4, c8l = lane & 15;
         auto slot_of = [&](int c, int hh) __attribute__((always_inline)) {
-          return ((static_cast<long>(first_rng + c) * npair + pr) * 2 + (c == 0 ? 1 : 0)) * 2 + hh;
+          return (static_cast<long>(lwg0 + first_rng + c) * 2 + (c == 0 ? 1 : 0)) * 2 + hh;
         };
 #pragma unroll 1
         for (int ig = 0; ig < 2; ++ig) {     // row groups {r4, r4 + 4} and {r4 + 8, r4 + 12}
-          if (ig * 8 >= rows_valid) break;   // wave-uniform
-          float um[kH][2], ul[kH][2], ua[kH][2][8];
+          if (!kQuad && ig * 8 >= rows_valid) break;   // wave-uniform
+          float um[2][2], ul[2][2], ua[2][2][8];
 #pragma unroll
-          for (int hh = 0; hh < kH; ++hh)
+          for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
               um[hh][i] = kNegInf;
@@ -580,13 +636,13 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
               for (int e = 0; e < 8; ++e) ua[hh][i][e] = 0.f;
             }
           for (int c0 = wave; c0 < nchunks; c0 += 2 * kWaves) {
-            float lv[2][kH][2];
-            u32x4 x0[2][kH][2], x1[2][kH][2];
+            float lv[2][2][2];
+            u32x4 x0[2][2][2], x1[2][2][2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
               const int c = c0 + u * kWaves < nchunks ? c0 + u * kWaves : c0;
 #pragma unroll
-              for (int hh = 0; hh < kH; ++hh) {
+              for (int hh = 0; hh < 2; ++hh) {
                 const long slot = slot_of(c, hh);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -602,7 +658,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
             for (int u = 0; u < 2; ++u) {
               const bool real = c0 + u * kWaves < nchunks;
 #pragma unroll
-              for (int hh = 0; hh < kH; ++hh)
+              for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                   const float lse = real ? lv[u][hh][i] : kNegInf;
@@ -620,7 +676,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
             }
           }
 #pragma unroll
-          for (int hh = 0; hh < kH; ++hh)
+          for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
               const int row = ig * 8 + i * 4 + r4;
@@ -635,9 +691,9 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
         }
         __syncthreads();
         const int row16 = tid >> 4, c8 = tid & 15;
-        if (row16 < rows_valid) {
+        if (row_ok(row16)) {
 #pragma unroll
-          for (int hh = 0; hh < kH; ++hh) {
+          for (int hh = 0; hh < 2; ++hh) {
             float acc[8], M, L;
             combine4(hh, row16, c8, acc, M, L);
             store_y(db, hh, row16, c8, acc, L > 0.f ? 1.0f / L : 0.f);
@@ -699,7 +755,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     auto write_k = [&](int tb) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if constexpr (kBf16)
+        if constexpr (kWide)
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q << 1) ^ (tb << 3)) * 16)) + (tb * 8 + q * 2) * kRowB)) = kr[tb][q];
         else
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q << 2) ^ (tb << 3)) * 16)) + (tb * 16 + q * 4) * kRowB)) = kr[tb][q];
@@ -710,6 +766,8 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
       for (int q = 0; q < 4; ++q) {
         if constexpr (kBf16)
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w1 ^ (((q << 2) ^ tb) * 16)) + (tb * 8 + q * 2) * kRowB)) = vr[tb][q];
+        else if constexpr (kQuad)
+          *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q << 1) ^ (tb << 3)) * 16)) + kVOff + (tb * 8 + q * 2) * kRowB)) = vr[tb][q];
         else
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q << 2) ^ (tb << 3)) * 16)) + kVOff + (tb * 16 + q * 4) * kRowB)) = vr[tb][q];
       }
@@ -817,6 +875,85 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
 #pragma unroll
         for (int u = 0; u < 8; ++u)
           o[hh][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt[u], pf[hh], o[hh][u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (kQuad) {
+      // S^T = K Q^T: one K = 128 MFMA per head (16 tokens x 128 dims) against the pair's packed Q^T (columns 0..7 the
+      // q rows of head 2p, 8..15 those of head 2p + 1); a lane keeps the product of the head its column belongs to
+      f32x4 sacc[2];
+      const bool hi_col = n >= 8;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        f32x4 sh[2];
+        const u32x4 q0 = qf[p][0], q1 = qf[p][1];
+        const i32x8 qv8 = {static_cast<int>(q0[0]), static_cast<int>(q0[1]), static_cast<int>(q0[2]), static_cast<int>(q0[3]),
+                           static_cast<int>(q1[0]), static_cast<int>(q1[1]), static_cast<int>(q1[2]), static_cast<int>(q1[3])};
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int hh = p * 2 + e;
+          const u32x4 k0 = *reinterpret_cast<const lds_u32x4*>(static_cast<uint32_t>(r0 ^ ((hh << 3) * 16)));
+          const u32x4 k1 = *reinterpret_cast<const lds_u32x4*>(static_cast<uint32_t>(r0 ^ (((hh << 3) ^ 4) * 16)));
+          const i32x8 kv8 = {static_cast<int>(k0[0]), static_cast<int>(k0[1]), static_cast<int>(k0[2]), static_cast<int>(k0[3]),
+                             static_cast<int>(k1[0]), static_cast<int>(k1[1]), static_cast<int>(k1[2]), static_cast<int>(k1[3])};
+          sh[e] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(kv8, qv8, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
+        }
+        const float rsc = row_scale[p];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[p][r] = (hi_col ? sh[1][r] : sh[0][r]) * rsc;
+      }
+      if (d_fl & kFMasked) {  // wave-uniform: only the WIs that hold a request's last tokens
+        const int sq_row = (n & 7) >> a.g_shift;
+        const int lim = (q0_end - 1 < q0_ltot - Sq + sq_row) ? q0_end - 1 : q0_ltot - Sq + sq_row;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc[p][r] = (d_tok + g * 4 + r) <= lim ? sacc[p][r] : kNegInf;
+      }
+      // online softmax in base 2, ONE per head pair: lane (n, g) holds tokens 4 g + r of column n.  P~ = e4m3(256 p) as
+      // in the pair form.  The probabilities of a column then move to the lane groups that carry its head's k-slots:
+      // permlane32_swap(w, w) = {w of lane group g % 2, w of lane group g % 2 + 2} = k-slots (tokens) 4 (g % 2) + r and
+      // 4 (g % 2) + 8 + r; lane groups 0, 1 feed head 2p's slots (columns 8..15 zero there), groups 2, 3 head 2p + 1's.
+      uint32_t pf[2][2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        float mt = __builtin_fmaxf(__builtin_fmaxf(sacc[p][0], sacc[p][1]), __builtin_fmaxf(sacc[p][2], sacc[p][3]));
+        mt = row4_max(mt);
+        const float m_new = fmaxf(m_run[p], mt);
+        const float m_use = m_new == kNegInf ? 0.f : m_new;
+        const float m8 = m_use - 8.0f;
+        float prb[4], psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          prb[r] = __builtin_amdgcn_exp2f(sacc[p][r] - m8);
+          psum += prb[r];
+        }
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(prb[0], prb[1], 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(prb[2], prb[3], w, true);
+        const auto sw = __builtin_amdgcn_permlane32_swap(static_cast<uint32_t>(w), static_cast<uint32_t>(w), false, false);
+        pf[p][0] = sw[0] & p_keep;
+        pf[p][1] = sw[1] & p_keep;
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run[p]) != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(m_run[p] - m_use);
+          l_run[p] *= alpha;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) o[p][jj] *= alpha;
+          m_run[p] = m_new;
+        }
+        l_run[p] += psum;
+      }
+      // O^T += [V_2p^T | V_2p+1^T] P^T: lane groups 0, 1 transpose-read head 2p's 16 tokens, groups 2, 3 head 2p + 1's
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        v2i32 vt[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          vt[u] = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+              reinterpret_cast<lds_v2i32*>(static_cast<uint32_t>(t0 ^ (((p << 4) | u) * 16))));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          o[p][u] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+              pack64(static_cast<uint32_t>(vt[u][0]), static_cast<uint32_t>(vt[u][1])), pack64(pf[p][0], pf[p][1]), o[p][u], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -964,21 +1101,49 @@ int mode_of(const Args& a, int num_head_q, int block_size, int64_t k_head_stride
                   (a.v_block_stride % 16) == 0 && a.k_block_stride > 0 && a.v_block_stride > 0 &&
                   a.k_block_stride < (1ll << 32) && a.v_block_stride < (1ll << 32) && a.num_batch <= 64 * 16 &&
                   static_cast<int64_t>(a.num_batch) * (a.num_head_kv / 2) * 4 <= kCounterBytes;
-  return ok ? 1 : 0;
+  if (!ok) return 0;
+  // fp8 with <= 8 q rows per kv head and a multiple of 4 kv heads can run four heads per workgroup (kQuad).  Measured
+  // 3-5 % SLOWER than head pairs on the graded shapes (uniform 8k 188.8 vs 183.0 us, C3 mix 145.4 vs 138.6 us, same box,
+  // profiles/round3_decode_fp8_forms_ab.txt): the wider rows do not pay in the kernel although they do in a pure streaming
+  // probe - the waves sit in the load issue either way (tools/prof_decode.py: 52-57 % of a wave's cycles).  So head
+  // pairs stay the default and development key 29 = 2 selects the four-head form (kept: tested, half the softmax work).
+  const bool quad = !a.bf16 && (a.num_head_kv % 4) == 0 && a.num_seq_q * group <= 8 && hpc_dev_tuning_get(29) == 2;
+  return quad ? 2 : 1;
 }
 
-int launch(Args a, void* counters, void* partials, int num_wg, int /*mode*/, hipStream_t stream) {
+int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStream_t stream) {
   char* ws = static_cast<char*>(partials);
   a.part_o = reinterpret_cast<float*>(ws);
   ws += static_cast<int64_t>(num_wg) * 2 * 2 * 16 * 128 * 4;
   a.part_lse = reinterpret_cast<float*>(ws);
   a.arrive = static_cast<int*>(counters);
   const bool temporal = hpc_dev_tuning_get(0) == 1;
+  // Unequal shares for the four 256-byte slices of an 8-kv-head fp8 row (see the kernel): slice 1 gets d1 more
+  // workgroups than the even share, slice 3 d3, slices 0 and 2 give them up.  Off by default: measured +3 % on the C3 mix
+  // at d1 = 12 of 128 and nothing on uniform 8k (where the even split puts exactly one request half on every
+  // workgroup); development keys 30 / 31 set the deltas (value - 100, per 128 workgroups of a slice).
+  a.pair_wgs[0] = a.pair_wgs[1] = a.pair_wgs[2] = a.pair_wgs[3] = 0;
+  if (!a.bf16 && mode == 1 && a.num_head_kv == 8 && num_wg >= 256 && num_wg % 4 == 0) {
+    const int k30 = hpc_dev_tuning_get(30), k31 = hpc_dev_tuning_get(31);
+    const int even = num_wg / 4;
+    int d1 = (k30 != 0 ? k30 - 100 : 0) * even / 128, d3 = (k31 != 0 ? k31 - 100 : 0) * even / 128;
+    if (d1 != 0 || d3 != 0) {
+      const int give = d1 + d3, g0 = give / 2, g2 = give - g0;
+      a.pair_wgs[0] = even - g0, a.pair_wgs[1] = even + d1, a.pair_wgs[2] = even - g2, a.pair_wgs[3] = even + d3;
+    }
+  }
   if (a.bf16) {
     if (temporal)
       decode2_kernel<0, true><<<num_wg, kThreads, 0, stream>>>(a);
     else
       decode2_kernel<2, true><<<num_wg, kThreads, 0, stream>>>(a);
+  } else if (mode == 2) {
+    if (a.prof)  // development: per-wave s_memtime sums (hpc_dev_decode_prof_buffer)
+      decode2_kernel<2, false, true, true><<<num_wg, kThreads, 0, stream>>>(a);
+    else if (temporal)
+      decode2_kernel<0, false, false, true><<<num_wg, kThreads, 0, stream>>>(a);
+    else
+      decode2_kernel<2, false, false, true><<<num_wg, kThreads, 0, stream>>>(a);
   } else if (a.prof) {  // development: per-wave s_memtime sums (hpc_dev_decode_prof_buffer)
     decode2_kernel<2, false, true><<<num_wg, kThreads, 0, stream>>>(a);
   } else if (temporal) {

@@ -214,3 +214,23 @@ def test_attn_fp8_single_kv_head(block_size, num_seq_q):
     was built in round 3 and measured slower at this size: DESIGN.md) - split requests, short requests, odd lengths."""
     lens = torch.tensor([20000, 3, 9000, 130, 64, 63, 65, 4097, 700, 1, 127, 129, 31000, 2], dtype=torch.int32)
     _run(len(lens), num_seq_q, lens, block_size, (1, 8 if num_seq_q <= 2 else 4), False, True, True, "NHD", 0.2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["four_heads", "head_pairs"])
+@pytest.mark.parametrize("num_seq_q,block_size,heads", [(1, 64, (8, 64)), (1, 64, (4, 32)), (2, 32, (4, 16)), (1, 16, (4, 16)),
+                                                         (2, 16, (8, 32)), (1, 32, (12, 48)), (1, 64, (16, 64))])
+def test_attn_fp8_four_heads_per_workgroup(form, num_seq_q, block_size, heads):
+    """Calls with <= 8 q rows per kv head and a multiple of 4 kv heads can run the four-head form of the
+    second-generation kernel (two kv heads share the 16 columns of an MFMA tile; development key 29 = 2 - measured
+    slower than head pairs, so not the default).  Both against the oracle: full tiles (8 rows) and half-filled ones (4 rows: group 4, one q token), every
+    page size, split requests, short and empty requests, one to three head quads."""
+    import hpc
+
+    lens = torch.tensor([20000, 3, 9000, 130, 64, 63, 65, 4097, 700, 1, 0, 127, 129, 15, 16, 17, 31000, 2], dtype=torch.int32)
+    hpc._C.lib.hpc_dev_tuning_set(29, 0 if form == "head_pairs" else 2)
+    try:
+        for new_kv_included in (True, False):
+            _run(len(lens), num_seq_q, lens, block_size, heads, False, new_kv_included, True, "NHD", 0.2)
+    finally:
+        hpc._C.lib.hpc_dev_tuning_set(29, 0)

@@ -1,7 +1,7 @@
 """Development tool: where the waves of the FP8 decode kernel (attention_decode_v2.hip) spend their cycles.
 Runs the profiling build (per-wave s_memtime sums around the phases of a wave-iteration) on the C3 mix and on
 uniform 8k lengths, with and without real KV loads, and prints averages + the spread of finish times.
-usage: python tools/prof_decode.py"""
+usage: python tools/prof_decode.py [four_heads] [dump]"""
 import ctypes, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -61,8 +61,8 @@ def run(name, lens_c, nomem):
     print(f"   shader clock seen by the waves: {clk.median():.0f} MHz")
 
 DUMP = "dump" in sys.argv
-MAP = 1 if "map1" in sys.argv else 0
-lib.hpc_dev_tuning_set(24, MAP)
+MAP = 2 if "four_heads" in sys.argv else 0   # "four_heads": the four-head form (key 29 = 2) instead of head pairs
+lib.hpc_dev_tuning_set(29, MAP)
 mixed = bench.c3_lens()
 for nm, lens in (("mixed", mixed), ("uniform8k", torch.full((B,), 8192, dtype=torch.int32))):
     for nomem in ((False,) if DUMP else (False, True)):

@@ -1,5 +1,5 @@
 """Development tool: FP8 decode timing (uniform 8k / the C3 mix; NHD pages), sweeping development tuning keys.
-usage: python tools/tune_fp8.py [heads=8/64,1/8] ["k=v,k=v" ...]   each argument is one configuration of tuning registers"""
+usage: python tools/tune_fp8.py [heads=8/64,1/8] [cases=uniform8k,mixed] ["k=v,k=v" ...]   each argument is one configuration of tuning registers"""
 import math, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
@@ -29,6 +29,10 @@ args = sys.argv[1:]
 heads_list = [(8, 64)]
 if args and args[0].startswith("heads="):
     heads_list = [tuple(int(x) for x in h.split("/")) for h in args[0][6:].split(",")]
+    args = args[1:]
+if args and args[0].startswith("cases="):
+    keep = args[0][6:].split(",")
+    cases = tuple(c for c in cases if c[0] in keep)
     args = args[1:]
 configs = args or ["12=1", ""]
 for heads in heads_list:
