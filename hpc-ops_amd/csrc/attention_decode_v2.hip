@@ -277,9 +277,20 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   // a range is never smaller than min_range_cost: a batch with little work (one long request among a few short
   // ones) runs on fewer workgroups instead of being cut into one-tile chunks that the last arriver of the long
   // request has to merge one by one (15 x 64 + 1 x 16k tokens: 87-99 us with 128 ranges per pair, 47 us with a floor of 8)
-  const int per_even = (Th + nrange - 1) / nrange;
-  const int per = per_even > a.min_range_cost ? per_even : a.min_range_cost;
-  const long g_begin = static_cast<long>(rng) * per;
+  // Two sizes of range.  The first half of the grid is the first workgroup on every CU (the dispatcher hands out
+  // workgroups in index order, one per CU, then the second ones ~4 us later: tools/prof_decode.py dump, 256 CUs x 2),
+  // and a CU's first workgroup streams 13-19 % faster than its second for the whole kernel (the older waves win the
+  // load-issue arbitration).  With a.big_pct > 100 the ranges of the first-half workgroups (range index < nbig) are
+  // that much longer than the others: range r starts at r * per_b (r < nbig) or nbig * per_b + (r - nbig) * per_s.
+  const int nbig = a.big_pct > 100 ? (nwg / 2) / npair : 0;
+  const long denom = static_cast<long>(nbig) * a.big_pct + static_cast<long>(nrange - nbig) * 100;
+  const int per_s_even = static_cast<int>((static_cast<long>(Th) * 100 + denom - 1) / denom);
+  const int per_s = per_s_even > a.min_range_cost ? per_s_even : a.min_range_cost;
+  const int per_b = nbig > 0 ? (per_s * a.big_pct + 99) / 100 : per_s;
+  const int big_span = nbig * per_b;
+  auto range_of = [&](int pos) __attribute__((always_inline)) { return pos < big_span ? pos / per_b : nbig + (pos - big_span) / per_s; };
+  const long g_begin = rng < nbig ? static_cast<long>(rng) * per_b : big_span + static_cast<long>(rng - nbig) * per_s;
+  const int per = rng < nbig ? per_b : per_s;
   const long g_end = g_begin + per < Th ? g_begin + per : Th;
   if (g_begin >= g_end) return;
 
@@ -559,8 +570,8 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     const int db = q0_b;
     const int d_tiles = (q0_ltot + 63) >> 6;
     // tile t of the request sits at cost position req0 + kOvh + t
-    const int first_rng = (q0_cc + kOvh) / per;
-    const int nchunks = (q0_cc + kOvh + d_tiles - 1) / per - first_rng + 1;
+    const int first_rng = range_of(q0_cc + kOvh);
+    const int nchunks = range_of(q0_cc + kOvh + d_tiles - 1) - first_rng + 1;
     const int ichunk = rng - first_rng;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
@@ -1131,6 +1142,19 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
       const int give = d1 + d3, g0 = give / 2, g2 = give - g0;
       a.pair_wgs[0] = even - g0, a.pair_wgs[1] = even + d1, a.pair_wgs[2] = even - g2, a.pair_wgs[3] = even + d3;
     }
+  }
+  // longer ranges for the first workgroup of every CU (see the kernel): only when the grid is exactly two workgroups
+  // per CU, so that "first half of the grid" means "first on its CU".  Development key 32: percentage (0 = off).
+  // Measured: no gain at 108 / 115 / 122 % (C3 mix 139.7 / 139.0 / 138.4 us vs 139.3 us) - when a CU's first workgroup
+  // ends early its second one speeds up, and the chip's aggregate rate does not change: the spread of finish times
+  // (first halves 119-143 us, second halves 142-169 us on uniform 8k) is not where the time goes.  Off.
+  {
+    int dev = 0;
+    const int k32 = hpc_dev_tuning_get(32);
+    a.big_pct = 100;
+    if (k32 > 100 && k32 <= 200 && hipGetDevice(&dev) == hipSuccess && num_wg == 2 * hpc_get_cu_count(dev) &&
+        (num_wg / 2) % (a.num_head_kv / (mode == 2 ? 4 : 2)) == 0)
+      a.big_pct = k32;
   }
   if (a.bf16) {
     if (temporal)

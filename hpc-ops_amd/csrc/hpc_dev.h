@@ -22,6 +22,7 @@
 //   key 28 decode bf16: 1 = never the head-pair kernel (attention_decode_v2.hip, bf16 form)
 //   key 29 decode fp8: 2 = the four-head form of the head-pair kernel (<= 8 q rows per kv head, kv heads % 4 == 0)
 //   key 30 / 31 decode fp8, 8 kv heads: extra workgroups (value - 100 per 128) for the head pair at byte 256 / 768 of a token row
+//   key 32 decode fp8: ranges of the first half of the grid in percent of the others' (0 = equal)
 //   key 18 256x256 grouped GEMM: 1 = no DMA in the k-loop (timing only)
 //   others: see the launchers that read them
 #pragma once

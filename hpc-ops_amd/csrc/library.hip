@@ -67,7 +67,7 @@ extern "C" int hpc_get_cu_count(int device_id) {
 
 namespace {
 struct Tuning {
-  static constexpr int kKeys = 32;
+  static constexpr int kKeys = 64;
   std::atomic<int> v[kKeys];
   Tuning() {
     for (auto& x : v) x.store(0, std::memory_order_relaxed);

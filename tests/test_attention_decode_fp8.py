@@ -234,3 +234,22 @@ def test_attn_fp8_four_heads_per_workgroup(form, num_seq_q, block_size, heads):
             _run(len(lens), num_seq_q, lens, block_size, heads, False, new_kv_included, True, "NHD", 0.2)
     finally:
         hpc._C.lib.hpc_dev_tuning_set(29, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("keys", [{32: 115}, {30: 112, 31: 106}, {30: 118, 31: 108, 32: 125}, {32: 200}])
+@pytest.mark.parametrize("num_batch,hi", [(64, 6000), (200, 1500), (7, 30000)])
+def test_attn_fp8_uneven_ranges(keys, num_batch, hi):
+    """Development variants of the in-kernel plan: longer ranges for the first half of the grid (key 32) and unequal
+    numbers of ranges per head pair (keys 30 / 31).  Every request still has to be covered exactly once and split
+    requests have to find all their chunks (the chunk count of a request comes from the same range arithmetic)."""
+    import hpc
+
+    lens = _mixed_lens(num_batch, 7 * num_batch, hi)
+    for k, v in keys.items():
+        hpc._C.lib.hpc_dev_tuning_set(k, v)
+    try:
+        _run(num_batch, 1, lens, 64, (8, 64), False, True, True, "NHD", 0.2)
+    finally:
+        for k in keys:
+            hpc._C.lib.hpc_dev_tuning_set(k, 0)
