@@ -50,6 +50,24 @@ constexpr float kNegInf = -__builtin_inff();
 constexpr int kKRow = 128 + 16;  // padded LDS row of the K transpose tile
 constexpr int kMaskCols = 512;    // block-sparse: mask columns (128-token tiles) cached per head
 
+typedef int v2i32 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) v2i32 lds_v2i32;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+// max / sum over the 4 lanes that share a q row (lane, lane ^ 16, lane ^ 32, lane ^ 48): gfx950 row swaps,
+// permlane16_swap(x, x) = {[x0 x0 x2 x2], [x1 x1 x3 x3]} by 16-lane rows, permlane32_swap(y, y) = {[y0 y1 y0 y1], [y2 y3 y2 y3]}
+__device__ __forceinline__ float row4_max(float x) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float y = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float row4_sum(float x) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
   return static_cast<long>(static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32));
 }
@@ -60,16 +78,22 @@ __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
 // K/V staging: every 64-token tile is fetched ONCE per workgroup - wave w loads token block w of K and
 // of V (16 rows x 128 B each, full-row loads, one tile ahead, held in 4+4 VGPRs while the current tile
 // computes) and drops them into a double-buffered LDS tile; one barrier per tile; all waves then read K
-// in MFMA A-operand layout (ds_read_b128) and V as 8-byte row pieces for the private transposes.
+// in MFMA A-operand layout (ds_read_b128) and V^T through ds_read_b64_tr_b8 (round 3: the transposing LDS read
+// hands every lane one dim of an 8-token x 16-dim tile = the A operand of O^T += V^T P^T; before, 16 plain reads
+// and 48 v_perm byte shuffles per tile did that on the VALU).  The V tile is stored unpadded with its 16-byte chunks
+// XOR-swizzled (slot = chunk ^ key(row), key = (row / 2) % 4 | ((row / 16) % 2) * 4): the 16 rows x 2 halves of a
+// transpose read's 32 lanes fall on 32 different 8-byte bank pairs.
 template <int kQuant, bool kSparse>
 __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) {
   __shared__ __attribute__((aligned(16))) float s_o[kWaves][16][128 + 4];
   __shared__ float s_l[kWaves][16];
   __shared__ __attribute__((aligned(16))) uint8_t s_k[2][64 * kKRow];
-  __shared__ __attribute__((aligned(16))) uint8_t s_v[2][64 * kKRow];
+  __shared__ __attribute__((aligned(1024))) uint8_t s_v[2][64 * 128];
   __shared__ __attribute__((aligned(16))) float s_ks[2][64];  // per-token K scales of the tile (kQuant 0)
   // block-sparse: the mask rows of this workgroup's q tile, one per q head of the kv head (<= 64k tokens)
-  __shared__ uint8_t s_mask[kSparse ? 16 * kMaskCols : 16];
+  // (round 3: ONE byte per mask column, bit gq = q head gq of this kv head attends the column - a tile costs one
+  // broadcast LDS read instead of G + 2 byte reads)
+  __shared__ uint8_t s_mask[kSparse ? kMaskCols : 16];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -174,15 +198,22 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   auto stash = [&](int buf) {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int off = (wave * 16 + c * 8 + st_rsub) * kKRow + st_chunk * 16;
-      *reinterpret_cast<u32x4*>(&s_k[buf][off]) = kst[c];
-      *reinterpret_cast<u32x4*>(&s_v[buf][off]) = vst[c];
+      const int row = wave * 16 + c * 8 + st_rsub;
+      *reinterpret_cast<u32x4*>(&s_k[buf][row * kKRow + st_chunk * 16]) = kst[c];
+      const int key = ((row >> 1) & 3) | (((row >> 4) & 1) << 2);
+      *reinterpret_cast<u32x4*>(&s_v[buf][row * 128 + ((st_chunk ^ key) << 4)]) = vst[c];
     }
     if constexpr (kQuant == 0) {
       if (lane < 16) s_ks[buf][wave * 16 + lane] = ksst;
     }
   };
 
+  // transposing V reads: this lane's row of the 8 x 16 tile and its (swizzled) byte address in buffer 0, ks 0, dims 0-15
+  const int tr_j = (lane & 15) >> 1;
+  const int tr_row = 16 * (tr_j >> 2) + 4 * g + (tr_j & 3);
+  const int tr_key = ((tr_row >> 1) & 3) | (((tr_row >> 4) & 1) << 2);
+  const uint32_t vt_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8*)&s_v[0][0])) + tr_row * 128 + (tr_key << 4) +
+                           (lane & 1) * 8;
   f32x4 o[kNB][8];
   float m_run[kNB], l_run[kNB];
 #pragma unroll
@@ -207,11 +238,12 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   if constexpr (kSparse) {
     const int mask_tm = min(wg_pos0 >> 7, a.mask_tiles_m - 1);
     const int cols = min(a.mask_tiles_kv, kMaskCols);
-    for (int i = tid; i < G * cols; i += kThreads) {
-      const int gq = i / cols, col = i % cols;
-      s_mask[gq * kMaskCols + col] =
-          a.block_mask[((static_cast<long>(b) * a.num_head_q + (h << a.g_shift) + gq) * a.mask_tiles_m + mask_tm) *
-                           a.mask_tiles_kv + col];
+    for (int col = tid; col < cols; col += kThreads) {
+      uint32_t bits = 0;
+      for (int gq = 0; gq < G; ++gq)
+        bits |= (a.block_mask[((static_cast<long>(b) * a.num_head_q + (h << a.g_shift) + gq) * a.mask_tiles_m + mask_tm) *
+                                  a.mask_tiles_kv + col] != 0 ? 1u : 0u) << gq;
+      s_mask[col] = static_cast<uint8_t>(bits);
     }
     __syncthreads();
   }
@@ -222,14 +254,16 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
       return true;
     } else {
       const int col = min(t >> 1, min(a.mask_tiles_kv, kMaskCols) - 1);
+      const uint32_t bits = s_mask[col];
 #pragma unroll
-      for (int nb = 0; nb < kNB; ++nb) bit[nb] = s_mask[row_hl[nb] * kMaskCols + col] != 0;
-      // fetch / skip must be one decision for the whole workgroup: OR over the G heads of this kv head
-      bool need = false;
-      for (int gq = 0; gq < G; ++gq) need |= s_mask[gq * kMaskCols + col] != 0;
-      return need;
+      for (int nb = 0; nb < kNB; ++nb) bit[nb] = ((bits >> row_hl[nb]) & 1u) != 0;
+      // fetch / skip must be one decision for the whole workgroup: any of the G heads of this kv head
+      return __builtin_amdgcn_readfirstlane(bits) != 0;
     }
   };
+  bool scales_nonneg = true;
+#pragma unroll
+  for (int nb = 0; nb < kNB; ++nb) scales_nonneg &= __ballot(row_scale[nb] < 0.f) == 0;
   bool bit_cur[kNB], bit_next[kNB] = {};
   bool need_cur = tile_bits(0, bit_cur);
   fetch(0);
@@ -240,7 +274,6 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
     const bool need_next = t + 1 < ntile && tile_bits(t + 1, bit_next);
     if (need_next) fetch(t + 1);
     const uint8_t* kt = s_k[buf];
-    const uint8_t* vt = s_v[buf];
     bool nb_on[kNB];  // block-sparse: does this 16-row block (one head when G <= 8) attend the tile at all?
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) nb_on[nb] = !kSparse || __ballot(bit_cur[nb] && row_lim[nb] >= 0) != 0;
@@ -289,17 +322,16 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
       const float rs = row_scale[nb];
       const int lim = bit_cur[nb] ? row_lim[nb] : -1;
       float mt;
-      const bool fast = kQuant == 1 && !masked;  // per-row scale only, nothing to mask: never form s * rs
+      // per-row scale only, nothing to mask: never form s * rs (a negative scale - not what a quantiser produces -
+      // takes the general path: one test per wave, hoisted)
+      const bool fast = kQuant == 1 && !masked && scales_nonneg;
       if (fast) {
-        float mx = kNegInf, mn = -kNegInf;
+        float mx = kNegInf;
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            mx = fmaxf(mx, s[nb][tb][r]);
-            mn = fminf(mn, s[nb][tb][r]);
-          }
-        mt = rs >= 0.f ? rs * mx : rs * mn;
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[nb][tb][r]);
+        mt = rs * mx;
       } else {
         mt = kNegInf;
 #pragma unroll
@@ -319,61 +351,52 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
           }
         }
       }
-      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      mt = row4_max(mt);  // the 4 lanes of a q row, by row-swap instructions (no LDS round trip)
       const float m_new = fmaxf(m_run[nb], mt);
       const float m_use = m_new == kNegInf ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_use);
-      m_run[nb] = m_new;
       const float bias = 8.0f - m_use;  // exp2(x - m + 8) = 256 p
       float psum = 0.f;
+      const float mul = fast ? rs : 1.0f;  // one form for both paths: the slow path left s * rs (masked) in s
 #pragma unroll
       for (int tb = 0; tb < 4; ++tb) {
         float p[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p[r] = __builtin_amdgcn_exp2f(fast ? fmaf(s[nb][tb][r], rs, bias) : s[nb][tb][r] + bias);
+          p[r] = __builtin_amdgcn_exp2f(fmaf(s[nb][tb][r], mul, bias));
           psum += p[r];
         }
-        pf[nb][tb >> 1][tb & 1] = cvt_4xe4m3(p[0], p[1], p[2], p[3]);
+        // p <= 2^8 < 448 by construction (x <= m): no clamp in front of the conversion
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], w, true);
+        pf[nb][tb >> 1][tb & 1] = static_cast<uint32_t>(w);
       }
-      l_run[nb] = l_run[nb] * alpha + psum;
+      // rescale only when some row's maximum moved (past the first tiles of a long row it rarely does)
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run[nb]) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_use);
+        l_run[nb] *= alpha;
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) o[nb][jj] *= alpha;
+        for (int jj = 0; jj < 8; ++jj) o[nb][jj] *= alpha;
+        m_run[nb] = m_new;
+      }
+      l_run[nb] += psum;
     }
 
-    // ---- O^T += V^T P^T: lane (n, g) reads dims 8n..8n+7 of tokens 16tb + 4g + r, transposes 8x8 bytes ----
+    // ---- O^T += V^T P^T: one transposing read per 16 dims and 32 tokens (lane (i, g): row j = i / 2 of the 8 x 16
+    // tile is token 32 ks + 16 (j / 4) + 4 g + j % 4 - the k-slot order of pf -, 8-byte half i % 2) --------------------
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      u32x2 vf[8];
+      v2i32 vtr[8];
 #pragma unroll
-      for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          vf[hb * 4 + r] = *reinterpret_cast<const u32x2*>(vt + ((2 * ks + hb) * 16 + g * 4 + r) * kKRow + n * 8);
-      uint32_t st[2][2][4];
-#pragma unroll
-      for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-        for (int tq = 0; tq < 2; ++tq) {
-          const uint32_t r0 = vf[tq * 4 + 0][dh], r1 = vf[tq * 4 + 1][dh];
-          const uint32_t r2 = vf[tq * 4 + 2][dh], r3 = vf[tq * 4 + 3][dh];
-          st[dh][tq][0] = __builtin_amdgcn_perm(r1, r0, 0x05010400u);
-          st[dh][tq][1] = __builtin_amdgcn_perm(r1, r0, 0x07030602u);
-          st[dh][tq][2] = __builtin_amdgcn_perm(r3, r2, 0x05010400u);
-          st[dh][tq][3] = __builtin_amdgcn_perm(r3, r2, 0x07030602u);
-        }
+      for (int jj = 0; jj < 8; ++jj)
+        vtr[jj] = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+            reinterpret_cast<lds_v2i32*>(static_cast<uint32_t>((vt_base ^ (jj << 4)) + buf * (64 * 128) + ks * (32 * 128))));
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
-        const int dh = jj >> 2, dp = (jj >> 1) & 1;
-        const uint32_t sel = (jj & 1) ? 0x07060302u : 0x05040100u;
-        const uint32_t lo = __builtin_amdgcn_perm(st[dh][0][2 + dp], st[dh][0][dp], sel);
-        const uint32_t hi = __builtin_amdgcn_perm(st[dh][1][2 + dp], st[dh][1][dp], sel);
+        const long va = pack64(static_cast<uint32_t>(vtr[jj][0]), static_cast<uint32_t>(vtr[jj][1]));
 #pragma unroll
         for (int nb = 0; nb < kNB; ++nb)
           if (nb_on[nb])
-            o[nb][jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(lo, hi), pack64(pf[nb][ks][0], pf[nb][ks][1]),
-                                                                   o[nb][jj], 0, 0, 0);
+            o[nb][jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(va, pack64(pf[nb][ks][0], pf[nb][ks][1]), o[nb][jj], 0, 0, 0);
       }
     }
     }  // need_cur
@@ -387,14 +410,11 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   // ---- finish: row-major re-read through the wave's LDS tile, scale, bf16 store ---------------------------
 #pragma unroll
   for (int nb = 0; nb < kNB; ++nb) {
-    float l = l_run[nb];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    const float l = row4_sum(l_run[nb]);
     if (g == 0) s_l[wave][n] = l;
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s_o[wave][n][8 * (g * 4 + r) + jj] = o[nb][jj][r];
+    for (int jj = 0; jj < 8; ++jj)  // o[nb][jj][r] = dim 16 jj + 4 g + r of q row n
+      *reinterpret_cast<f32x4*>(&s_o[wave][n][jj * 16 + g * 4]) = o[nb][jj];
 #pragma unroll 1
     for (int it = 0; it < 4; ++it) {
       const int row16 = it * 4 + (lane >> 4), c8 = lane & 15;
