@@ -50,6 +50,31 @@ constexpr float kNegInf = -__builtin_inff();
 constexpr int kKRow = 128 + 16;  // padded LDS row of the K transpose tile
 constexpr int kMaskCols = 512;    // block-sparse: mask columns (128-token tiles) cached per head
 
+// ---- loads the compiler does not see (hand-counted vmcnt, as in attention_decode_v2.hip) ---------------------------
+__device__ __forceinline__ i32x4 srd_of(const void* base) {  // every word pinned: an "s" operand must be provably uniform
+  const uint64_t v = reinterpret_cast<uint64_t>(base);
+  return i32x4{__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(v))),
+               __builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(v >> 32))), -1, 0x00020000};
+}
+__device__ __forceinline__ void ld_pair(u32x4& x0, u32x4& x1, int voff, i32x4 rs, int soff1) {
+  const int s1 = __builtin_amdgcn_readfirstlane(soff1);
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, %4 offen"
+               : "=&v"(x0), "=&v"(x1)
+               : "v"(voff), "s"(rs), "s"(s1));
+}
+__device__ __forceinline__ void ld_one(float& x, int voff, i32x4 rs) {
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=&v"(x) : "v"(voff), "s"(rs));
+}
+// the set's loads have landed once at most kLeft younger loads are in flight
+template <int kLeft>
+__device__ __forceinline__ void wait_set(u32x4 (&k)[2], u32x4 (&v)[2], float& ks) {
+  asm volatile("s_waitcnt vmcnt(%5)" : "+v"(k[0]), "+v"(k[1]), "+v"(v[0]), "+v"(v[1]), "+v"(ks) : "n"(kLeft));
+}
+
+template <int kN>
+struct IntC {
+  static constexpr int value = kN;
+};
 typedef int v2i32 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) v2i32 lds_v2i32;
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
@@ -171,40 +196,49 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   const int k_voff = st_rsub * static_cast<int>(a.k_token_stride) + st_chunk * 16;
   const int v_voff = st_rsub * static_cast<int>(a.v_token_stride) + st_chunk * 16;
   const int k_ld_bytes = 8 * static_cast<int>(a.k_token_stride), v_ld_bytes = 8 * static_cast<int>(a.v_token_stride);
-  u32x4 kst[2], vst[2];
-  float ksst = 0.f;
-  auto fetch = [&](int t) {  // unconditional: tiles past the end re-read the last block (never used)
+  // Two register sets: tile u travels in set u % 2, fetched TWO tiles ahead (at the top of tile u - 2) and written to
+  // the LDS buffer u % 2 at the end of tile u - 1.  (One tile ahead - round 1 - the loads had one tile's compute to
+  // land, less than their latency: halving the compute with a block mask did not shorten the kernel at all.)
+  u32x4 kst[2][2], vst[2][2];
+  float ksst[2] = {0.f, 0.f};
+  auto fetch = [&](int t, auto set_c) {  // unconditional: tiles past the end re-read the last block (never used)
+    constexpr int kSet = decltype(set_c)::value;
     int blk = t * 4 + wave;
     blk = blk < last_blk16 ? blk : last_blk16;
     const int gtok = blk << 4;
     const int pid = __builtin_amdgcn_readfirstlane(bid_row[gtok >> a.page_shift]);
     const int inpage = gtok & page_mask;
-    const auto rk = make_rsrc(kbase + pid * a.k_block_stride + inpage * a.k_token_stride + h * a.k_head_stride,
-                              0xffffffffu);
-    const auto rv = make_rsrc(vbase + pid * a.v_block_stride + inpage * a.v_token_stride + h * a.v_head_stride,
-                              0xffffffffu);
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      kst[c] = buf_ld16<0>(rk, k_voff, c * k_ld_bytes);
-      vst[c] = buf_ld16<0>(rv, v_voff, c * v_ld_bytes);
-    }
+    const i32x4 rk = srd_of(kbase + pid * a.k_block_stride + inpage * a.k_token_stride + h * a.k_head_stride);
+    const i32x4 rv = srd_of(vbase + pid * a.v_block_stride + inpage * a.v_token_stride + h * a.v_head_stride);
+    // Loads the compiler does not see (as in attention_decode_v2.hip): with compiler-visible loads hipcc drains the
+    // whole queue - the set fetched at the top of this tile included - in front of every stash.  A fetch is kPer loads
+    // in a fixed order; the stash of the older set waits with vmcnt(kPer).
+    ld_pair(kst[kSet][0], kst[kSet][1], k_voff, rk, k_ld_bytes);
+    ld_pair(vst[kSet][0], vst[kSet][1], v_voff, rv, v_ld_bytes);
     if constexpr (kQuant == 0) {
       // scales of tokens inpage .. inpage+15: tail row (tok >> 5), float (tok & 31); lanes 0..15 fetch one each
       const uint8_t* sp = reinterpret_cast<const uint8_t*>(a.kscale) + pid * a.ks_block_stride +
-                          (inpage >> 5) * a.ks_row_stride + h * a.ks_head_stride + ((inpage & 31) + (lane & 15)) * 4;
-      ksst = *reinterpret_cast<const float*>(sp);
+                          (inpage >> 5) * a.ks_row_stride + h * a.ks_head_stride + (inpage & 31) * 4;
+      ld_one(ksst[kSet], (lane & 15) * 4, srd_of(sp));
     }
   };
-  auto stash = [&](int buf) {
+  constexpr int kPer = kQuant == 0 ? 5 : 4;
+  auto landed = [&](auto set_c) {  // the older set: only the kPer loads of the younger one may still be in flight
+    constexpr int kSet = decltype(set_c)::value;
+    wait_set<kPer>(kst[kSet], vst[kSet], ksst[kSet]);
+  };
+  auto stash = [&](auto set_c) {  // set u % 2 -> LDS buffer u % 2
+    constexpr int kSet = decltype(set_c)::value;
+    constexpr int buf = kSet;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       const int row = wave * 16 + c * 8 + st_rsub;
-      *reinterpret_cast<u32x4*>(&s_k[buf][row * kKRow + st_chunk * 16]) = kst[c];
+      *reinterpret_cast<u32x4*>(&s_k[buf][row * kKRow + st_chunk * 16]) = kst[kSet][c];
       const int key = ((row >> 1) & 3) | (((row >> 4) & 1) << 2);
-      *reinterpret_cast<u32x4*>(&s_v[buf][row * 128 + ((st_chunk ^ key) << 4)]) = vst[c];
+      *reinterpret_cast<u32x4*>(&s_v[buf][row * 128 + ((st_chunk ^ key) << 4)]) = vst[kSet][c];
     }
     if constexpr (kQuant == 0) {
-      if (lane < 16) s_ks[buf][wave * 16 + lane] = ksst;
+      if (lane < 16) s_ks[buf][wave * 16 + lane] = ksst[kSet];
     }
   };
 
@@ -264,15 +298,18 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   bool scales_nonneg = true;
 #pragma unroll
   for (int nb = 0; nb < kNB; ++nb) scales_nonneg &= __ballot(row_scale[nb] < 0.f) == 0;
-  bool bit_cur[kNB], bit_next[kNB] = {};
+  bool bit_cur[kNB], bit_next[kNB] = {}, bit_next2[kNB] = {};
   bool need_cur = tile_bits(0, bit_cur);
-  fetch(0);
-  stash(0);
+  bool need_next = 1 < ntile && tile_bits(1, bit_next);
+  fetch(0, IntC<0>{});
+  fetch(1, IntC<1>{});  // (fetches are unconditional - past the end they re-read the last block - so that the count holds)
+  landed(IntC<0>{});
+  stash(IntC<0>{});
   __syncthreads();
-  for (int t = 0; t < ntile; ++t) {
-    const int buf = t & 1;
-    const bool need_next = t + 1 < ntile && tile_bits(t + 1, bit_next);
-    if (need_next) fetch(t + 1);
+  auto tile = [&](int t, auto par_c) {
+    constexpr int buf = decltype(par_c)::value;
+    const bool need_next2 = t + 2 < ntile && tile_bits(t + 2, bit_next2);
+    fetch(t + 2, IntC<buf>{});  // this set went to LDS at the end of tile t - 1
     const uint8_t* kt = s_k[buf];
     bool nb_on[kNB];  // block-sparse: does this 16-row block (one head when G <= 8) attend the tile at all?
 #pragma unroll
@@ -400,12 +437,22 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
       }
     }
     }  // need_cur
-    if (need_next) stash(buf ^ 1);
+    landed(IntC<1 - buf>{});
+    stash(IntC<1 - buf>{});  // tile t + 1: fetched during tile t - 1
     __syncthreads();
     need_cur = need_next;
+    need_next = need_next2;
 #pragma unroll
-    for (int nb = 0; nb < kNB; ++nb) bit_cur[nb] = bit_next[nb];
+    for (int nb = 0; nb < kNB; ++nb) {
+      bit_cur[nb] = bit_next[nb];
+      bit_next[nb] = bit_next2[nb];
+    }
+  };
+  for (int t = 0; t < ntile; t += 2) {
+    tile(t, IntC<0>{});
+    if (t + 1 < ntile) tile(t + 1, IntC<1>{});
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the fetches past the end own their registers until they retire
 
   // ---- finish: row-major re-read through the wave's LDS tile, scale, bf16 store ---------------------------
 #pragma unroll
