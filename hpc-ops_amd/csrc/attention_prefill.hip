@@ -306,8 +306,12 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   landed(IntC<0>{});
   stash(IntC<0>{});
   __syncthreads();
-  auto tile = [&](int t, auto par_c) {
+  // kFast (compile time): per-row scale only and nothing to mask - the softmax never forms s * rs.  As a run-time
+  // condition inside one body hipcc if-converts the two paths: every tile then pays the general path's 16 multiplies,
+  // compares and selects per 16-row block on top of the fast one (150 of the tile's 370 VALU instructions).
+  auto tile = [&](int t, auto par_c, auto fast_c) {
     constexpr int buf = decltype(par_c)::value;
+    constexpr bool kFast = decltype(fast_c)::value != 0;
     const bool need_next2 = t + 2 < ntile && tile_bits(t + 2, bit_next2);
     fetch(t + 2, IntC<buf>{});  // this set went to LDS at the end of tile t - 1
     const uint8_t* kt = s_k[buf];
@@ -327,7 +331,8 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
 #pragma unroll
       for (int nb = 0; nb < kNB; ++nb) {
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (nb_on[nb]) {
+        {  // (also for a block the mask switches off: its softmax is skipped and its P stays zero - a branch around
+           // every MFMA costs the tiles that ARE computed more than the idle MFMAs cost the ones that are not)
           // the whole head dim in ONE v_mfma_f32_16x16x128_f8f6f4 (plain fp8 x fp8, twice the rate of four
           // 16x16x32 fp8 MFMAs); lane (n, g) supplies chunks g and g + 4 of its row on both sides - a dot
           // product does not care which lane slot a dim sits in as long as K and Q agree
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) all_bits &= bit_cur[nb] || row_lim[nb] < 0;
     // head-major blocks share head and q tile: sparsity switches whole blocks (nb_on), never single rows
-    const bool masked = t >= ntile_full || (kSparse && !by_head && __ballot(!all_bits) != 0);
+    const bool masked = !kFast && (t >= ntile_full || (kSparse && !by_head && __ballot(!all_bits) != 0));
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) {
       pf[nb][0][0] = pf[nb][0][1] = pf[nb][1][0] = pf[nb][1][1] = 0u;
@@ -361,7 +366,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
       float mt;
       // per-row scale only, nothing to mask: never form s * rs (a negative scale - not what a quantiser produces -
       // takes the general path: one test per wave, hoisted)
-      const bool fast = kQuant == 1 && !masked && scales_nonneg;
+      constexpr bool fast = kFast;
       if (fast) {
         float mx = kNegInf;
 #pragma unroll
@@ -432,8 +437,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
         const long va = pack64(static_cast<uint32_t>(vtr[jj][0]), static_cast<uint32_t>(vtr[jj][1]));
 #pragma unroll
         for (int nb = 0; nb < kNB; ++nb)
-          if (nb_on[nb])
-            o[nb][jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(va, pack64(pf[nb][ks][0], pf[nb][ks][1]), o[nb][jj], 0, 0, 0);
+          o[nb][jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(va, pack64(pf[nb][ks][0], pf[nb][ks][1]), o[nb][jj], 0, 0, 0);
       }
     }
     }  // need_cur
@@ -448,9 +452,19 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
       bit_next[nb] = bit_next2[nb];
     }
   };
+  // tiles every row of this wave sees in full, scales of a real quantiser (>= 0), no per-row mask bits: the fast body
+  const int n_fast = (kQuant == 1 && scales_nonneg && (!kSparse || by_head)) ? ntile_full : 0;
   for (int t = 0; t < ntile; t += 2) {
-    tile(t, IntC<0>{});
-    if (t + 1 < ntile) tile(t + 1, IntC<1>{});
+    if (t < n_fast)
+      tile(t, IntC<0>{}, IntC<1>{});
+    else
+      tile(t, IntC<0>{}, IntC<0>{});
+    if (t + 1 < ntile) {
+      if (t + 1 < n_fast)
+        tile(t + 1, IntC<1>{}, IntC<1>{});
+      else
+        tile(t + 1, IntC<1>{}, IntC<0>{});
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the fetches past the end own their registers until they retire
 
