@@ -117,14 +117,15 @@ def test_ctypes_signatures_match_the_header():
 
 
 def test_development_registers_are_internal_and_cover_their_keys():
-    """The variant-selection registers live outside the public header (csrc/hpc_dev.h) and hold 32 keys: keys
-    16-31 were silently dropped by a 16-entry table once, which turned two A/B runs into no-ops."""
+    """The variant-selection registers live outside the public header (csrc/hpc_dev.h) and hold 64 keys: keys
+    16-31 were silently dropped by a 16-entry table once and key 32 by a 32-entry one, which turned A/B runs into
+    no-ops."""
     lib = ctypes.CDLL(str(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so"))
     header = (ROOT / "include" / "hpc_amd.h").read_text()
     assert "tuning" not in header
-    for key in (0, 15, 16, 17, 20, 31):
+    for key in (0, 15, 16, 17, 20, 31, 32, 63):
         assert lib.hpc_dev_tuning_set(key, 7 + key) == 0
         assert lib.hpc_dev_tuning_get(key) == 7 + key
         assert lib.hpc_dev_tuning_set(key, 0) == 0
-    assert lib.hpc_dev_tuning_set(32, 1) == -2 and lib.hpc_dev_tuning_get(32) == 0
+    assert lib.hpc_dev_tuning_set(64, 1) == -2 and lib.hpc_dev_tuning_get(64) == 0
     assert lib.hpc_dev_tuning_set(-1, 1) == -2
