@@ -44,6 +44,25 @@ constexpr int kTileBytes = 64 * kKRow;      // one K or V tile
 constexpr int kStageBytes = 4 * kTileBytes; // K, V x 2 buffers
 constexpr int kEpiBytes = kWaves * 16 * (128 + 4) * 4 + kWaves * 16 * 4;
 
+// max / sum over the 4 lanes that share a q row (lane, lane ^ 16, lane ^ 32, lane ^ 48) with the gfx950 row swaps
+// (no LDS round trip): permlane16_swap(x, x) = {[x0 x0 x2 x2], [x1 x1 x3 x3]}, permlane32_swap(y, y) = {[y0 y1 y0 y1], [y2 y3 y2 y3]}
+__device__ __forceinline__ float row4_max(float x) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float y = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float row4_sum(float x) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  const float y = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+template <int kN>
+struct IntC {
+  static constexpr int value = kN;
+};
+
 union Frag16 {
   u32x4 u;
   bf16x8 b;
@@ -167,7 +186,10 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a)
   stash_k(0);
   stash_v(0);
   __syncthreads();
-  for (int t = 0; t < ntile; ++t) {
+  // kMasked (compile time): tiles some row of the wave does not see in full.  As a run-time condition hipcc
+  // if-converts the masking into every tile (round 3, as in attention_prefill.hip).
+  auto tile = [&](int t, auto masked_c) {
+    constexpr bool masked = decltype(masked_c)::value != 0;
     const int buf = t & 1;
     const bool more = t + 1 < ntile;
     if (more) fetch_k(t + 1);
@@ -198,7 +220,6 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a)
 
     // ---- online softmax, base 2 ---------------------------------------------------------------------
     uint32_t pf[kNB][2][4];
-    const bool masked = t >= ntile_full;
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) {
       float mt = kNegInf;
@@ -215,12 +236,9 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a)
           mt = fmaxf(mt, x);
         }
       mt *= a.scale_log2;  // scale > 0: max commutes with it
-      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      mt = row4_max(mt);
       const float m_new = fmaxf(m_run[nb], mt);
       const float m_use = m_new == kNegInf ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_use);
-      m_run[nb] = m_new;
       float psum = 0.f;
 #pragma unroll
       for (int tb = 0; tb < 4; ++tb) {
@@ -233,9 +251,15 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a)
         pf[nb][tb >> 1][(tb & 1) * 2] = pack_bf16x2(p[0], p[1]);
         pf[nb][tb >> 1][(tb & 1) * 2 + 1] = pack_bf16x2(p[2], p[3]);
       }
-      l_run[nb] = l_run[nb] * alpha + psum;
+      // rescale only when some row's maximum moved (past the first tiles of a long row it rarely does)
+      if (__builtin_amdgcn_ballot_w64(m_new != m_run[nb]) != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_use);
+        l_run[nb] *= alpha;
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) o[nb][jj] *= alpha;
+        for (int jj = 0; jj < 8; ++jj) o[nb][jj] *= alpha;
+        m_run[nb] = m_new;
+      }
+      l_run[nb] += psum;
     }
 
     if (more) stash_k(buf ^ 1);
@@ -267,16 +291,17 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a)
     }
     if (more) stash_v(buf ^ 1);
     __syncthreads();
-  }
+  };
+  const int n_plain = min(max(ntile_full, 0), ntile);  // (two loops: one loop choosing per tile spills 556 bytes)
+  for (int t = 0; t < n_plain; ++t) tile(t, IntC<0>{});
+  for (int t = n_plain; t < ntile; ++t) tile(t, IntC<1>{});
 
   // ---- finish (the staging LDS is free now: reuse it for the row-major re-read) ------------------------------
   float (*s_o)[16][128 + 4] = reinterpret_cast<float (*)[16][128 + 4]>(s_raw);
   float (*s_l)[16] = reinterpret_cast<float (*)[16]>(s_raw + kWaves * 16 * (128 + 4) * 4);
 #pragma unroll
   for (int nb = 0; nb < kNB; ++nb) {
-    float l = l_run[nb];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    const float l = row4_sum(l_run[nb]);
     if (g == 0) s_l[wave][n] = l;
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj)
