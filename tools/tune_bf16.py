@@ -30,7 +30,8 @@ for name, lens_c in cases:
     o = torch.empty_like(q)
     kvb = int(lens_c.sum()) * Hkv * 512
     outs = {}
-    for gen, key in (("head_pair", 0), ("first", 1)):
+    # order matters on these boxes (the first measurement after a pause runs 4-7 % faster): A B A B, read the later pair
+    for gen, key in (("first", 1), ("head_pair", 0), ("first", 1), ("head_pair", 0)):
         _C.lib.hpc_dev_tuning_set(28, key)
         us = bench.timed(lambda: hpc.attention_decode_bf16(q, k, v, bid, lens, 0, True, True, tm, None, o), graph=True, iters=30, reps=10)
         outs[gen] = o.clone()
