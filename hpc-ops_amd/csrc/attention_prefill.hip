@@ -110,11 +110,14 @@ __device__ __forceinline__ long pack64(uint32_t lo, uint32_t hi) {
 // transpose read's 32 lanes fall on 32 different 8-byte bank pairs.
 template <int kQuant, bool kSparse>
 __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) {
-  __shared__ __attribute__((aligned(16))) float s_o[kWaves][16][128 + 4];
+  // A STAGE = two 64-token tiles: one barrier, one round of fetch bookkeeping per 128 tokens (round 3).
   __shared__ float s_l[kWaves][16];
-  __shared__ __attribute__((aligned(16))) uint8_t s_k[2][64 * kKRow];
-  __shared__ __attribute__((aligned(1024))) uint8_t s_v[2][64 * 128];
-  __shared__ __attribute__((aligned(16))) float s_ks[2][64];  // per-token K scales of the tile (kQuant 0)
+  __shared__ __attribute__((aligned(16))) uint8_t s_k[2][128 * kKRow];
+  __shared__ __attribute__((aligned(1024))) uint8_t s_v[2][128 * 128];
+  __shared__ __attribute__((aligned(16))) float s_ks[2][128];  // per-token K scales of the stage (kQuant 0)
+  // the epilogue's row-major tile lives in the K stage (idle by then; every wave is past the loop's last barrier)
+  static_assert(sizeof(float) * kWaves * 16 * (128 + 4) <= 2 * 128 * kKRow, "s_o aliases s_k");
+  float (*s_o)[16][128 + 4] = reinterpret_cast<float (*)[16][128 + 4]>(&s_k[0][0]);
   // block-sparse: the mask rows of this workgroup's q tile, one per q head of the kv head (<= 64k tokens)
   // (round 3: ONE byte per mask column, bit gq = q head gq of this kv head attends the column - a tile costs one
   // broadcast LDS read instead of G + 2 byte reads)
@@ -196,9 +199,9 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   const int k_voff = st_rsub * static_cast<int>(a.k_token_stride) + st_chunk * 16;
   const int v_voff = st_rsub * static_cast<int>(a.v_token_stride) + st_chunk * 16;
   const int k_ld_bytes = 8 * static_cast<int>(a.k_token_stride), v_ld_bytes = 8 * static_cast<int>(a.v_token_stride);
-  // Two register sets: tile u travels in set u % 2, fetched TWO tiles ahead (at the top of tile u - 2) and written to
-  // the LDS buffer u % 2 at the end of tile u - 1.  (One tile ahead - round 1 - the loads had one tile's compute to
-  // land, less than their latency: halving the compute with a block mask did not shorten the kernel at all.)
+  // Two register sets = the two tiles of the NEXT stage, fetched at the top of a stage and written to the other LDS
+  // buffer at its end.  (Fetching two 64-token tiles ahead with one barrier per tile measured the same as one ahead: the
+  // loop is not latency-bound.)
   u32x4 kst[2][2], vst[2][2];
   float ksst[2] = {0.f, 0.f};
   auto fetch = [&](int t, auto set_c) {  // unconditional: tiles past the end re-read the last block (never used)
@@ -222,23 +225,21 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
       ld_one(ksst[kSet], (lane & 15) * 4, srd_of(sp));
     }
   };
-  constexpr int kPer = kQuant == 0 ? 5 : 4;
-  auto landed = [&](auto set_c) {  // the older set: only the kPer loads of the younger one may still be in flight
+  auto landed = [&](auto set_c) {  // everything fetched so far has landed (the sets are written to LDS together)
     constexpr int kSet = decltype(set_c)::value;
-    wait_set<kPer>(kst[kSet], vst[kSet], ksst[kSet]);
+    wait_set<0>(kst[kSet], vst[kSet], ksst[kSet]);
   };
-  auto stash = [&](auto set_c) {  // set u % 2 -> LDS buffer u % 2
+  auto stash = [&](auto set_c, int buf) {  // tile kSet of a stage -> rows kSet * 64 .. + 63 of LDS buffer buf
     constexpr int kSet = decltype(set_c)::value;
-    constexpr int buf = kSet;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int row = wave * 16 + c * 8 + st_rsub;
+      const int row = kSet * 64 + wave * 16 + c * 8 + st_rsub;
       *reinterpret_cast<u32x4*>(&s_k[buf][row * kKRow + st_chunk * 16]) = kst[kSet][c];
       const int key = ((row >> 1) & 3) | (((row >> 4) & 1) << 2);
       *reinterpret_cast<u32x4*>(&s_v[buf][row * 128 + ((st_chunk ^ key) << 4)]) = vst[kSet][c];
     }
     if constexpr (kQuant == 0) {
-      if (lane < 16) s_ks[buf][wave * 16 + lane] = ksst[kSet];
+      if (lane < 16) s_ks[buf][kSet * 64 + wave * 16 + lane] = ksst[kSet];
     }
   };
 
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
       for (int nb = 0; nb < kNB; ++nb) bit[nb] = true;
       return true;
     } else {
-      const int col = min(t >> 1, min(a.mask_tiles_kv, kMaskCols) - 1);
+      const int col = min(t, min(a.mask_tiles_kv, kMaskCols) - 1);  // t: stage = mask column
       const uint32_t bits = s_mask[col];
 #pragma unroll
       for (int nb = 0; nb < kNB; ++nb) bit[nb] = ((bits >> row_hl[nb]) & 1u) != 0;
@@ -298,23 +299,22 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   bool scales_nonneg = true;
 #pragma unroll
   for (int nb = 0; nb < kNB; ++nb) scales_nonneg &= __ballot(row_scale[nb] < 0.f) == 0;
-  bool bit_cur[kNB], bit_next[kNB] = {}, bit_next2[kNB] = {};
-  bool need_cur = tile_bits(0, bit_cur);
-  bool need_next = 1 < ntile && tile_bits(1, bit_next);
+  bool bit_cur[kNB];
+  bool need_cur = true;
   fetch(0, IntC<0>{});
-  fetch(1, IntC<1>{});  // (fetches are unconditional - past the end they re-read the last block - so that the count holds)
+  fetch(1, IntC<1>{});  // (fetches are unconditional: past the end they re-read the last block)
   landed(IntC<0>{});
-  stash(IntC<0>{});
+  landed(IntC<1>{});
+  stash(IntC<0>{}, 0);
+  stash(IntC<1>{}, 0);
   __syncthreads();
   // kFast (compile time): per-row scale only and nothing to mask - the softmax never forms s * rs.  As a run-time
   // condition inside one body hipcc if-converts the two paths: every tile then pays the general path's 16 multiplies,
   // compares and selects per 16-row block on top of the fast one (150 of the tile's 370 VALU instructions).
-  auto tile = [&](int t, auto par_c, auto fast_c) {
-    constexpr int buf = decltype(par_c)::value;
+  auto tile = [&](int t, int buf, auto sub_c, auto fast_c) {  // tile t = rows kSub * 64 .. + 63 of LDS buffer buf
+    constexpr int kSub = decltype(sub_c)::value;
     constexpr bool kFast = decltype(fast_c)::value != 0;
-    const bool need_next2 = t + 2 < ntile && tile_bits(t + 2, bit_next2);
-    fetch(t + 2, IntC<buf>{});  // this set went to LDS at the end of tile t - 1
-    const uint8_t* kt = s_k[buf];
+    const uint8_t* kt = s_k[buf] + kSub * 64 * kKRow;
     bool nb_on[kNB];  // block-sparse: does this 16-row block (one head when G <= 8) attend the tile at all?
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) nb_on[nb] = !kSparse || __ballot(bit_cur[nb] && row_lim[nb] >= 0) != 0;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb) {
           f32x4 kscl = f32x4{1.f, 1.f, 1.f, 1.f};
-          if constexpr (kQuant == 0) kscl = *reinterpret_cast<const f32x4*>(&s_ks[buf][tb * 16 + g * 4]);
+          if constexpr (kQuant == 0) kscl = *reinterpret_cast<const f32x4*>(&s_ks[buf][kSub * 64 + tb * 16 + g * 4]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float x = s[nb][tb][r] * rs;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj)
         vtr[jj] = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
-            reinterpret_cast<lds_v2i32*>(static_cast<uint32_t>((vt_base ^ (jj << 4)) + buf * (64 * 128) + ks * (32 * 128))));
+            reinterpret_cast<lds_v2i32*>(static_cast<uint32_t>((vt_base ^ (jj << 4)) + buf * (128 * 128) + kSub * (64 * 128) + ks * (32 * 128))));
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
         const long va = pack64(static_cast<uint32_t>(vtr[jj][0]), static_cast<uint32_t>(vtr[jj][1]));
@@ -441,31 +441,27 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
       }
     }
     }  // need_cur
-    landed(IntC<1 - buf>{});
-    stash(IntC<1 - buf>{});  // tile t + 1: fetched during tile t - 1
-    __syncthreads();
-    need_cur = need_next;
-    need_next = need_next2;
-#pragma unroll
-    for (int nb = 0; nb < kNB; ++nb) {
-      bit_cur[nb] = bit_next[nb];
-      bit_next[nb] = bit_next2[nb];
-    }
   };
   // tiles every row of this wave sees in full, scales of a real quantiser (>= 0), no per-row mask bits: the fast body
   const int n_fast = (kQuant == 1 && scales_nonneg && (!kSparse || by_head)) ? ntile_full : 0;
-  for (int t = 0; t < ntile; t += 2) {
-    if (t < n_fast)
-      tile(t, IntC<0>{}, IntC<1>{});
-    else
-      tile(t, IntC<0>{}, IntC<0>{});
-    if (t + 1 < ntile) {
-      if (t + 1 < n_fast)
-        tile(t + 1, IntC<1>{}, IntC<1>{});
-      else
-        tile(t + 1, IntC<1>{}, IntC<0>{});
-    }
-  }
+  auto stage = [&](int t, auto fast_c) {  // tiles t, t + 1
+    const int buf = (t >> 1) & 1;
+    fetch(t + 2, IntC<0>{});  // the next stage (both sets went to LDS at the end of the previous one)
+    fetch(t + 3, IntC<1>{});
+    need_cur = tile_bits(t >> 1, bit_cur);
+    tile(t, buf, IntC<0>{}, fast_c);
+    if (t + 1 < ntile) tile(t + 1, buf, IntC<1>{}, fast_c);
+    landed(IntC<0>{});
+    landed(IntC<1>{});
+    stash(IntC<0>{}, buf ^ 1);
+    stash(IntC<1>{}, buf ^ 1);
+    __syncthreads();
+  };
+  // two loops (one loop that picks the body per tile keeps four bodies live and spills): the stages whose two tiles
+  // are both fast, then the rest on the general body
+  const int t_fast = min(n_fast & ~1, ntile & ~1);
+  for (int t = 0; t < t_fast; t += 2) stage(t, IntC<1>{});
+  for (int t = t_fast; t < ntile; t += 2) stage(t, IntC<0>{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the fetches past the end own their registers until they retire
 
   // ---- finish: row-major re-read through the wave's LDS tile, scale, bf16 store ---------------------------
