@@ -311,75 +311,73 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   // kFast (compile time): per-row scale only and nothing to mask - the softmax never forms s * rs.  As a run-time
   // condition inside one body hipcc if-converts the two paths: every tile then pays the general path's 16 multiplies,
   // compares and selects per 16-row block on top of the fast one (150 of the tile's 370 VALU instructions).
-  auto tile = [&](int t, int buf, auto sub_c, auto fast_c) {  // tile t = rows kSub * 64 .. + 63 of LDS buffer buf
-    constexpr int kSub = decltype(sub_c)::value;
+  // One body per STAGE (128 tokens = tiles t, t + 1): eight S^T blocks per 16-row block, ONE softmax update, and P V with
+  // the K = 128 MFMA - lane (n, g) of the B operand holds its own 32 probabilities (byte 4 v + r of its 8 registers =
+  // token 16 v + 4 g + r of the stage), lane (dim, g) of the A operand the same 32 tokens of V^T from four transposing
+  // reads; the two sides agree on which token sits in which byte, which is all a dot product needs.  Half the matrix
+  // pipe time of the K = 32 form for P V, 32 instead of 80 MFMA instructions per stage.  A second tile past the end
+  // (odd tile count) holds a re-read of the last block: its tokens lie beyond every row's limit and the stage is never
+  // a fast one.
+  auto body = [&](int t, int buf, auto fast_c) {
     constexpr bool kFast = decltype(fast_c)::value != 0;
-    const uint8_t* kt = s_k[buf] + kSub * 64 * kKRow;
-    bool nb_on[kNB];  // block-sparse: does this 16-row block (one head when G <= 8) attend the tile at all?
+    const uint8_t* kt = s_k[buf];
+    bool nb_on[kNB];  // block-sparse: does this 16-row block (one head when G <= 8) attend the stage at all?
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) nb_on[nb] = !kSparse || __ballot(bit_cur[nb] && row_lim[nb] >= 0) != 0;
-    if (need_cur) {
+    if (!need_cur) return;
 
-    // ---- S^T = K Q^T --------------------------------------------------------------------------------
-    f32x4 s[kNB][4];
+    // ---- S^T = K Q^T: the whole head dim in ONE v_mfma_f32_16x16x128_f8f6f4 per 16 x 16 block; lane (n, g) supplies
+    // chunks g and g + 4 of its row on both sides ---------------------------------------------------------------
+    f32x4 s[kNB][8];
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb) {
+    for (int tb = 0; tb < 8; ++tb) {
       u32x4 ka[2];
 #pragma unroll
       for (int c = 0; c < 2; ++c)
         ka[c] = *reinterpret_cast<const u32x4*>(kt + (tb * 16 + n) * kKRow + (g + 4 * c) * 16);
+      const i32x8 kv8 = {static_cast<int>(ka[0][0]), static_cast<int>(ka[0][1]), static_cast<int>(ka[0][2]),
+                         static_cast<int>(ka[0][3]), static_cast<int>(ka[1][0]), static_cast<int>(ka[1][1]),
+                         static_cast<int>(ka[1][2]), static_cast<int>(ka[1][3])};
 #pragma unroll
       for (int nb = 0; nb < kNB; ++nb) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        {  // (also for a block the mask switches off: its softmax is skipped and its P stays zero - a branch around
-           // every MFMA costs the tiles that ARE computed more than the idle MFMAs cost the ones that are not)
-          // the whole head dim in ONE v_mfma_f32_16x16x128_f8f6f4 (plain fp8 x fp8, twice the rate of four
-          // 16x16x32 fp8 MFMAs); lane (n, g) supplies chunks g and g + 4 of its row on both sides - a dot
-          // product does not care which lane slot a dim sits in as long as K and Q agree
-          const i32x8 kv8 = {static_cast<int>(ka[0][0]), static_cast<int>(ka[0][1]), static_cast<int>(ka[0][2]),
-                             static_cast<int>(ka[0][3]), static_cast<int>(ka[1][0]), static_cast<int>(ka[1][1]),
-                             static_cast<int>(ka[1][2]), static_cast<int>(ka[1][3])};
-          const i32x8 qv8 = {static_cast<int>(qf[nb][0][0]), static_cast<int>(qf[nb][0][1]),
-                             static_cast<int>(qf[nb][0][2]), static_cast<int>(qf[nb][0][3]),
-                             static_cast<int>(qf[nb][1][0]), static_cast<int>(qf[nb][1][1]),
-                             static_cast<int>(qf[nb][1][2]), static_cast<int>(qf[nb][1][3])};
-          acc = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(kv8, qv8, acc, 0, 0, 0, 0, 0, 0);
-        }
-        s[nb][tb] = acc;
+        // (also for a block the mask switches off: its softmax is skipped and its P stays zero - a branch around
+        // every MFMA costs the stages that ARE computed more than the idle MFMAs cost the ones that are not)
+        const i32x8 qv8 = {static_cast<int>(qf[nb][0][0]), static_cast<int>(qf[nb][0][1]),
+                           static_cast<int>(qf[nb][0][2]), static_cast<int>(qf[nb][0][3]),
+                           static_cast<int>(qf[nb][1][0]), static_cast<int>(qf[nb][1][1]),
+                           static_cast<int>(qf[nb][1][2]), static_cast<int>(qf[nb][1][3])};
+        s[nb][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(kv8, qv8, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
       }
     }
 
     // ---- online softmax, base 2.  p is produced as 256 p (the +8 rides in the exponent): it feeds the
     // e4m3 pack directly and the row sum is kept in the same units (undone once in the epilogue). -------
-    uint32_t pf[kNB][2][2];
+    i32x8 pf[kNB];
     bool all_bits = true;
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) all_bits &= bit_cur[nb] || row_lim[nb] < 0;
     // head-major blocks share head and q tile: sparsity switches whole blocks (nb_on), never single rows
-    const bool masked = !kFast && (t >= ntile_full || (kSparse && !by_head && __ballot(!all_bits) != 0));
+    const bool masked = !kFast && (t + 1 >= ntile_full || (kSparse && !by_head && __ballot(!all_bits) != 0));
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) {
-      pf[nb][0][0] = pf[nb][0][1] = pf[nb][1][0] = pf[nb][1][1] = 0u;
-      if (!nb_on[nb]) continue;  // nothing of this tile is visible to the block: m, l, O stay as they are
+      pf[nb] = i32x8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (!nb_on[nb]) continue;  // nothing of this stage is visible to the block: m, l, O stay as they are
       const float rs = row_scale[nb];
       const int lim = bit_cur[nb] ? row_lim[nb] : -1;
-      float mt;
-      // per-row scale only, nothing to mask: never form s * rs (a negative scale - not what a quantiser produces -
-      // takes the general path: one test per wave, hoisted)
-      constexpr bool fast = kFast;
-      if (fast) {
-        float mx = kNegInf;
+      float mt = kNegInf;
+      if constexpr (kFast) {
+        // per-row scale only, nothing to mask: never form s * rs (a negative scale - not what a quantiser produces -
+        // takes the general body: one test per wave, hoisted)
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
+        for (int tb = 0; tb < 8; ++tb)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[nb][tb][r]);
-        mt = rs * mx;
+          for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[nb][tb][r]);
+        mt *= rs;
       } else {
-        mt = kNegInf;
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb) {
+        for (int tb = 0; tb < 8; ++tb) {
           f32x4 kscl = f32x4{1.f, 1.f, 1.f, 1.f};
-          if constexpr (kQuant == 0) kscl = *reinterpret_cast<const f32x4*>(&s_ks[buf][kSub * 64 + tb * 16 + g * 4]);
+          if constexpr (kQuant == 0) kscl = *reinterpret_cast<const f32x4*>(&s_ks[buf][tb * 16 + g * 4]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float x = s[nb][tb][r] * rs;
@@ -398,9 +396,9 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
       const float m_use = m_new == kNegInf ? 0.f : m_new;
       const float bias = 8.0f - m_use;  // exp2(x - m + 8) = 256 p
       float psum = 0.f;
-      const float mul = fast ? rs : 1.0f;  // one form for both paths: the slow path left s * rs (masked) in s
+      const float mul = kFast ? rs : 1.0f;  // one form for both bodies: the general one left s * rs (masked) in s
 #pragma unroll
-      for (int tb = 0; tb < 4; ++tb) {
+      for (int tb = 0; tb < 8; ++tb) {
         float p[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -410,9 +408,9 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
         // p <= 2^8 < 448 by construction (x <= m): no clamp in front of the conversion
         int w = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], 0, false);
         w = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], w, true);
-        pf[nb][tb >> 1][tb & 1] = static_cast<uint32_t>(w);
+        pf[nb][tb] = w;
       }
-      // rescale only when some row's maximum moved (past the first tiles of a long row it rarely does)
+      // rescale only when some row's maximum moved (past the first stages of a long row it rarely does)
       if (__builtin_amdgcn_ballot_w64(m_new != m_run[nb]) != 0) {
         const float alpha = __builtin_amdgcn_exp2f(m_run[nb] - m_use);
         l_run[nb] *= alpha;
@@ -423,24 +421,20 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
       l_run[nb] += psum;
     }
 
-    // ---- O^T += V^T P^T: one transposing read per 16 dims and 32 tokens (lane (i, g): row j = i / 2 of the 8 x 16
-    // tile is token 32 ks + 16 (j / 4) + 4 g + j % 4 - the k-slot order of pf -, 8-byte half i % 2) --------------------
+    // ---- O^T += V^T P^T: four transposing reads per 16 dims (lane (i, g): row j = i / 2 of read u is token
+    // 32 u + 16 (j / 4) + 4 g + j % 4 = byte 8 u + j of the lane's 32 - the byte order of pf -, 8-byte half i % 2) -----
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      v2i32 vtr[8];
+    for (int jj = 0; jj < 8; ++jj) {
+      v2i32 vtr[4];
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj)
-        vtr[jj] = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
-            reinterpret_cast<lds_v2i32*>(static_cast<uint32_t>((vt_base ^ (jj << 4)) + buf * (128 * 128) + kSub * (64 * 128) + ks * (32 * 128))));
+      for (int u = 0; u < 4; ++u)
+        vtr[u] = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+            reinterpret_cast<lds_v2i32*>(static_cast<uint32_t>((vt_base ^ (jj << 4)) + buf * (128 * 128) + u * (32 * 128))));
+      const i32x8 va = {vtr[0][0], vtr[0][1], vtr[1][0], vtr[1][1], vtr[2][0], vtr[2][1], vtr[3][0], vtr[3][1]};
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        const long va = pack64(static_cast<uint32_t>(vtr[jj][0]), static_cast<uint32_t>(vtr[jj][1]));
-#pragma unroll
-        for (int nb = 0; nb < kNB; ++nb)
-          o[nb][jj] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(va, pack64(pf[nb][ks][0], pf[nb][ks][1]), o[nb][jj], 0, 0, 0);
-      }
+      for (int nb = 0; nb < kNB; ++nb)
+        o[nb][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(va, pf[nb], o[nb][jj], 0, 0, 0, 0, 0, 0);
     }
-    }  // need_cur
   };
   // tiles every row of this wave sees in full, scales of a real quantiser (>= 0), no per-row mask bits: the fast body
   const int n_fast = (kQuant == 1 && scales_nonneg && (!kSparse || by_head)) ? ntile_full : 0;
@@ -449,8 +443,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
     fetch(t + 2, IntC<0>{});  // the next stage (both sets went to LDS at the end of the previous one)
     fetch(t + 3, IntC<1>{});
     need_cur = tile_bits(t >> 1, bit_cur);
-    tile(t, buf, IntC<0>{}, fast_c);
-    if (t + 1 < ntile) tile(t + 1, buf, IntC<1>{}, fast_c);
+    body(t, buf, fast_c);
     landed(IntC<0>{});
     landed(IntC<1>{});
     stash(IntC<0>{}, buf ^ 1);
