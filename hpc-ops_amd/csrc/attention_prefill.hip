@@ -321,6 +321,21 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   auto body = [&](int t, int buf, auto fast_c) {
     constexpr bool kFast = decltype(fast_c)::value != 0;
     const uint8_t* kt = s_k[buf];
+    // O^T += V^T P^T: four transposing reads per 16 dims (lane (i, g): row j = i / 2 of read u is token
+    // 32 u + 16 (j / 4) + 4 g + j % 4 = byte 8 u + j of the lane's 32 - the byte order of pf -, 8-byte half i % 2)
+    auto vt_operand = [&](int jj) {
+      v2i32 vtr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        vtr[u] = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+            reinterpret_cast<lds_v2i32*>(static_cast<uint32_t>((vt_base ^ (jj << 4)) + buf * (128 * 128) + u * (32 * 128))));
+      return i32x8{vtr[0][0], vtr[0][1], vtr[1][0], vtr[1][1], vtr[2][0], vtr[2][1], vtr[3][0], vtr[3][1]};
+    };
+    auto pv_block = [&](int nb, const i32x8& p) {
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj)
+        o[nb][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(vt_operand(jj), p, o[nb][jj], 0, 0, 0, 0, 0, 0);
+    };
     bool nb_on[kNB];  // block-sparse: does this 16-row block (one head when G <= 8) attend the stage at all?
 #pragma unroll
     for (int nb = 0; nb < kNB; ++nb) nb_on[nb] = !kSparse || __ballot(bit_cur[nb] && row_lim[nb] >= 0) != 0;
@@ -419,21 +434,19 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
         m_run[nb] = m_new;
       }
       l_run[nb] += psum;
-    }
 
-    // ---- O^T += V^T P^T: four transposing reads per 16 dims (lane (i, g): row j = i / 2 of read u is token
-    // 32 u + 16 (j / 4) + 4 g + j % 4 = byte 8 u + j of the lane's 32 - the byte order of pf -, 8-byte half i % 2) -----
+      if constexpr (kSparse) pv_block(nb, pf[nb]);  // block-sparse: right here, and not at all for a block that is off
+    }
+    // dense: V^T operands shared by the two blocks (848 us against 888 us with one pass per block; the block-sparse
+    // form is the other way round, 799 against 839 us at skip 0.5: half its blocks need no pass)
+    if constexpr (!kSparse) {
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      v2i32 vtr[4];
+      for (int jj = 0; jj < 8; ++jj) {
+        const i32x8 va = vt_operand(jj);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        vtr[u] = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
-            reinterpret_cast<lds_v2i32*>(static_cast<uint32_t>((vt_base ^ (jj << 4)) + buf * (128 * 128) + u * (32 * 128))));
-      const i32x8 va = {vtr[0][0], vtr[0][1], vtr[1][0], vtr[1][1], vtr[2][0], vtr[2][1], vtr[3][0], vtr[3][1]};
-#pragma unroll
-      for (int nb = 0; nb < kNB; ++nb)
-        o[nb][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(va, pf[nb], o[nb][jj], 0, 0, 0, 0, 0, 0);
+        for (int nb = 0; nb < kNB; ++nb)
+          o[nb][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(va, pf[nb], o[nb][jj], 0, 0, 0, 0, 0, 0);
+      }
     }
   };
   // tiles every row of this wave sees in full, scales of a real quantiser (>= 0), no per-row mask bits: the fast body
