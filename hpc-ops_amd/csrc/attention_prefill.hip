@@ -135,7 +135,9 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   // q head x 16 consecutive positions (block-sparse masks are per head: a whole block can then skip a
   // tile); G = 16: 8 positions x 16 heads, head fastest.
   constexpr int kWgRows = kWaves * kRowsPerWave;
-  const int wg_pos0 = (blockIdx.x * kWgRows) >> a.g_shift;  // positions per workgroup = 128 / G
+  // q tiles are handed out last-first: a late tile walks the most KV (causal), so the longest workgroups start first
+  // and the grid's tail is made of the short ones
+  const int wg_pos0 = ((gridDim.x - 1 - blockIdx.x) * kWgRows) >> a.g_shift;  // positions per workgroup = 128 / G
   if (wg_pos0 >= Sq) return;  // whole workgroup past the request (uniform exit)
   const bool by_head = a.by_head != 0;
   const int blk_per_head = by_head ? (kWgRows >> a.g_shift) >> 4 : 0;  // 16-position blocks per head

@@ -82,7 +82,9 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a)
   const int Sq = as_const(a.cu_seqlens_q)[b + 1] - q0;
   const int L = a.seqlens_kv ? as_const(a.seqlens_kv)[b] : Sq;
   constexpr int kWgRows = kWaves * kRowsPerWave;
-  const int wg_pos0 = (blockIdx.x * kWgRows) >> a.g_shift;
+  // q tiles are handed out last-first: a late tile walks the most KV (causal), so the longest workgroups start first
+  // and the grid's tail is made of the short ones
+  const int wg_pos0 = ((gridDim.x - 1 - blockIdx.x) * kWgRows) >> a.g_shift;
   if (wg_pos0 >= Sq) return;
   const int row0 = wave * kRowsPerWave;  // rows of the workgroup: position-major, q head fastest
   const int pos_first = wg_pos0 + (row0 >> a.g_shift);
