@@ -217,7 +217,7 @@ def test_attn_fp8_single_kv_head(block_size, num_seq_q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form", ["four_heads", "head_pairs"])
+@pytest.mark.parametrize("form", ["four_heads"])  # (the head-pair form serves these shapes by default: every other test)
 @pytest.mark.parametrize("num_seq_q,block_size,heads", [(1, 64, (8, 64)), (1, 64, (4, 32)), (2, 32, (4, 16)), (1, 16, (4, 16)),
                                                          (2, 16, (8, 32)), (1, 32, (12, 48)), (1, 64, (16, 64))])
 def test_attn_fp8_four_heads_per_workgroup(form, num_seq_q, block_size, heads):
@@ -237,7 +237,7 @@ def test_attn_fp8_four_heads_per_workgroup(form, num_seq_q, block_size, heads):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("keys", [{32: 115}, {30: 112, 31: 106}, {30: 118, 31: 108, 32: 125}, {32: 200}])
+@pytest.mark.parametrize("keys", [{32: 115}, {30: 118, 31: 108, 32: 125}])
 @pytest.mark.parametrize("num_batch,hi", [(64, 6000), (200, 1500), (7, 30000)])
 def test_attn_fp8_uneven_ranges(keys, num_batch, hi):
     """Development variants of the in-kernel plan: longer ranges for the first half of the grid (key 32) and unequal
