@@ -204,6 +204,8 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   // Two register sets = the two tiles of the NEXT stage, fetched at the top of a stage and written to the other LDS
   // buffer at its end.  (Fetching two 64-token tiles ahead with one barrier per tile measured the same as one ahead: the
   // loop is not latency-bound.)
+  const uint8_t* kbase_h = kbase + h * a.k_head_stride;
+  const uint8_t* vbase_h = vbase + h * a.v_head_stride;
   u32x4 kst[2][2], vst[2][2];
   float ksst[2] = {0.f, 0.f};
   auto fetch = [&](int t, auto set_c) {  // unconditional: tiles past the end re-read the last block (never used)
@@ -213,8 +215,13 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
     const int gtok = blk << 4;
     const int pid = __builtin_amdgcn_readfirstlane(bid_row[gtok >> a.page_shift]);
     const int inpage = gtok & page_mask;
-    const i32x4 rk = srd_of(kbase + pid * a.k_block_stride + inpage * a.k_token_stride + h * a.k_head_stride);
-    const i32x4 rv = srd_of(vbase + pid * a.v_block_stride + inpage * a.v_token_stride + h * a.v_head_stride);
+    // unsigned 32 x 32 -> 64 products (the launcher refuses block strides of 4 GB and more): as signed 64-bit
+    // arithmetic the four descriptor bases of a stage cost ~90 scalar instructions
+    const uint32_t pidu = static_cast<uint32_t>(pid), inp = static_cast<uint32_t>(inpage);
+    const i32x4 rk = srd_of(kbase_h + static_cast<uint64_t>(pidu) * static_cast<uint32_t>(a.k_block_stride) +
+                            inp * static_cast<uint32_t>(a.k_token_stride));
+    const i32x4 rv = srd_of(vbase_h + static_cast<uint64_t>(pidu) * static_cast<uint32_t>(a.v_block_stride) +
+                            inp * static_cast<uint32_t>(a.v_token_stride));
     // Loads the compiler does not see (as in attention_decode_v2.hip): with compiler-visible loads hipcc drains the
     // whole queue - the set fetched at the top of this tile included - in front of every stash.  A fetch is kPer loads
     // in a fixed order; the stash of the older set waits with vmcnt(kPer).
@@ -570,6 +577,11 @@ static int prefill_fp8_launch(const void* block_mask_ptr, int mask_tiles_m, int 
   a.ks_row_stride = kscale_row_stride_bytes;
   a.ks_head_stride = kscale_head_stride_bytes;
   a.scale_log2 = 1.4426950408889634f / 11.313708498984761f;  // log2(e) / sqrt(128)
+  // the kernel forms page offsets as unsigned 32 x 32 -> 64 products
+  if (kcache_block_stride <= 0 || vcache_block_stride <= 0 || kcache_token_stride <= 0 || vcache_token_stride <= 0 ||
+      kcache_block_stride >= (1ll << 32) || vcache_block_stride >= (1ll << 32) ||
+      kcache_token_stride * block_size >= (1ll << 32) || vcache_token_stride * block_size >= (1ll << 32))
+    return HPC_ERR_UNSUPPORTED;
   const long rows = static_cast<long>(max_seqlens_q) * group;
   dim3 grid(static_cast<unsigned>((rows + kWaves * kRowsPerWave - 1) / (kWaves * kRowsPerWave)), num_head_kv, num_batch);
   if (grid.z > 65535 || grid.y > 65535) return HPC_ERR_UNSUPPORTED;
