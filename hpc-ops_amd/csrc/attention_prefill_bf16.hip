@@ -133,8 +133,13 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a)
       const int pid = __builtin_amdgcn_readfirstlane(
           as_const(a.block_ids)[static_cast<long>(b) * a.max_blocks + (gtok >> a.page_shift)]);
       const int inpage = gtok & page_mask;
-      kb = pid * a.k_block_stride + inpage * a.k_token_stride;
-      vb = pid * a.v_block_stride + inpage * a.v_token_stride;
+      // unsigned 32 x 32 -> 64 products (the launcher refuses larger strides): a quarter of the scalar instructions
+      // of the signed 64-bit form
+      const uint32_t pidu = static_cast<uint32_t>(pid), inp = static_cast<uint32_t>(inpage);
+      kb = static_cast<long>(static_cast<uint64_t>(pidu) * static_cast<uint32_t>(a.k_block_stride) +
+                             inp * static_cast<uint32_t>(a.k_token_stride));
+      vb = static_cast<long>(static_cast<uint64_t>(pidu) * static_cast<uint32_t>(a.v_block_stride) +
+                             inp * static_cast<uint32_t>(a.v_token_stride));
       k_lim = v_lim = 0xffffffffu;
     } else {
       // contiguous K/V: the last 16-token block of a request may run past its end - bound the read by
@@ -389,6 +394,11 @@ extern "C" int hpc_attention_with_kvcache_prefill_bf16_async(
   a.v_block_stride = vcache_block_stride;
   a.v_token_stride = vcache_token_stride;
   a.v_head_stride = vcache_head_stride;
+  // the kernel forms page offsets (in elements) as unsigned 32 x 32 -> 64 products
+  if (kcache_block_stride <= 0 || vcache_block_stride <= 0 || kcache_token_stride <= 0 || vcache_token_stride <= 0 ||
+      kcache_block_stride >= (1ll << 31) || vcache_block_stride >= (1ll << 31) ||
+      kcache_token_stride * block_size >= (1ll << 31) || vcache_token_stride * block_size >= (1ll << 31))
+    return HPC_ERR_UNSUPPORTED;
   return launch_prefill_bf16(a, max_seqlens_q, num_head_q, num_head_kv, num_batch, stream);
 }
 
