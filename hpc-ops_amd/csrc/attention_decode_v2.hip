@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   __shared__ __attribute__((aligned(1024))) uint8_t s_wave[kWaves][kWaveLds];  // stage addresses are (base) ^ (bits 4-7)
   __shared__ float s_m[2][kWaves][16];
   __shared__ float s_l[2][kWaves][16];
-  __shared__ int s_ticket;
+  __shared__ int s_ticket[2];
   constexpr int kH = kQuad ? 4 : 2;          // kv heads per workgroup
   constexpr int kW = kWide ? 16 : 32;        // tokens (= stage rows) per wave-iteration
   constexpr int kRowB = kWide ? 512 : 256;   // bytes of a stage row: the workgroup's heads of a token
@@ -565,6 +565,116 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     st16(dst, pk);
   };
 
+  // ---- split requests: arrival tickets and merges, deferred to the end of the workgroup's range --------------------
+  // (reference: the last CTA of a request reduces, static_splitk_kernels.cuh:362-377; combine math:
+  // splitk_combine_kernels.cuh.)  One atomic add per arrival: the counter region is zero on first use - the contract of
+  // hpc_attention_decode_workspace_zero_bytes() - and the last arriver puts the zero back.
+  int np = 0, p0_b = 0, p0_first = 0, p0_n = 0, p1_b = 0, p1_first = 0, p1_n = 0;
+  auto merge_request = [&](int db, int first_rng, int nchunks) __attribute__((always_inline)) {
+    int* cnt = a.arrive + static_cast<long>(pr) * B + db;
+    // Wave w folds chunks w, w + 4, ... of every (head, row) into (max lse, sum of weights, weighted O) - the
+    // form the per-task merge takes - two chunks x four (head, row) units in flight per lane; then the
+    // per-task combine finishes.  lane (r4 = lane / 16, c8 = lane % 16): rows r4 + 4 i, dims c8 * 8 .. + 8.
+    const int r4 = lane >> 4, c8l = lane & 15;
+    auto slot_of = [&](int c, int hh) __attribute__((always_inline)) {
+      return (static_cast<long>(lwg0 + first_rng + c) * 2 + (c == 0 ? 1 : 0)) * 2 + hh;
+    };
+#pragma unroll 1
+    for (int ig = 0; ig < 2; ++ig) {     // row groups {r4, r4 + 4} and {r4 + 8, r4 + 12}
+      if (!kQuad && ig * 8 >= rows_valid) break;   // wave-uniform
+      float um[2][2], ul[2][2], ua[2][2][8];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          um[hh][i] = kNegInf;
+          ul[hh][i] = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ua[hh][i][e] = 0.f;
+        }
+      for (int c0 = wave; c0 < nchunks; c0 += 2 * kWaves) {
+        float lv[2][2][2];
+        u32x4 x0[2][2][2], x1[2][2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int c = c0 + u * kWaves < nchunks ? c0 + u * kWaves : c0;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const long slot = slot_of(c, hh);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int row = ig * 8 + i * 4 + r4;
+              lv[u][hh][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(lse_rs, static_cast<int>((slot * 16 + row) * 4), 0, 16));
+              const int off = static_cast<int>(((slot * 16 + row) * 128 + c8l * 8) * 4);
+              x0[u][hh][i] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, off, 0, 16);
+              x1[u][hh][i] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, off + 16, 0, 16);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const bool real = c0 + u * kWaves < nchunks;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const float lse = real ? lv[u][hh][i] : kNegInf;
+              const float mn = fmaxf(um[hh][i], lse);
+              const float mu = mn == kNegInf ? 0.f : mn;
+              const float sc_old = __builtin_amdgcn_exp2f(um[hh][i] - mu), wgt = __builtin_amdgcn_exp2f(lse - mu);
+              um[hh][i] = mn;
+              ul[hh][i] = ul[hh][i] * sc_old + wgt;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                ua[hh][i][e] = fmaf(wgt, __uint_as_float(x0[u][hh][i][e]), ua[hh][i][e] * sc_old);
+                ua[hh][i][4 + e] = fmaf(wgt, __uint_as_float(x1[u][hh][i][e]), ua[hh][i][4 + e] * sc_old);
+              }
+            }
+        }
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = ig * 8 + i * 4 + r4;
+          if (c8l == 0) {
+            s_m[hh][wave][row] = um[hh][i];
+            s_l[hh][wave][row] = ul[hh][i];
+          }
+          float* so = my_so + (hh * 16 + row) * 128 + c8l * 8;
+          *reinterpret_cast<f32x4*>(so) = f32x4{ua[hh][i][0], ua[hh][i][1], ua[hh][i][2], ua[hh][i][3]};
+          *reinterpret_cast<f32x4*>(so + 4) = f32x4{ua[hh][i][4], ua[hh][i][5], ua[hh][i][6], ua[hh][i][7]};
+        }
+    }
+    __syncthreads();
+    const int row16 = tid >> 4, c8 = tid & 15;
+    if (row_ok(row16)) {
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float acc[8], M, L;
+        combine4(hh, row16, c8, acc, M, L);
+        store_y(db, hh, row16, c8, acc, L > 0.f ? 1.0f / L : 0.f);
+      }
+    }
+    if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+    __syncthreads();  // the merge buffers are free again
+  };
+  auto flush_pending = [&]() __attribute__((always_inline)) {
+    if (np == 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my partial stores have reached memory
+    __syncthreads();
+    if (tid == 0) {
+      s_ticket[0] = __hip_atomic_fetch_add(a.arrive + static_cast<long>(pr) * B + p0_b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+      if (np > 1)
+        s_ticket[1] = __hip_atomic_fetch_add(a.arrive + static_cast<long>(pr) * B + p1_b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    }
+    __syncthreads();
+    const int t0 = s_ticket[0], t1 = s_ticket[1];
+    if (t0 == p0_n) merge_request(p0_b, p0_first, p0_n);
+    if (np > 1 && t1 == p1_n) merge_request(p1_b, p1_first, p1_n);
+    np = 0;
+  };
+
   // ---- end of a task: merge the 4 waves and emit (the stage regions are idle: they double as s_o) ---------------
   auto finish_task = [&]() __attribute__((always_inline)) {
     const int db = q0_b;
@@ -613,105 +723,15 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
       }
     }
     if (nchunks > 1) {
-      // ---- split request: take a ticket; the last chunk to arrive merges all of them (reference: the last
-      // CTA of a request reduces, static_splitk_kernels.cuh:362-377; combine math: splitk_combine_kernels.cuh)
-      int* cnt = a.arrive + static_cast<long>(pr) * B + db;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my partial stores have reached memory
-      __syncthreads();
-      if (tid == 0) {
-        // one atomic add = one round trip (the epoch-tagged compare-and-swap loop of round 2 cost two on the
-        // critical path of every split task): the counter region is zero on first use - the contract of
-        // hpc_attention_decode_workspace_zero_bytes() - and the last arriver puts the zero back
-        s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-      }
-      __syncthreads();
-      if (s_ticket == nchunks) {
-        // Wave w folds chunks w, w + 4, ... of every (head, row) into (max lse, sum of weights, weighted O) - the
-        // form the per-task merge takes - two chunks x four (head, row) units in flight per lane; then the
-        // per-task combine finishes.  lane (r4 = lane / 16, c8 = lane % 16): rows r4 + 4 i, dims c8 * 8 .. + 8.
-        const int r4 = lane >> 4, c8l = lane & 15;
-        auto slot_of = [&](int c, int hh) __attribute__((always_inline)) {
-          return (static_cast<long>(lwg0 + first_rng + c) * 2 + (c == 0 ? 1 : 0)) * 2 + hh;
-        };
-#pragma unroll 1
-        for (int ig = 0; ig < 2; ++ig) {     // row groups {r4, r4 + 4} and {r4 + 8, r4 + 12}
-          if (!kQuad && ig * 8 >= rows_valid) break;   // wave-uniform
-          float um[2][2], ul[2][2], ua[2][2][8];
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              um[hh][i] = kNegInf;
-              ul[hh][i] = 0.f;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) ua[hh][i][e] = 0.f;
-            }
-          for (int c0 = wave; c0 < nchunks; c0 += 2 * kWaves) {
-            float lv[2][2][2];
-            u32x4 x0[2][2][2], x1[2][2][2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const int c = c0 + u * kWaves < nchunks ? c0 + u * kWaves : c0;
-#pragma unroll
-              for (int hh = 0; hh < 2; ++hh) {
-                const long slot = slot_of(c, hh);
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                  const int row = ig * 8 + i * 4 + r4;
-                  lv[u][hh][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(lse_rs, static_cast<int>((slot * 16 + row) * 4), 0, 16));
-                  const int off = static_cast<int>(((slot * 16 + row) * 128 + c8l * 8) * 4);
-                  x0[u][hh][i] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, off, 0, 16);
-                  x1[u][hh][i] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, off + 16, 0, 16);
-                }
-              }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-              const bool real = c0 + u * kWaves < nchunks;
-#pragma unroll
-              for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                  const float lse = real ? lv[u][hh][i] : kNegInf;
-                  const float mn = fmaxf(um[hh][i], lse);
-                  const float mu = mn == kNegInf ? 0.f : mn;
-                  const float sc_old = __builtin_amdgcn_exp2f(um[hh][i] - mu), wgt = __builtin_amdgcn_exp2f(lse - mu);
-                  um[hh][i] = mn;
-                  ul[hh][i] = ul[hh][i] * sc_old + wgt;
-#pragma unroll
-                  for (int e = 0; e < 4; ++e) {
-                    ua[hh][i][e] = fmaf(wgt, __uint_as_float(x0[u][hh][i][e]), ua[hh][i][e] * sc_old);
-                    ua[hh][i][4 + e] = fmaf(wgt, __uint_as_float(x1[u][hh][i][e]), ua[hh][i][4 + e] * sc_old);
-                  }
-                }
-            }
-          }
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              const int row = ig * 8 + i * 4 + r4;
-              if (c8l == 0) {
-                s_m[hh][wave][row] = um[hh][i];
-                s_l[hh][wave][row] = ul[hh][i];
-              }
-              float* so = my_so + (hh * 16 + row) * 128 + c8l * 8;
-              *reinterpret_cast<f32x4*>(so) = f32x4{ua[hh][i][0], ua[hh][i][1], ua[hh][i][2], ua[hh][i][3]};
-              *reinterpret_cast<f32x4*>(so + 4) = f32x4{ua[hh][i][4], ua[hh][i][5], ua[hh][i][6], ua[hh][i][7]};
-            }
-        }
-        __syncthreads();
-        const int row16 = tid >> 4, c8 = tid & 15;
-        if (row_ok(row16)) {
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            float acc[8], M, L;
-            combine4(hh, row16, c8, acc, M, L);
-            store_y(db, hh, row16, c8, acc, L > 0.f ? 1.0f / L : 0.f);
-          }
-        }
-        if (tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
-      }
+      // ---- split request: this chunk's partial is on its way to memory; the arrival ticket - and, for the chunk that
+      // arrives last, the merge - wait until this workgroup has walked its whole range (round 3: taken on the spot, the
+      // ticket cost every split task a drain of the load queue, two barriers and an atomic round trip with the memory
+      // pipeline idle; a range holds at most two split tasks - its first and its last)
+      // (a range is an interval of the cost axis: only the request that crosses its start and the one that crosses its
+      // end are split - or one request that crosses both)
+      p1_b = np == 1 ? db : p1_b, p1_first = np == 1 ? first_rng : p1_first, p1_n = np == 1 ? nchunks : p1_n;
+      p0_b = np == 0 ? db : p0_b, p0_first = np == 0 ? first_rng : p0_first, p0_n = np == 0 ? nchunks : p0_n;
+      np = np < 2 ? np + 1 : 2;
     }
     __syncthreads();
     reset_state();
@@ -1089,6 +1109,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
                 (static_cast<uint64_t>(rng) << 8) | static_cast<uint64_t>(pr);
     }
   }
+  flush_pending();
   // the loads issued for the WI past the end were no-ops, but they own the registers until they retire
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
