@@ -37,8 +37,9 @@
 //  * the 4 waves of a workgroup share a task (WIs w, w+4, ...), merge through LDS once per task (the idle
 //    stage regions double as the merge buffer) and write bf16 y.  A request cut by a range boundary leaves
 //    an fp32 partial + base-2 LSE per chunk (write-through stores) and takes a ticket on the request's arrival
-//    counter; the chunk that arrives LAST merges all of them in the same launch (the reference's static path
-//    does the same, static_splitk_kernels.cuh:362-377) - no second kernel, no launch boundary.  That merge is
+//    counter - at the END of its workgroup's range, once for the (at most two) split tasks of the range; the chunk
+//    that arrives LAST merges all of them in the same launch (the reference's static path does the same,
+//    static_splitk_kernels.cuh:362-377) - no second kernel, no launch boundary.  That merge is
 //    spread over the workgroup: wave w folds chunks w, w+4, ... into a partial in the same (max, sum, O) form the
 //    per-task merge uses, and the per-task combine code finishes it.  The counters live at the start of the
 //    call's scratch: a fixed 64 KB region that must be zero on first use and is left zero by every call (one
