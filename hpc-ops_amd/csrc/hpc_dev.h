@@ -1,6 +1,6 @@
 // Development tuning registers - INTERNAL, not part of the C-ABI of include/hpc_amd.h.
 //
-// 32 small integers that select kernel variants inside the launchers for A/B measurements and for
+// 64 small integers that select kernel variants inside the launchers for A/B measurements and for
 // the parity tests that pin one variant (tests/, tools/).  All zero = the shipped configuration.
 // Storage is a set of relaxed atomics (any host thread may read them while another one writes);
 // the environment variable HPC_AMD_TUNING="key=value,key=value" seeds them once at library load,
@@ -23,7 +23,8 @@
 //   key 29 decode fp8: 2 = the four-head form of the head-pair kernel (<= 8 q rows per kv head, kv heads % 4 == 0)
 //   key 30 / 31 decode fp8, 8 kv heads: extra workgroups (value - 100 per 128) for the head pair at byte 256 / 768 of a token row
 //   key 32 decode fp8: ranges of the first half of the grid in percent of the others' (0 = equal)
-//   key 18 256x256 grouped GEMM: 1 = no DMA in the k-loop (timing only)
+//   key 18 256x256 grouped GEMM: 1 = no DMA in the k-loop (timing only - wrong results), 2 = the round-2 FMA form of the
+//          blockwise rescale (same results up to fp32 rounding)
 //   others: see the launchers that read them
 #pragma once
 
