@@ -129,3 +129,25 @@ def test_development_registers_are_internal_and_cover_their_keys():
         assert lib.hpc_dev_tuning_set(key, 0) == 0
     assert lib.hpc_dev_tuning_set(64, 1) == -2 and lib.hpc_dev_tuning_get(64) == 0
     assert lib.hpc_dev_tuning_set(-1, 1) == -2
+
+
+def test_prefill_refuses_strides_the_kernel_cannot_address():
+    """Host-side argument checks run before any device call: the FP8 prefill kernels form page offsets as unsigned
+    32 x 32 -> 64 products, so a page (block) stride of 4 GB or more is refused - HPC_ERR_UNSUPPORTED, not a launch."""
+    from ctypes import c_int, c_int64, c_void_p
+
+    lib = ctypes.CDLL(str(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so"))
+    fn = lib.hpc_attention_with_kvcache_prefill_fp8_async
+    fn.restype = c_int
+    fn.argtypes = [c_void_p] * 10 + [c_int] * 12 + [c_int64] * 9 + [c_void_p]
+    p = c_void_p(4096)  # never dereferenced on the host
+    ints = (1, 2, 128, 128, 128, 128, 8, 1, 64, 4, 1024, 1024)  # quant_type 1, B 2, Sq 128, D 128/128, 8/1 heads, pages of 64
+    ok_strides = (64 * 128, 128, 128, 64 * 128, 128, 128, 0, 0, 0)
+    big = 1 << 32
+    for which in (0, 3):  # K block stride, V block stride
+        strides = list(ok_strides)
+        strides[which] = big
+        assert fn(*([p] * 10), *ints, *strides, None) == -1
+    strides = list(ok_strides)
+    strides[1] = big // 64  # token stride x page size reaches 4 GB
+    assert fn(*([p] * 10), *ints, *strides, None) == -1
