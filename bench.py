@@ -547,20 +547,22 @@ def extra_moe_presets(dev, hpc, presets=("qwen3-235b", "deepseek-v3"), batches=(
             h2 = torch.randn(H, I, device=dev, generator=g).bfloat16()
             s1[e], s2[e] = h1.float().abs().max() / 448.0, h2.float().abs().max() / 448.0
             w1[e], w2[e] = (h1.float() / s1[e]).to(torch.float8_e4m3fn), (h2.float() / s2[e]).to(torch.float8_e4m3fn)
-        a_scale = torch.full((1,), 1e-2, device=dev)
-        act_scale = torch.ones(1, device=dev)
-        gus = s1 * a_scale
+        # backends/hpcops.py:31-41: A_SCALE_VALUE = 1e-2 as a 0-dim tensor, folded into both GEMM scales, and
+        # as the activation scale
+        a_scale = torch.full((), 1e-2, device=dev)
+        act_scale = torch.full((1,), 1e-2, device=dev)
+        gus = (s1 * 1e-2).contiguous()
+        dns = (s2 * 1e-2).contiguous()
         row = {}
         for T in batches:
             ids = torch.stack([torch.sort(torch.randperm(E, device=dev, generator=g)[:k].to(torch.int32)).values for _ in range(min(T, 512))])
             ids = ids.repeat((T + ids.size(0) - 1) // ids.size(0), 1)[:T].contiguous()
             tw = torch.softmax(torch.randn(T, k, device=dev, generator=g), dim=-1)
-            a_half = torch.randn(T, H, device=dev, generator=g).bfloat16() / 10
+            a_half = torch.randn(T, H, device=dev, generator=g).half()  # base.py:164-172: fp16 activations
 
-            def call():
-                x8 = hpc.scaled_fp8_quant(a_half, a_scale)
-                x8 = x8[0] if isinstance(x8, (tuple, list)) else x8
-                return hpc.fuse_moe(x8, w1, w2, gus, s2, act_scale, ids, tw, 0, E, use_bf16_mul=True)
+            def call():  # backends/hpcops.py:49-57, literally
+                x_fp8, _ = torch.ops.hpc.scaled_fp8_quant(a_half, a_scale, None)
+                return hpc.fuse_moe(x_fp8, w1, w2, gus, dns, act_scale, ids, tw, 0, E, use_bf16_mul=True)
 
             us = timed(call, iters=10, warm=2, graph=True)
             flops = 2.0 * T * k * 3 * I * H

@@ -119,9 +119,9 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
   static_assert(sizeof(float) * kWaves * 16 * (128 + 4) <= 2 * 128 * kKRow, "s_o aliases s_k");
   float (*s_o)[16][128 + 4] = reinterpret_cast<float (*)[16][128 + 4]>(&s_k[0][0]);
   // block-sparse: the mask rows of this workgroup's q tile, one per q head of the kv head (<= 64k tokens)
-  // (round 3: ONE byte per mask column, bit gq = q head gq of this kv head attends the column - a tile costs one
-  // broadcast LDS read instead of G + 2 byte reads)
-  __shared__ uint8_t s_mask[kSparse ? kMaskCols : 16];
+  // (round 3: ONE word per mask column, bit gq = q head gq of this kv head attends the column - a tile costs one
+  // broadcast LDS read instead of G + 2 byte reads; 16 bits: the launcher accepts up to 16 q heads per kv head)
+  __shared__ uint16_t s_mask[kSparse ? kMaskCols : 16];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
       for (int gq = 0; gq < G; ++gq)
         bits |= (a.block_mask[((static_cast<long>(b) * a.num_head_q + (h << a.g_shift) + gq) * a.mask_tiles_m + mask_tm) *
                                   a.mask_tiles_kv + col] != 0 ? 1u : 0u) << gq;
-      s_mask[col] = static_cast<uint8_t>(bits);
+      s_mask[col] = static_cast<uint16_t>(bits);
     }
     __syncthreads();
   }

@@ -247,20 +247,50 @@ __global__ __launch_bounds__(kThreads) void act_mul_quant_kernel(
   *reinterpret_cast<u32x2*>(out + static_cast<long>(row) * inter + c8 * 8) = q;
 }
 
-// out = e4m3(float(in) * scale[0])  (reference scaled_fp8_quant, src/activation/activation.cu)
-__global__ __launch_bounds__(kThreads) void scaled_fp8_quant_kernel(const uint16_t* __restrict__ in,
+// out = e4m3(float(in) * (1.0f / scale[0]))  (reference scaled_fp8_quant_kernel, src/activation/activation.cu:461-505:
+// the reciprocal is taken once, IEEE division, and every element is MULTIPLIED by it - so is this).
+// kIn: 0 = bf16, 1 = fp16, 2 = fp32.  A thread converts 8 elements per trip (16 B in for the 2-byte types, 2 x 16 B
+// for fp32, 8 B out); the < 8 elements of a ragged tail are done one by one by the first threads of the grid.
+template <int kIn>
+__device__ __forceinline__ float quant_in_to_f32(const void* in, long i) {
+  if constexpr (kIn == 0) return bf16_to_f32(static_cast<const uint16_t*>(in)[i]);
+  if constexpr (kIn == 1) return static_cast<float>(static_cast<const _Float16*>(in)[i]);
+  return static_cast<const float*>(in)[i];
+}
+template <int kIn>
+__global__ __launch_bounds__(kThreads) void scaled_fp8_quant_kernel(const void* __restrict__ in,
                                                                     const float* __restrict__ scale,
-                                                                    long n8, uint8_t* __restrict__ out) {
-  const float sc = scale[0];
-  for (long i = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x; i < n8;
-       i += static_cast<long>(gridDim.x) * kThreads) {
-    const u32x4 v = ld16(in + i * 8);
+                                                                    long numel, uint8_t* __restrict__ out) {
+  const float inv = 1.0f / scale[0];
+  const long n8 = numel >> 3;
+  const long tid = static_cast<long>(blockIdx.x) * kThreads + threadIdx.x;
+  for (long i = tid; i < n8; i += static_cast<long>(gridDim.x) * kThreads) {
+    float a[8];
+    if constexpr (kIn == 0) {
+      const u32x4 v = ld16(static_cast<const uint16_t*>(in) + i * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[2 * j] = bf16lo_to_f32(v[j]), a[2 * j + 1] = bf16hi_to_f32(v[j]);
+    } else if constexpr (kIn == 1) {
+      typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+      const h8 v = *reinterpret_cast<const h8*>(static_cast<const _Float16*>(in) + i * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] = static_cast<float>(v[j]);
+    } else {
+      typedef float f4 __attribute__((ext_vector_type(4)));
+      const f4 v0 = *reinterpret_cast<const f4*>(static_cast<const float*>(in) + i * 8);
+      const f4 v1 = *reinterpret_cast<const f4*>(static_cast<const float*>(in) + i * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = v0[j], a[4 + j] = v1[j];
+    }
     u32x2 q;
-    q[0] = quant_4xe4m3(bf16lo_to_f32(v[0]) * sc, bf16hi_to_f32(v[0]) * sc, bf16lo_to_f32(v[1]) * sc,
-                      bf16hi_to_f32(v[1]) * sc);
-    q[1] = quant_4xe4m3(bf16lo_to_f32(v[2]) * sc, bf16hi_to_f32(v[2]) * sc, bf16lo_to_f32(v[3]) * sc,
-                      bf16hi_to_f32(v[3]) * sc);
+    q[0] = quant_4xe4m3(a[0] * inv, a[1] * inv, a[2] * inv, a[3] * inv);
+    q[1] = quant_4xe4m3(a[4] * inv, a[5] * inv, a[6] * inv, a[7] * inv);
     *reinterpret_cast<u32x2*>(out + i * 8) = q;
+  }
+  const long t = n8 * 8 + tid;
+  if (t < numel) {
+    const float v = quant_in_to_f32<kIn>(in, t) * inv;
+    out[t] = static_cast<uint8_t>(quant_4xe4m3(v, 0.f, 0.f, 0.f) & 0xff);
   }
 }
 
@@ -484,15 +514,21 @@ extern "C" int hpc_act_mul_and_quant_async(void* out_ptr, const void* gate_up_pt
 }
 
 extern "C" int hpc_scaled_fp8_quant_async(void* out_ptr, const void* in_ptr, const void* scale_ptr,
-                                          int64_t numel, hipStream_t stream) {
+                                          int64_t numel, int in_dtype, hipStream_t stream) {
   if (!out_ptr || !in_ptr || !scale_ptr) return HPC_ERR_INVALID;
-  if (numel & 7) return HPC_ERR_UNSUPPORTED;
-  if (numel <= 0) return HPC_OK;
+  if (in_dtype < 0 || in_dtype > 2) return HPC_ERR_UNSUPPORTED;
+  if (numel <= 0) return HPC_ERR_INVALID;  // reference: "input must be non-empty" (src/activation/entry.cc:165)
   const long n8 = numel / 8;
-  const int grid = static_cast<int>(n8 / kThreads + 1 < 4096 ? n8 / kThreads + 1 : 4096);
-  scaled_fp8_quant_kernel<<<grid, kThreads, 0, stream>>>(static_cast<const uint16_t*>(in_ptr),
-                                                         static_cast<const float*>(scale_ptr), n8,
-                                                         static_cast<uint8_t*>(out_ptr));
+  const long want = n8 / kThreads + 1;
+  const int grid = static_cast<int>(want < 4096 ? want : 4096);
+  const float* sp = static_cast<const float*>(scale_ptr);
+  uint8_t* op = static_cast<uint8_t*>(out_ptr);
+  if (in_dtype == 0)
+    scaled_fp8_quant_kernel<0><<<grid, kThreads, 0, stream>>>(in_ptr, sp, numel, op);
+  else if (in_dtype == 1)
+    scaled_fp8_quant_kernel<1><<<grid, kThreads, 0, stream>>>(in_ptr, sp, numel, op);
+  else
+    scaled_fp8_quant_kernel<2><<<grid, kThreads, 0, stream>>>(in_ptr, sp, numel, op);
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }

@@ -126,16 +126,14 @@ __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, co
 // kNoDma (development key 18 = 1, timing only - results are wrong): no DMA inside the k-loop
 // kAct: the gate-up GEMM of the fused MoE - a tile is 128 gate rows (wave group 0) + the 128 up rows of the same
 // columns (group 1); the epilogue applies SiLU(gate) * up and the 128-block quantisation instead of storing y
-// kFmaRescale (development key 18 = 2): the round-2 form of the blockwise rescale - every MFMA starts from zero and
-// its fp32 partial is folded into the running sum with 4 FMAs that follow the MFMA of block n + 2.  Default: the
-// running sums are kept in units of the CURRENT k-block's scale (tot' = tot / f_T), so that the MFMAs of k-tile T
-// accumulate in place; going from k-tile T to T + 1 multiplies them by f_T / f_{T+1}, and the epilogue multiplies by
-// the last scale.  Those multiplies ride in the shadow of the MFMAs of the OTHER half of the wave's rows: section Y
-// (rows 64-127) of k-tile T rescales rows 0-63 for k-tile T + 1, section X of T + 1 rescales rows 64-127 - two
-// v_pk_mul_f32 behind every MFMA, no register in common with the MFMAs in flight, so no wait states (the FMA form
-// reads MFMA results; with the multiplies in the load sections instead those sections outgrow the other wave's 16
-// MFMAs: 1.99 / 2.10 PFLOP/s against 1.98 / 2.05 for the FMA form).
-template <bool kHasXs, bool kNoDma = false, bool kFmaRescale = false, bool kAct = false>
+// Blockwise rescale (kHasXs): the ARITHMETIC OF THE REFERENCE KERNEL (src/group_gemm/kernels.cuh:808-834) - every MFMA
+// starts from zero (K = 128 = one scale block), `f = xs[token, kb] * ws[n / 128, kb]` is one fp32 multiply and the
+// block's fp32 partial is folded into the running sum with ONE fused multiply-add per element, k blocks in order;
+// with block partials that are exact in fp32 the result is bit-identical to what the reference kernel computes
+// (tests/test_fuse_moe_blockwise.py::test_group_gemm_blockwise_is_the_reference_kernel_arithmetic).  Round 3 shipped
+// a cheaper form (running sums kept in units of the current block's scale, tot' = tot / f_T: +2-6 %): it rounds
+// differently from the reference kernel and clamped tiny scales - removed in round 4, parity first.
+template <bool kHasXs, bool kNoDma = false, bool kAct = false>
 __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, const int* __restrict__ cu_tiles,
                                                                   int num_group) {
   __shared__ __attribute__((aligned(1024))) uint8_t s_mem[kLds];
@@ -285,7 +283,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
       const i32x8 bv = {static_cast<int>(bf[0][0]), static_cast<int>(bf[0][1]), static_cast<int>(bf[0][2]),
                         static_cast<int>(bf[0][3]), static_cast<int>(bf[1][0]), static_cast<int>(bf[1][1]),
                         static_cast<int>(bf[1][2]), static_cast<int>(bf[1][3])};
-      if constexpr (kHasXs && kFmaRescale) {
+      if constexpr (kHasXs) {
         const f32x4 part = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0,
                                                                             0, 0);
         __builtin_amdgcn_sched_barrier(0);  // MFMA n first, then the rescale of block n - 2
@@ -297,8 +295,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
         prev2 = prev1;
         prev1 = part;
       } else {
-        // blockwise: tot is in units of this k-block's scale (see k_tile); per-tensor:
-        // one scale per group: accumulate straight into the running sum, scale once in the epilogue
+        // per-tensor: one scale per group: accumulate straight into the running sum, scale once in the epilogue
         // (the reference scales every k-tile: same value up to fp32 rounding)
         tot[i0 + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, tot[i0 + i][j], 0, 0, 0, 0, 0, 0);
       }
@@ -310,7 +307,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
     tail[1] = prev1;
   };
   auto apply_tail = [&](int i0, const float (&f)[4], const f32x4 (&tail)[2]) {
-    if constexpr (kHasXs && kFmaRescale) {
+    if constexpr (kHasXs) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -363,26 +360,6 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
 
   u32x4 a_frag[4][2], b_early[2][2], b_late[2][2];
   f32x4 tail[2];
-  constexpr bool kRatio = kHasXs && !kFmaRescale;
-  // kRatio: cur = the unit of tot (the scale of the k-block being accumulated) per token block; ratio = the factor that
-  // took rows 0-63 to that unit, still to be applied to rows 64-127.  |f| is kept >= 2^-60 so that an all-zero block
-  // (scale 0) cannot produce inf or NaN - its products are exact zeros anyway.  rcp is 1 ulp: the weights of the sum
-  // move by parts in 10^7.
-  float cur[4] = {1.f, 1.f, 1.f, 1.f}, ratio[4] = {1.f, 1.f, 1.f, 1.f};
-  // a 16 x 16 block of running sums times the lane's factor: four v_mul_f32.  (Two v_pk_mul_f32 are slower here: 3215 /
-  // 1504 us against 2931 / 1370 us for the two GEMMs of the MoE at 512 rows per expert - and 32 of them in a load
-  // section cost that section ~340 cycles.)
-  auto scale_block = [](f32x4& t, float r) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t[i] *= r;
-  };
-  auto clamp_scale = [](float v) { return __builtin_fabsf(v) < 0x1p-60f ? __builtin_copysignf(0x1p-60f, v) : v; };
-  if constexpr (kRatio) {  // the unit of the (zero) sums: the first k-block's scale (its token scales have landed)
-    const float ws0 = __int_as_float(ws_row[0]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      cur[j] = clamp_scale(ws0 * *reinterpret_cast<const float*>(s_mem + kXsOff + (wm * 64 + j * 16 + r16) * 4));
-  }
   auto k_tile = [&](int T, auto par) {
     constexpr int kP = decltype(par)::value;
     const uint8_t* buf = s_mem + kP * kBuf;
@@ -392,7 +369,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
     read_b(buf, 1, b_late);
     read_a(buf, a_frag);
     float f[4] = {1.f, 1.f, 1.f, 1.f}, xsv[4] = {1.f, 1.f, 1.f, 1.f}, wsk = 1.f;
-    if constexpr (kHasXs) {  // (the ratio form needs them for k-tile 0 only)
+    if constexpr (kHasXs) {
       wsk = __int_as_float(ws_row[T * a.ws_kb_stride]);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -405,9 +382,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
     enter_mma(IntC<kFlyX>{});
 #pragma unroll
     for (int j = 0; j < 4; ++j) f[j] = wsk * xsv[j];
-    section(0, a_frag, b_early, b_late, f, tail, [&](int n) {
-      if constexpr (kRatio) scale_block(tot[4 + (n >> 2)][n & 3], ratio[n & 3]);  // rows 64-127: from k-block T - 1's unit to T's
-    });
+    section(0, a_frag, b_early, b_late, f, tail, [&](int) {});
     leave_mma();
     apply_tail(0, f, tail);
     // ---- section Y: rows 64-127 ----------------------------------------------------------------------------
@@ -419,40 +394,11 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
       dma_x(T + 2, on2, IntC<kP>{}, IntC<0>{}, 1);
     }
     enter_mma(IntC<kFlyY>{});
-    // the next k-block's scales: its token scales landed before this section's barrier (end of load section Y)
-    float xsn[4] = {1.f, 1.f, 1.f, 1.f}, wsn = 1.f;
-    if constexpr (kRatio) {
-      wsn = __int_as_float(ws_row[(on1 ? T + 1 : T) * a.ws_kb_stride]);  // (scalar select: no read past the last k-block)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        xsn[j] = *reinterpret_cast<const float*>(s_mem + kXsOff + (1 - kP) * 1024 + (wm * 64 + j * 16 + r16) * 4);
-    }
     section(4, a_frag, b_early, b_late, f, tail, [&](int n) {
       if constexpr (!kNoDma) {
         if (n == 3) dma_x(T + 2, on2, IntC<kP>{}, IntC<1>{}, 0);
         if (n == 8) dma_x(T + 2, on2, IntC<kP>{}, IntC<1>{}, 1);
         if (n == 12) dma_xs(T + 2, on2, IntC<kP>{});
-      }
-      if constexpr (kRatio) {
-        // rows 0-63 (idle in this section): from k-block T's unit to T + 1's.  The scale reads above are back after
-        // four MFMAs; blocks 0-7 behind MFMAs 4-7 (two each), blocks 8-15 behind MFMAs 8-15.
-        if (n == 3) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            // past the last k-block the unit stays (a bit select, so that hipcc does not turn the uniform condition
-            // into a branch around the section's schedule)
-            const uint32_t keep = on1 ? 0u : 0xffffffffu;
-            const float fn = __uint_as_float((__float_as_uint(clamp_scale(wsn * xsn[j])) & ~keep) | (__float_as_uint(cur[j]) & keep));
-            ratio[j] = cur[j] * __builtin_amdgcn_rcpf(fn);
-            cur[j] = fn;
-          }
-        }
-        if (n >= 4 && n < 8) {
-          const int b0 = (n - 4) * 2;
-          scale_block(tot[b0 >> 2][b0 & 3], ratio[b0 & 3]);
-          scale_block(tot[(b0 + 1) >> 2][(b0 + 1) & 3], ratio[(b0 + 1) & 3]);
-        }
-        if (n >= 8) scale_block(tot[n >> 2][n & 3], ratio[n & 3]);
       }
     });
     leave_mma();
@@ -465,12 +411,6 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   if (wn == 0) __builtin_amdgcn_s_barrier();  // even out the barrier count
   __builtin_amdgcn_s_waitcnt(0x0F70);         // drain the (empty) tail DMAs before the workgroup's LDS is released
 
-  if constexpr (kRatio) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) tot[i][j] *= cur[j];
-  }
   if constexpr (!kHasXs) {
     const float gs = __int_as_float(ws_row[0]);  // per-tensor form: strides are zero, one scale per group
 #pragma unroll
@@ -609,16 +549,12 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a, const int* cu_tiles, int num_
   const long items = max_tiles * (n / kBN) + 8;  // + 8: the per-XCD chunks round up
   if (items > 0x7fffffffl) return HPC_ERR_UNSUPPORTED;
   dim3 grid(static_cast<unsigned>(items));
-  if (a.has_xs && a.act_out && hpc_dev_tuning_get(18) == 2)
-    gemm_fp8_p8_kernel<true, false, true, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
-  else if (a.has_xs && a.act_out)
-    gemm_fp8_p8_kernel<true, false, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  if (a.has_xs && a.act_out)
+    gemm_fp8_p8_kernel<true, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else if (a.act_out)
-    gemm_fp8_p8_kernel<false, false, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+    gemm_fp8_p8_kernel<false, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else if (a.has_xs && hpc_dev_tuning_get(18) == 1)
     gemm_fp8_p8_kernel<true, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
-  else if (a.has_xs && hpc_dev_tuning_get(18) == 2)
-    gemm_fp8_p8_kernel<true, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else if (a.has_xs)
     gemm_fp8_p8_kernel<true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else

@@ -57,6 +57,17 @@ extern "C" int hpc_get_cu_count(int device_id) {
   return cache[device_id];
 }
 
+// 0 when `stream` is not being captured into a hipGraph, else the (non-zero) unique id of the capture; < 0 on error.
+// The hosts key their per-stream decode scratch on it: a buffer first used inside a capture has its zero-fill recorded
+// as a node of THAT graph only, so it must not be reused by a later capture or by eager calls.
+extern "C" long long hpc_stream_capture_id(hipStream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  if (hipStreamGetCaptureInfo(stream, &st, &id) != hipSuccess) return -1;
+  if (st != hipStreamCaptureStatusActive) return 0;
+  return static_cast<long long>(id ? id : 1);
+}
+
 // Development tuning registers: see csrc/hpc_dev.h (internal; not in include/hpc_amd.h).
 #include <atomic>
 #include <cstdio>

@@ -51,6 +51,7 @@ _sig("hpc_assign_attention_decode_task_sync", I, IP, I, I, I, I, I, I, IP, I)
 _sig("hpc_assign_attention_decode_task_async", I, IP, IP, I, I, I, I, I, I, P)
 _sig("hpc_attention_decode_workspace_bytes", L, I, I, I, I, I)
 _sig("hpc_attention_decode_workspace_zero_bytes", L)
+_sig("hpc_stream_capture_id", ctypes.c_longlong, P)
 _sig("hpc_attention_decode_bf16_async", I, P, P, IP, P, P, P, IP, IP, I, I, I, I, I, I, I, I, I, I, I, I,
      L, L, L, L, L, L, P)
 _sig("hpc_attention_decode_fp8_async", I, P, P, IP, P, P, P, IP, IP, P, P, P, I, I, I, I, I, I, I, I, I, I, I,
@@ -67,7 +68,7 @@ _sig("hpc_fuse_moe_blockwise_async", I, P, P, P, P, P, P, P, P, P, P, P, I, I, I
 
 _sig("hpc_group_gemm_pertensor_fp8_async", I, P, P, P, P, P, P, P, I, I, I, I, I, P, P)
 _sig("hpc_act_mul_and_quant_async", I, P, P, P, P, I, I, I, P)
-_sig("hpc_scaled_fp8_quant_async", I, P, P, P, L, P)
+_sig("hpc_scaled_fp8_quant_async", I, P, P, P, L, I, P)
 _sig("hpc_moe_gather_rows_async", I, P, P, I, I, I, P, P)
 _sig("hpc_fuse_moe_pertensor_async", I, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P)
 _sig("hpc_rope_norm_store_kv_async", I, P, P, P, P, P, P, P, P, P, P, P, P, L, L, I, I, I, I, I, I, I, I, I, I, P)
@@ -114,8 +115,14 @@ import os
 _SHIM_PATH = Path(__file__).resolve().parent / "_hpc_torch.so"
 NATIVE_OPS = frozenset()
 if _SHIM_PATH.exists() and os.environ.get("HPC_AMD_PY_ENTRIES", "0") != "1":
-    torch.ops.load_library(str(_SHIM_PATH))
-    NATIVE_OPS = frozenset(torch.ops.hpc._native_ops())
+    try:
+        torch.ops.load_library(str(_SHIM_PATH))
+        NATIVE_OPS = frozenset(torch.ops.hpc._native_ops())
+    except OSError as exc:  # stale / ABI-mismatched shim (built against another torch): the Python entries serve every op
+        import warnings
+
+        warnings.warn(f"hpc: {_SHIM_PATH.name} could not be loaded ({exc}); falling back to the Python entries - "
+                      "rebuild with `python hpc-ops_amd/build.py --force`")
 
 
 class _OpLibrary:

@@ -8,14 +8,14 @@ from . import _C
 from .communicator import lookup_peers
 
 _T = _C.torch_lib
-_T.define(
-    "fuse_allreduce_rmsnorm_high_throughput(Tensor x, Tensor multicast_x, Tensor residual, Tensor weight, "
-    "Tensor signal, int rank, int world_size, int num_max_blocks, float rms_norm_eps, Tensor! output_x, "
-    "Tensor! output_multicast_x, Tensor! output_residual) -> ()"
+_T.define(  # verbatim: reference src/allreduce/entry.cc:197
+    "fuse_allreduce_rmsnorm_high_throughput(Tensor input, Tensor mc_input, Tensor in_residual, Tensor "
+    "weight, Tensor signal, int rank, int world_size, int num_max_blocks, float rms_norm_eps, Tensor "
+    "output, Tensor mc_output, Tensor out_residual) -> ()"
 )
-_T.define(
+_T.define(  # verbatim: reference src/allreduce/entry.cc:205
     "fuse_allreduce_rmsnorm_low_latency(Tensor input_x, Tensor multicast_x, Tensor data_buffer_ptrs, "
-    "Tensor! multinode_x, Tensor! buffer_flags, int world_size, int rank, bool rmsnorm_fusion, bool "
+    "Tensor! multinode_x, Tensor buffer_flags, int world_size, int rank, bool rmsnorm_fusion, bool "
     "launch_with_pdl, bool use_two_shot, Tensor! output_x, Tensor! residual_out, Tensor residual_in, "
     "Tensor weight_gamma, float rms_norm_eps) -> ()"
 )

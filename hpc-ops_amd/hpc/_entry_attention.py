@@ -6,6 +6,8 @@ allocation, stride extraction, schema block :851-873); compute is in libhpc_amd.
 """
 import ctypes
 
+from ctypes import c_void_p
+
 import torch
 
 from . import _C
@@ -122,11 +124,19 @@ def _decode_workspace(device, nbytes):
     (device, stream) instead of an allocator round trip on every step (the reference allocates per call and zeroes
     its split_flag per call, src/attention/entry.cc:660-663, 690-694).  Calls on one stream are ordered, so sharing
     the buffer between them is safe; different streams get different buffers.  While a hipGraph is being captured
-    the buffer of the capturing stream is used if there is one; otherwise it is allocated inside the capture (from
-    the graph's pool, its zero-fill becomes a node of the graph) and kept for the following calls on that stream."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    the zero-fill of a new buffer is only RECORDED (a node of that graph): such a buffer serves the calls of THAT
+    capture and nothing else - the key carries the capture id, the entry of an earlier capture is dropped (its memory
+    stays with its graph's pool), and a buffer cached by eager calls is not used inside a capture either, so every
+    graph owns its buffer and its zero node and two graphs never share one."""
+    stream = torch.cuda.current_stream(device).cuda_stream
+    cap = int(_C.lib.hpc_stream_capture_id(c_void_p(stream)))
+    _C.require(cap >= 0, "hipStreamGetCaptureInfo failed")
+    key = (device.index, stream, cap)
     ws = _DECODE_WS.get(key)
     if ws is None or ws.numel() < nbytes:
+        if cap:
+            for old in [k for k in _DECODE_WS if k[:2] == key[:2] and k[2] not in (0, cap)]:
+                del _DECODE_WS[old]
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         ws[: _C.lib.hpc_attention_decode_workspace_zero_bytes()].zero_()
         _DECODE_WS[key] = ws
@@ -134,8 +144,11 @@ def _decode_workspace(device, nbytes):
 
 
 def release_decode_workspaces():
-    """Drop the cached decode scratch buffers (e.g. after the streams / graphs that used them are gone)."""
+    """Drop the cached decode scratch buffers (e.g. after the streams / graphs that used them are gone) - the Python
+    entries' and, when the C++ shim serves the decode ops, its cache too."""
     _DECODE_WS.clear()
+    if "attention_decode_fp8" in _C.NATIVE_OPS:
+        torch.ops.hpc._release_decode_workspaces()
 
 
 def _decode_common_checks(q, kcache, vcache, block_ids, num_seq_kvcache, mtp, max_mtp):
@@ -262,10 +275,10 @@ _T.impl("attention_decode_fp8", _attention_decode_fp8_entry, "CUDA")
 
 
 # ---------------------------------------------------------------------------- fp8 paged prefill
-_T.define(
-    "attention_with_kvcache_prefill_fp8(Tensor q, Tensor kcache, Tensor vcache, Tensor qscale, Tensor kscale, "
-    "Tensor vscale, Tensor cu_seqlens_q, Tensor block_ids, Tensor seqlens_kvcache, int max_seqlens_q, "
-    "int quant_type, Tensor? output) -> Tensor"
+_T.define(  # verbatim: reference src/attention/entry.cc:835
+    "attention_with_kvcache_prefill_fp8(Tensor q, Tensor kcache, Tensor vcache,Tensor qscale, Tensor "
+    "kscale, Tensor vscale, Tensor cu_seqlens_q,Tensor block_ids, Tensor num_seq_kvcache, int "
+    "max_seqlens_q, int quant_type,Tensor? output) -> (Tensor)"
 )
 
 
@@ -350,10 +363,10 @@ def _attention_prefill_fp8_entry(q, kcache, vcache, qscale, kscale, vscale, cu_s
 _T.impl("attention_with_kvcache_prefill_fp8", _attention_prefill_fp8_entry, "CUDA")
 
 
-_T.define(
-    "attention_with_kvcache_blocksparse_prefill_fp8(Tensor q, Tensor kcache, Tensor vcache, Tensor qscale, "
-    "Tensor kscale, Tensor vscale, Tensor cu_seqlens_q, Tensor block_ids, Tensor seqlens_kvcache, "
-    "int max_seqlens_q, int quant_type, Tensor? block_mask, Tensor? output) -> Tensor"
+_T.define(  # verbatim: reference src/attention/entry.cc:843
+    "attention_with_kvcache_blocksparse_prefill_fp8(Tensor q, Tensor kcache, Tensor vcache,Tensor qscale,"
+    " Tensor kscale, Tensor vscale, Tensor cu_seqlens_q,Tensor block_ids, Tensor num_seq_kvcache, int "
+    "max_seqlens_q, int quant_type,Tensor? block_mask, Tensor? output) -> (Tensor)"
 )
 
 

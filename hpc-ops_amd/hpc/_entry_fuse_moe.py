@@ -23,10 +23,10 @@ _T.define(
     "topk_scale, Tensor ? shared_output, int rank_ep, int num_expert_total, Tensor ? output) -> (Tensor)"
 )
 _T.define("reduce(Tensor x, Tensor topk_pos, Tensor topk_scale, Tensor ? shared_output) -> (Tensor)")
-_T.define(
-    "group_gemm_blockwise_fp8(Tensor x, Tensor weight, Tensor seqlens, Tensor cu_seqlens, Tensor "
-    "x_scale, Tensor w_scale, int num_seq_per_group_avg, Tensor? output, Tensor? tma_desc, "
-    "Tensor? task_map_workspace) -> (Tensor)"
+_T.define(  # verbatim: reference src/group_gemm/entry.cc:239
+    "group_gemm_blockwise_fp8(Tensor x, Tensor weight, Tensor seqlens, Tensor cu_seqlens, Tensor xscale, "
+    "Tensor wscale,int num_seq_per_group_avg, Tensor? output, Tensor? tma_desc, Tensor? "
+    "task_map_workspace) -> (Tensor)"
 )
 
 
@@ -203,8 +203,12 @@ _T.define(
     "group_gemm_pertensor_fp8(Tensor x, Tensor weight, Tensor seqlens, Tensor cu_seqlens, Tensor y_scale, "
     "int num_seq_per_group_avg, Tensor? output, Tensor? tma_desc, Tensor? task_map_workspace) -> (Tensor)"
 )
-_T.define("act_mul_and_quant(Tensor gate_up, Tensor scale, bool use_bf16_mul, Tensor? output) -> (Tensor)")
-_T.define("scaled_fp8_quant(Tensor input, Tensor? scale, Tensor? output) -> (Tensor)")
+_T.define(  # verbatim: reference src/activation/entry.cc:208
+    "act_mul_and_quant(Tensor input, Tensor scale, bool use_bf16_mul, Tensor? output) -> (Tensor)"
+)
+_T.define(  # verbatim: reference src/activation/entry.cc:223
+    "scaled_fp8_quant(Tensor input, Tensor? scale, Tensor? output) -> (Tensor, Tensor)"
+)
 
 
 def _fuse_moe_entry(x, gate_up_weight, down_weight, gate_up_scale, down_scale, act_and_mul_scale,
@@ -334,16 +338,29 @@ def _act_mul_and_quant_entry(gate_up, scale, use_bf16_mul, output):
 _T.impl("act_mul_and_quant", _act_mul_and_quant_entry, "CUDA")
 
 
+_QUANT_IN = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+
+
 def _scaled_fp8_quant_entry(input, scale, output):
-    _cuda_contig(input, "input")
-    _C.require(input.dtype == torch.bfloat16, "input must be bfloat16")
-    if scale is None:
-        scale = torch.ones(1, dtype=torch.float32, device=input.device)
-    out = output if output is not None else torch.empty(input.shape, dtype=_F8, device=input.device)
+    """reference scaled_fp8_quant_entry, src/activation/entry.cc:158-200: out = e4m3(input * (1 / scale[0])),
+    returns (output, scale)."""
+    _C.require(input.is_cuda, "input must be a CUDA tensor")
+    _C.require(input.is_contiguous(), "input must be contiguous")
+    _C.require(input.numel() > 0, "input must be non-empty")
+    _C.require(input.dtype in _QUANT_IN, "input dtype must be float32, float16, or bfloat16")
+    out = output if output is not None else torch.empty_like(input, dtype=_F8)
+    _C.require(out.is_cuda, "output must be a CUDA tensor")
+    _C.require(out.is_contiguous(), "output must be contiguous")
+    _C.require(out.shape == input.shape, "output shape must match input shape")
+    _C.require(out.dtype == _F8, "output dtype must be float8_e4m3fn")
+    _C.require(scale is not None, "scale is required for scaled_fp8_quant")
+    _C.require(scale.is_cuda, "scale must be a CUDA tensor")
+    _C.require(scale.dtype == torch.float32, "scale dtype must be float32")
+    _C.require(scale.numel() == 1, "scale must contain one element")
     rc = _C.lib.hpc_scaled_fp8_quant_async(_C.ptr(out), _C.ptr(input), _C.ptr(scale), input.numel(),
-                                           _C.stream_of(input))
+                                           _QUANT_IN[input.dtype], _C.stream_of(input))
     _C.check(rc, "scaled_fp8_quant_async")
-    return out
+    return out, scale
 
 
 _T.impl("scaled_fp8_quant", _scaled_fp8_quant_entry, "CUDA")
@@ -418,8 +435,10 @@ _T.impl("group_gemm_fp8_scatter_cp_async", _group_gemm_fp8_scatter_cp_async_entr
 
 # ---- masked (DeepEP-layout) activation variants (reference src/activation/entry.cc:50-110) ---------------------
 _T.define("masked_act_mul_and_quant(Tensor input, Tensor scale, Tensor num_per_expert, Tensor? output) -> (Tensor)")
-_T.define("masked_act_mul_and_blockwise_quant(Tensor input, Tensor num_per_expert, Tensor? output, "
-          "Tensor? output_scale) -> (Tensor, Tensor)")
+_T.define(  # verbatim: reference src/activation/entry.cc:217
+    "masked_act_mul_and_blockwise_quant(Tensor input, Tensor num_per_expert, Tensor? output, Tensor? "
+    "output_scale) -> (Tensor output, Tensor output_scale)"
+)
 
 
 def _masked_common(input, num_per_expert):

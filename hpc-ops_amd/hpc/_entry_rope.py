@@ -12,14 +12,12 @@ _T.define(
     "Tensor? q_norm_weight, Tensor? k_norm_weight, "
     "Tensor? out_q=None, Tensor? out_k=None, Tensor? out_v=None, int qk_norm_policy=0) -> Tensor"
 )
-_T.define(
-    "rope_norm_store_kv_fp8(Tensor! kcache, Tensor! vcache, Tensor qkv, "
-    "Tensor cos_sin, Tensor num_seqlen_per_req, Tensor q_index, Tensor kvcache_indices, "
-    "bool is_prefill, Tensor k_scale, Tensor v_scale, "
-    "int quant_policy, int max_seqlens, float? upper_max, Tensor? q_scale_inv, "
-    "Tensor? q_norm_weight, Tensor? k_norm_weight, "
-    "Tensor? out_q=None, Tensor? out_k=None, Tensor? out_v=None, int qk_norm_policy=0) -> "
-    "(Tensor, Tensor?, Tensor)"
+_T.define(  # verbatim: reference src/rope/entry.cc:231
+    "rope_norm_store_kv_fp8(Tensor! kcache, Tensor! vcache, Tensor qkv, Tensor cos_sin, Tensor "
+    "num_seqlen_per_req, Tensor q_index, Tensor kvcache_indices, bool is_prefill, Tensor k_scale, Tensor "
+    "v_scale, int quant_policy, int max_seqlens, float? upper_max, Tensor? q_scale_inv, Tensor? "
+    "q_norm_weight, Tensor? k_norm_weight, Tensor? out_q=None, Tensor? out_k=None, Tensor? out_v=None, "
+    "int qk_norm_policy=0) -> (Tensor, Tensor, Tensor)"
 )
 
 

@@ -15,8 +15,10 @@ def act_mul_and_quant(gate_up: Tensor, scale: Tensor, use_bf16_mul: bool = True,
     return torch.ops.hpc.act_mul_and_quant(gate_up, scale, use_bf16_mul, output)
 
 
-def scaled_fp8_quant(input: Tensor, scale: Tensor = None, output: Tensor = None) -> Tensor:
-    """e4m3(input * scale[0]) for a bf16 tensor (scale defaults to 1)."""
+def scaled_fp8_quant(input: Tensor, scale: Tensor, output: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """Quantise a float32 / float16 / bfloat16 tensor to e4m3 with one per-tensor scale: output = e4m3(input *
+    (1 / scale[0])), saturating; returns (output, scale) like the reference (hpc/act.py:108-114,
+    src/activation/activation.cu:461-505)."""
     return torch.ops.hpc.scaled_fp8_quant(input, scale, output)
 
 
@@ -49,3 +51,17 @@ def _masked_act_mul_and_blockwise_quant_fake(input, num_per_expert, output=None,
     osc = output_scale if output_scale is not None else torch.empty((n, c // 128), dtype=torch.float32,
                                                                     device=input.device)
     return out, osc
+
+
+@torch.library.register_fake("hpc::act_mul_and_quant")
+def _act_mul_and_quant_fake(input, scale, use_bf16_mul, output):
+    if output is not None:
+        return output
+    return torch.empty((input.shape[0], input.shape[1] // 2), dtype=torch.float8_e4m3fn, device=input.device)
+
+
+@torch.library.register_fake("hpc::scaled_fp8_quant")
+def _scaled_fp8_quant_fake(input, scale, output):
+    out = output if output is not None else torch.empty_like(input, dtype=torch.float8_e4m3fn)
+    sc = scale if scale is not None else torch.empty((1,), dtype=torch.float32, device=input.device)
+    return out, sc

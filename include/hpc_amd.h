@@ -99,6 +99,10 @@ int hpc_assign_attention_decode_task_async(int* task_map, const int* num_seq_kvc
 int64_t hpc_attention_decode_workspace_bytes(int num_bins, int num_batch, int num_head_kv,
                                              int num_seq_q, int heads_per_group);
 int64_t hpc_attention_decode_workspace_zero_bytes(void);
+/* 0 when `stream` is not being captured into a hipGraph, else the unique non-zero id of the capture (< 0: error).  A
+ * host that caches the decode workspace per stream must not carry a buffer whose zero-fill was only RECORDED in one
+ * capture over to another capture or to eager calls: key the cache on (stream, capture id). */
+long long hpc_stream_capture_id(hpc_stream_t stream);
 int hpc_attention_decode_bf16_async(void* y_ptr, void* workspace, const int* task_map_ptr,
                                     const void* q_ptr, const void* kcache_ptr,
                                     const void* vcache_ptr, const int* block_ids_ptr,
@@ -120,10 +124,11 @@ int hpc_attention_decode_bf16_async(void* y_ptr, void* workspace, const int* tas
  * num_seq_q <= 4.  block_size 16/32/64 for quant_type 1, 32/64 for quant_type 0.
  * num_seq_kvcache_ptr (device int32 [num_batch]) / new_kv_included as in the reference launcher
  * (decode.h:27-35): with them, NHD pages (adjacent kv heads 128 bytes apart), <= 16 q rows per kv head and
- * either an even head count or a single kv head take the second-generation kernel (attention_decode_v2.hip:
- * 256 contiguous bytes per row and load - two heads of a token, or two tokens of the single head - deep
- * prefetch, the schedule planned in-kernel from the lengths in the closed form of the scheduler above: the
- * task map is validated but its bins, min_process_len and split decisions do not apply on that path);
+ * an even kv head count take the second-generation kernel (attention_decode_v2.hip: 256 contiguous bytes per
+ * row and load - two heads of a token - deep prefetch, the schedule planned in-kernel from the lengths in the
+ * closed form of the scheduler above: the task map is validated but its bins, min_process_len and split
+ * decisions do not apply on that path); an odd kv head count - incl. a single kv head - HND pages and
+ * per-token K scales run the first-generation kernel from the task map;
  * num_seq_kvcache_ptr may be NULL, then the task map drives the first-generation kernel as for bf16. */
 int hpc_attention_decode_fp8_async(void* y_ptr, void* workspace, const int* task_map_ptr,
                                    const void* q_ptr, const void* kcache_ptr,
@@ -224,8 +229,11 @@ int hpc_group_gemm_pertensor_fp8_async(void* y_ptr, const void* x_ptr, const voi
 int hpc_act_mul_and_quant_async(void* out_ptr, const void* gate_up_ptr, const void* scale_ptr,
                                 const void* num_rows_ptr, int max_rows, int intermediate_size,
                                 int use_bf16_mul, hpc_stream_t stream);
+/* out[i] = e4m3(float(in[i]) * (1.0f / scale[0])), saturating, any numel > 0 (reference scaled_fp8_quant_async,
+ * src/activation/activation.h + activation.cu:461-505, entry src/activation/entry.cc:158-200).  The reference
+ * overloads on the input type; here in_dtype says it: 0 = bf16, 1 = fp16, 2 = fp32. */
 int hpc_scaled_fp8_quant_async(void* out_ptr, const void* in_ptr, const void* scale_ptr, int64_t numel,
-                               hpc_stream_t stream);
+                               int in_dtype, hpc_stream_t stream);
 int hpc_moe_gather_rows_async(const void* x, const void* topk_pos, int num_tokens, int num_topk,
                               int hidden, void* x_gathered, hpc_stream_t stream);
 int hpc_fuse_moe_pertensor_async(void* y_ptr, void* workspace, const void* x_ptr,

@@ -56,6 +56,39 @@ def group_gemm_blockwise(x, w, seqlens, cu_seqlens, xscale, wscale):
     return y
 
 
+def group_gemm_blockwise_kernel_arith(x, w, seqlens, cu_seqlens, xscale, wscale):
+    """The same GEMM in the arithmetic of the reference KERNEL instead of the reference test's eager model
+    (src/group_gemm/kernels.cuh:808-834): per 128-wide k block the fp32 partial of the block (WGMMA from a zeroed
+    accumulator), `yscale = xs[m, kb] * ws[n / 128, kb]` (one fp32 multiply), then `tDr = tCr * yscale + tDr` - a
+    fused multiply-add, ONE rounding per k block - where the eager model (`group_gemm_blockwise` above =
+    tests/test_fuse_moe_blockwise.py:115-128) rounds `(part * xs) * ws` twice and adds with a third rounding.  The
+    two differ in the last fp32 bit of some sums, which moves a bf16 output by one ulp when the sum sits on a bf16
+    tie (and, in the fused MoE, one e4m3 code of the quantised activation when that bf16 value sits on an e4m3 tie).
+    The FMA is emulated in float64: the 48-bit product is exact, the sum is rounded once to 53 bits and once more to
+    fp32 - a double rounding that differs from a true FMA only when the 53-bit sum lands exactly on an fp32 tie (odds
+    2^-29 per operation, and visible in bf16 only on a further 2^-8 coincidence).  HIP's blockwise GEMMs use this
+    arithmetic; tests compare them BIT FOR BIT on inputs whose block partials are exact in fp32
+    (tests/test_fuse_moe_blockwise.py::test_group_gemm_blockwise_is_the_reference_kernel_arithmetic)."""
+    m, k = x.shape
+    num_group, n, _ = w.shape
+    kb = k // 128
+    y = torch.zeros((m, n), dtype=torch.bfloat16)
+    for i in range(num_group):
+        s, cnt = int(cu_seqlens[i]), int(seqlens[i])
+        if cnt == 0:
+            continue
+        xg = x[s : s + cnt].to(torch.float64).reshape(cnt, kb, 128)
+        wg = w[i].to(torch.float64).reshape(n, kb, 128)
+        part = torch.einsum("mbk,nbk->mnb", xg, wg).float()                     # the block partials, rounded once
+        ws = wscale[i][:, :kb].repeat_interleave(128, dim=0)                     # [n, kb]
+        out = torch.zeros((cnt, n), dtype=torch.float32)
+        for b in range(kb):
+            ys = xscale[s : s + cnt, b].unsqueeze(1) * ws[:, b].unsqueeze(0)   # fp32 multiply (kernels.cuh:811)
+            out = (part[:, :, b].double() * ys.double() + out.double()).float()  # FFMA (kernels.cuh:834)
+        y[s : s + cnt] = out.to(torch.bfloat16)
+    return y
+
+
 def act_mul_and_blockwise_quant(gate_up_out):
     gate, up = torch.chunk(gate_up_out.float(), 2, dim=1)
     out = gate / (1 + (-gate).exp()) * up
@@ -87,12 +120,15 @@ def reduce(x_bf16, topk_pos, topk_scale, shared_output=None):
 
 def fuse_moe_blockwise_fp8(x, x_scale, gate_up_weight, gate_up_weight_scale, down_weight,
                            down_weight_scale, topk_ids, topk_scale, rank_ep, num_expert,
-                           shared_output=None, return_intermediates=False):
+                           shared_output=None, return_intermediates=False, kernel_arith=False):
+    """kernel_arith: both GEMMs in the reference kernel's arithmetic (group_gemm_blockwise_kernel_arith) instead of
+    the reference test's eager model - used to tell what a literal-bar miss of an implementation is made of."""
     num_expert_local = gate_up_weight.size(0)
     gi, gis, topk_pos, seqlens, cu = gather_expert_inputs(x, x_scale, topk_ids, num_expert_local, rank_ep)
-    g = group_gemm_blockwise(gi, gate_up_weight, seqlens, cu, gis, gate_up_weight_scale)
+    gemm = group_gemm_blockwise_kernel_arith if kernel_arith else group_gemm_blockwise
+    g = gemm(gi, gate_up_weight, seqlens, cu, gis, gate_up_weight_scale)
     di, dis = act_mul_and_blockwise_quant(g)
-    d = group_gemm_blockwise(di, down_weight, seqlens, cu, dis, down_weight_scale)
+    d = gemm(di, down_weight, seqlens, cu, dis, down_weight_scale)
     y = reduce(d, topk_pos, topk_scale, shared_output)
     if return_intermediates:
         return y, dict(topk_pos=topk_pos, seqlens=seqlens, cu_seqlens=cu, gate_up=g, down_in=di,
@@ -122,6 +158,20 @@ def act_mul_and_quant(gate_up, scale, use_bf16_mul=True):
     else:
         out = silu * up * scale
     return out.to(torch.float8_e4m3fn)
+
+
+def scaled_fp8_quant(x, scale):
+    """reference scaled_fp8_quant_kernel, src/activation/activation.cu:461-505 (entry src/activation/entry.cc:158-200):
+    inv_scale = 1.0f / scale[0] once, every element of the fp32 / fp16 / bf16 input is MULTIPLIED by it in fp32 and
+    converted to e4m3 with saturation (__nv_fp8_e4m3(float) is a satfinite conversion; torch's cast turns values
+    beyond the format into NaN, so the clamp is explicit here); returns (output, scale) like the entry.
+    Pinned in tests/golden/make_golden.py against the reference benchmark's eager form `scaled_fp8_quant_local`
+    (benchmark/fused_moe/backends/base.py:64-67, `(x.float() / scale).to(fp8)`): bit-equal for power-of-two scales,
+    and for a general scale equal except where x / s and x * (1 / s) round to different sides of an e4m3 tie."""
+    inv = torch.ones((), dtype=torch.float32) / scale.detach().float().reshape(-1)[0]
+    y = x.float() * inv
+    y = torch.where(torch.isnan(y), y, y.clamp(-448.0, 448.0))
+    return y.to(torch.float8_e4m3fn), scale
 
 
 def fuse_moe_pertensor_fp8(x, gate_up_weight, down_weight, gate_up_scale, down_scale, act_and_mul_scale,

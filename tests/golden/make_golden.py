@@ -247,6 +247,28 @@ def golden_fp():
     assert torch.equal(t_ref, osamp.ref_temperature_sample(logits, temp, gum))
     assert torch.equal(t_ref_m, osamp.ref_temperature_sample(logits, temp, gum, draft))
     st.update(samp_temp=temp.numpy(), samp_draft=draft.numpy(), samp_ttok=t_ref.numpy(), samp_ttok_mask=t_ref_m.numpy())
+    # ---- scaled_fp8_quant (kernel src/activation/activation.cu:461-505; the reference's eager statement of it is
+    #      benchmark/fused_moe/backends/base.py:64-67 scaled_fp8_quant_local, the fallback its benchmark driver uses) ----
+    r = load("benchmark/fused_moe/backends/base.py", ["scaled_fp8_quant_local"], extra={"DTYPE_FP8": f8})
+    torch.manual_seed(7)
+    for tag, dt in (("bf16", torch.bfloat16), ("f16", torch.float16), ("f32", torch.float32)):
+        # numel = 4551: not a multiple of 8 (ragged tail of the kernel).  |x / s| stays inside the e4m3 range: beyond it
+        # the eager form yields NaN (torch's cast does not saturate) where the kernel's satfinite conversion yields
+        # +-448 - that difference is the kernel's documented behaviour, tested against the oracle on the GPU.
+        x = (torch.randn(37, 123) * 1.5).clamp(-4.4, 4.4).to(dt)
+        for si, sval in enumerate((1e-2, 0.25)):     # 1e-2 = the benchmark driver's A_SCALE_VALUE (base.py:174)
+            sc = torch.full((), sval, dtype=torch.float32)
+            ref_q, ref_s = r["scaled_fp8_quant_local"](x, sc)
+            my_q, my_s = omoe.scaled_fp8_quant(x, sc)
+            assert my_s is sc and ref_s is sc
+            if sval == 0.25:                         # power of two: x / s == x * (1 / s) exactly
+                assert torch.equal(ref_q.view(torch.uint8), my_q.view(torch.uint8)), tag
+            else:                                    # 1 / 0.01f is inexact: rare e4m3 ties may flip by one code
+                a, b = ref_q.view(torch.uint8).int(), my_q.view(torch.uint8).int()
+                assert (a - b).abs().max() <= 1 and (a != b).float().mean() < 2e-3, (tag, (a != b).sum())
+            view = x.view(torch.int16) if dt != torch.float32 else x
+            st[f"sfq_x_{tag}"] = view.numpy()
+            st[f"sfq_q_{tag}_{si}"] = ref_q.view(torch.uint8).numpy()
     np.savez_compressed(ROOT / "tests" / "golden" / "fp_golden.npz", **st)
     print("wrote fp_golden.npz:", len(st), "arrays")
 

@@ -86,14 +86,16 @@ def _run(num_batch, num_seq_q, lens_before, block_size, kv_head_q_head, k_per_to
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("num_batch", [1, 16, 50])
-@pytest.mark.parametrize("num_seq_q", [1, 2, 4])
+@pytest.mark.parametrize("num_batch", [1, 16, 50])  # (200: test_attn_fp8_reference_grid_batch_200)
+@pytest.mark.parametrize("num_seq_q", [1, 2, 3, 4])
+@pytest.mark.parametrize("max_seq_kv", [1024, 4096])
 @pytest.mark.parametrize("kv_head_q_head", [(1, 8), (4, 32)])
 @pytest.mark.parametrize("use_dynamic_sched", [True, False])
 @pytest.mark.parametrize("kvcache_shape", ["NHD", "HND"])
-def test_attn_fp8_kvpertensor(num_batch, num_seq_q, kv_head_q_head, use_dynamic_sched, kvcache_shape):
+def test_attn_fp8_kvpertensor(num_batch, num_seq_q, max_seq_kv, kv_head_q_head, use_dynamic_sched, kvcache_shape):
+    """The reference grid (tests/test_attention_decode_qpertoken_perhead_kvpertensor_fp8.py:263-273): num_seq_q
+    1 ... 4 x max_seq_kv 1024 / 4096 x 1 / 8 and 4 / 32 heads x dynamic / static schedule x NHD / HND pages."""
     torch.manual_seed(41)
-    max_seq_kv = 1024 if num_batch >= 16 else 4096
     lens = torch.randint(1, max_seq_kv, (num_batch,), dtype=torch.int32)
     _run(num_batch, num_seq_q, lens, 64, kv_head_q_head, False, True, use_dynamic_sched,
          kvcache_shape, 0.2)
@@ -253,3 +255,43 @@ def test_attn_fp8_uneven_ranges(keys, num_batch, hi):
     finally:
         for k in keys:
             hpc._C.lib.hpc_dev_tuning_set(k, 0)
+
+
+@pytest.mark.gpu
+def test_attn_fp8_two_graphs_captured_before_any_replay():
+    """The usual serving pattern: one hipGraph per batch size, all captured first, replayed later in any order.  The
+    scratch of a decode call starts with arrival counters that must be zero on first use; a buffer first used inside a
+    capture has its zero-fill only RECORDED in that graph, so every capture must own its buffer (and its zero node):
+    the second graph, replayed before the first one ever ran, must not find un-zeroed counters."""
+    import hpc
+    from oracle import attention as oattn
+
+    hpc._entry_attention.release_decode_workspaces()
+    cases = []
+    for num_batch, hi, seed in ((6, 30000, 1), (9, 20000, 2)):
+        torch.manual_seed(seed)
+        lens = _mixed_lens(num_batch, seed, hi)
+        lens[0] = hi  # a long request among short ones: split over many workgroups, merged by the last arriver
+        q8, q_scale, kv, block_ids, nblocks = _case(num_batch, 1, lens, 64, (4, 32), False)
+        kv8 = kv.to(torch.float8_e4m3fn)
+        ks, vs = torch.rand(1) + 0.5, torch.rand(1) + 0.5
+        gt = oattn.ref_attn_fp8(q8, kv8, block_ids, nblocks, 1, lens, q_scale, ks, vs, False)
+        kvd = kv8.cuda()
+        dev = dict(q=q8.cuda(), k=kvd[:, 0], v=kvd[:, 1], bid=block_ids.cuda(), lens=(lens + 1).cuda(), qs=q_scale.cuda(),
+                   ks=ks.cuda(), vs=vs.cuda(), out=torch.zeros(num_batch, 32, 128, dtype=torch.bfloat16, device="cuda"))
+        cases.append((dev, gt))
+    graphs = []
+    for dev, _ in cases:  # capture only: nothing runs
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            hpc.attention_decode_fp8(dev["q"], dev["k"], dev["v"], dev["bid"], dev["lens"], dev["qs"], dev["ks"], dev["vs"],
+                                     mtp=0, new_kv_included=True,
+                                     quant_type=hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, splitk=True,
+                                     output=dev["out"])
+        graphs.append(g)
+    for i in (1, 0, 1, 0):  # the graph captured second runs first
+        cases[i][0]["out"].zero_()
+        graphs[i].replay()
+        torch.cuda.synchronize()
+        assert allclose(cases[i][1], cases[i][0]["out"].cpu(), atol=0.2), i
+    hpc._entry_attention.release_decode_workspaces()

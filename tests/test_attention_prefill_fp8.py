@@ -138,7 +138,7 @@ def block_sparse_mask(batch, heads, nrow, ncol, skip_ratio, gen):
 @pytest.mark.parametrize("kv_layout", ["nhd", "hnd"])
 @pytest.mark.parametrize("num_seq", [1024, 2048])
 @pytest.mark.parametrize("skip_ratio", [0.0, 0.5, 0.9])
-@pytest.mark.parametrize("hq,hkv", [(4, 1), (16, 2)])
+@pytest.mark.parametrize("hq,hkv", [(4, 1), (16, 2), (32, 2)])  # (32, 2): 16 q heads per kv head - mask bits 8 ... 15
 def test_blocksparse_prefill_fp8(kv_layout, num_seq, skip_ratio, hq, hkv):
     import hpc
 

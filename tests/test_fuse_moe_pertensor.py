@@ -134,8 +134,67 @@ def test_act_mul_and_quant(use_bf16_mul):
     assert allclose(gt.float(), out.cpu().float(), rtol=0.13, atol=2e-3)
     agree = (gt.view(torch.uint8) == out.cpu().view(torch.uint8)).float().mean().item()
     assert agree > 0.995, agree
-    q = hpc.scaled_fp8_quant(gate_up.cuda(), scale.cuda())
-    assert torch.equal(q.cpu().view(torch.uint8), (gate_up.float() * scale).to(F8).view(torch.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("shape", [(513, 4608), (37, 123), (1, 1), (7,), (3, 5, 64)])
+def test_scaled_fp8_quant_vs_oracle(dtype, shape):
+    """hpc.scaled_fp8_quant against oracle/fuse_moe.py::scaled_fp8_quant (the restatement of the reference kernel,
+    src/activation/activation.cu:461-505, pinned in tests/golden/make_golden.py): output = e4m3(input * (1 / scale)),
+    saturating, fp32 / fp16 / bf16 inputs, any numel (vector body + ragged tail), returns (output, scale)."""
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(3)
+    x = (torch.randn(shape) * 3.0).to(dtype)          # |x / 1e-2| reaches ~1000: the saturating conversion is covered
+    if x.numel() > 16:
+        x.view(-1)[5] = float("nan")
+        x.view(-1)[6] = -0.0
+    for sc in (torch.full((), 1e-2), torch.tensor([0.37]), torch.tensor([[3.0]])):
+        want, _ = omoe.scaled_fp8_quant(x, sc)
+        scd = sc.cuda()
+        got, got_scale = hpc.scaled_fp8_quant(x.cuda(), scd)
+        assert got_scale is scd or got_scale.data_ptr() == scd.data_ptr()      # the entry hands the scale tensor back
+        assert got.shape == x.shape and got.dtype == F8
+        assert torch.equal(got.cpu().view(torch.uint8), want.view(torch.uint8))
+    # caller-provided output is used and returned
+    out = torch.zeros(shape, dtype=F8, device="cuda")
+    got, _ = hpc.scaled_fp8_quant(x.cuda(), torch.tensor([0.5]).cuda(), out)
+    assert got.data_ptr() == out.data_ptr()
+    assert torch.equal(out.cpu().view(torch.uint8), omoe.scaled_fp8_quant(x, torch.tensor([0.5]))[0].view(torch.uint8))
+
+
+@pytest.mark.gpu
+def test_scaled_fp8_quant_reference_benchmark_call_and_errors():
+    """The reference benchmark driver's call (benchmark/fused_moe/backends/hpcops.py:29,49-51): fp16 activations, a
+    0-dim scale of 1e-2, `torch.ops.hpc.scaled_fp8_quant(x, scale, None)` unpacked into two values; and the entry's
+    checks (src/activation/entry.cc:163-186)."""
+    import hpc  # noqa: F401
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(0)
+    a_half = torch.randn(64, 4096, dtype=torch.half)
+    a_scale = torch.full((), 1e-2, dtype=torch.float32)
+    x_fp8, _ = torch.ops.hpc.scaled_fp8_quant(a_half.cuda(), a_scale.cuda(), None)
+    assert torch.equal(x_fp8.cpu().view(torch.uint8), omoe.scaled_fp8_quant(a_half, a_scale)[0].view(torch.uint8))
+    # = 100 * a (not 0.01 * a): dequantised values are near a / scale
+    assert allclose(x_fp8.cpu().float(), (a_half.float() * 100).clamp(-448, 448), rtol=0.07, atol=0.02)
+    xc, sc = a_half.cuda(), a_scale.cuda()
+    with pytest.raises(RuntimeError, match="scale is required"):
+        torch.ops.hpc.scaled_fp8_quant(xc, None, None)
+    with pytest.raises(RuntimeError, match="float32, float16, or bfloat16"):
+        torch.ops.hpc.scaled_fp8_quant(xc.to(torch.float64), sc, None)
+    with pytest.raises(RuntimeError, match="non-empty"):
+        torch.ops.hpc.scaled_fp8_quant(xc[:0], sc, None)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        torch.ops.hpc.scaled_fp8_quant(xc.t(), sc, None)
+    with pytest.raises(RuntimeError, match="one element"):
+        torch.ops.hpc.scaled_fp8_quant(xc, torch.ones(2, device="cuda"), None)
+    with pytest.raises(RuntimeError, match="scale dtype must be float32"):
+        torch.ops.hpc.scaled_fp8_quant(xc, sc.half(), None)
+    with pytest.raises(RuntimeError, match="output shape must match"):
+        torch.ops.hpc.scaled_fp8_quant(xc, sc, torch.empty(3, dtype=F8, device="cuda"))
 
 
 @pytest.mark.gpu

@@ -48,6 +48,41 @@ def test_oracle_allreduce_matches_reference_output():
     assert torch.equal(rr, bf("ar_out_res")) and torch.equal(ro, bf("ar_out"))
 
 
+_SFQ = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
+
+
+def _sfq_x(tag):
+    x = t(f"sfq_x_{tag}")
+    return x if tag == "f32" else x.view(_SFQ[tag])
+
+
+@pytest.mark.parametrize("tag", sorted(_SFQ))
+def test_oracle_scaled_fp8_quant_matches_reference_output(tag):
+    """Stored outputs = the reference's eager form (benchmark/fused_moe/backends/base.py:64-67) on in-range inputs;
+    scale 0.25 is exact in both forms, at 1e-2 an e4m3 tie may fall on the other side (<= one code, < 0.2 %)."""
+    from oracle import fuse_moe as omoe
+
+    x = _sfq_x(tag)
+    q1, _ = omoe.scaled_fp8_quant(x, torch.full((), 0.25))
+    assert torch.equal(q1.view(torch.uint8), t(f"sfq_q_{tag}_1"))
+    q0, _ = omoe.scaled_fp8_quant(x, torch.full((), 1e-2))
+    d = (q0.view(torch.uint8).int() - t(f"sfq_q_{tag}_0").int()).abs()
+    assert d.max() <= 1 and (d != 0).float().mean() < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", sorted(_SFQ))
+def test_hip_scaled_fp8_quant_matches_reference_output(tag):
+    import hpc
+
+    x = _sfq_x(tag).cuda()
+    q1, s1 = hpc.scaled_fp8_quant(x, torch.full((), 0.25, device="cuda"))
+    assert torch.equal(q1.cpu().view(torch.uint8), t(f"sfq_q_{tag}_1"))
+    q0, _ = hpc.scaled_fp8_quant(x, torch.full((), 1e-2, device="cuda"))
+    d = (q0.cpu().view(torch.uint8).int() - t(f"sfq_q_{tag}_0").int()).abs()
+    assert d.max() <= 1 and (d != 0).float().mean() < 2e-3
+
+
 @pytest.mark.parametrize("tag", ["a", "b"])
 def test_oracle_attention_bf16_matches_reference_output(tag):
     from oracle import attention as oattn
