@@ -5,7 +5,14 @@ CUTLASS, no nvcc and no CMake here: every csrc/*.hip is compiled straight to an 
 for --offload-arch=gfx950 and linked into hpc/libhpc_amd.so, which the Python package loads with
 ctypes.  hipcc cross-compiles without a GPU, so this runs in the CPU-only build container.
 
-    python hpc-ops_amd/build.py [-j N] [--force]
+Two libraries come out of the same sources:
+  * hpc/libhpc_amd.so      - the PRODUCT: no development registers (csrc/hpc_dev.h: hpc_dev_tuning_get is the
+                             constant 0, every A/B variant and timing-only kernel folds away), no HPC_AMD_TUNING;
+  * hpc/libhpc_amd_dev.so  - the DEVELOPMENT build (-DHPC_DEV): registers + development entry points, for tools/ and
+                             the tests marked `dev` (`HPC_AMD_DEV=1` makes the Python package load it).
+Each has its C++ torch shim (hpc/_hpc_torch.so / hpc/_hpc_torch_dev.so).
+
+    python hpc-ops_amd/build.py [-j N] [--force] [--no-dev]
 """
 import argparse
 import concurrent.futures as cf
@@ -18,6 +25,7 @@ ROOT = Path(__file__).resolve().parent
 CSRC = ROOT / "csrc"
 OBJ = ROOT / "build"
 LIB = ROOT / "hpc" / "libhpc_amd.so"
+LIB_DEV = ROOT / "hpc" / "libhpc_amd_dev.so"
 INCLUDE = ROOT.parent / "include"
 
 
@@ -54,11 +62,11 @@ def _deps_newer(obj: Path, src: Path) -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def _compile(src: Path, force: bool) -> Path:
-    obj = OBJ / (src.stem + ".o")
+def _compile(src: Path, force: bool, dev: bool = False) -> Path:
+    obj = (OBJ / "dev" if dev else OBJ) / (src.stem + ".o")
     if not force and not _deps_newer(obj, src):
         return obj
-    cmd = ["hipcc"] + _flags()
+    cmd = ["hipcc"] + _flags() + (["-DHPC_DEV=1"] if dev else [])
     if src.stem == "library":
         h = _git_hash()
         cmd += ['-DHPC_VERSION_STR="0.0.1.dev0+g%s"' % h, '-DHPC_GIT_HASH_STR="%s"' % h]
@@ -71,27 +79,30 @@ def _compile(src: Path, force: bool) -> Path:
     return obj
 
 
-def build(jobs: int = 0, force: bool = False) -> Path:
-    OBJ.mkdir(exist_ok=True)
+def build(jobs: int = 0, force: bool = False, dev: bool = False) -> Path:
+    """dev=False: hpc/libhpc_amd.so (the product); dev=True: hpc/libhpc_amd_dev.so (-DHPC_DEV)."""
+    lib = LIB_DEV if dev else LIB
+    (OBJ / "dev" if dev else OBJ).mkdir(parents=True, exist_ok=True)
     srcs = sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.cc"))
     jobs = jobs or min(len(srcs), os.cpu_count() or 4)
     with cf.ThreadPoolExecutor(max_workers=jobs) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force), srcs))
-    need_link = force or not LIB.exists() or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs)
+        objs = list(ex.map(lambda s: _compile(s, force, dev), srcs))
+    need_link = force or not lib.exists() or any(o.stat().st_mtime > lib.stat().st_mtime for o in objs)
     if need_link:
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB)] + [
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(lib)] + [
             str(o) for o in objs
         ] + ["-lpthread"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    return LIB
+    return lib
 
 
 SHIM = ROOT / "hpc" / "_hpc_torch.so"
+SHIM_DEV = ROOT / "hpc" / "_hpc_torch_dev.so"
 
 
-def build_torch_shim(force: bool = False):
+def build_torch_shim(force: bool = False, dev: bool = False):
     """hpc/_hpc_torch.so: the C++ host side (csrc/torch_binding.cpp: TORCH_LIBRARY_FRAGMENT(hpc) registrations of the
     hot-path ops + the MulticastCommunicator torch class) on top of the C-ABI.  Host-only C++ compiled by g++ against
     the installed torch headers - the reference registers its ops the same way (src/*/entry.cc).  Returns the path, or
@@ -102,27 +113,32 @@ def build_torch_shim(force: bool = False):
     except Exception:  # noqa: BLE001
         return None
     src = CSRC / "torch_binding.cpp"
+    shim, lib = (SHIM_DEV, LIB_DEV) if dev else (SHIM, LIB)
     deps = [src, INCLUDE / "hpc_amd.h", Path(__file__)]
-    if not force and SHIM.exists() and all(d.stat().st_mtime <= SHIM.stat().st_mtime for d in deps) \
-            and SHIM.stat().st_mtime >= LIB.stat().st_mtime:
-        return SHIM
+    if not force and shim.exists() and all(d.stat().st_mtime <= shim.stat().st_mtime for d in deps) \
+            and shim.stat().st_mtime >= lib.stat().st_mtime:
+        return shim
     tlib = Path(ce.library_paths()[0])
     abi = int(getattr(torch._C, "_GLIBCXX_USE_CXX11_ABI", True))
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
            f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-w"]
     cmd += ["-I" + p for p in ce.include_paths()] + ["-I/opt/rocm/include", "-I" + str(INCLUDE)]
-    cmd += [str(src), "-o", str(SHIM), "-L" + str(tlib), "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip",
-            "-L" + str(LIB.parent), "-l:" + LIB.name, "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + str(tlib)]
+    cmd += [str(src), "-o", str(shim), "-L" + str(tlib), "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip",
+            "-L" + str(lib.parent), "-l:" + lib.name, "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + str(tlib)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("torch shim build failed:\n%s\n%s" % (r.stdout[-3000:], r.stderr[-3000:]))
-    return SHIM
+    return shim
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("-j", type=int, default=0)
     ap.add_argument("--force", action="store_true")
+    ap.add_argument("--no-dev", action="store_true", help="skip the development build")
     a = ap.parse_args()
     print(build(a.j, a.force))
     print(build_torch_shim(a.force))
+    if not a.no_dev:
+        print(build(a.j, a.force, dev=True))
+        print(build_torch_shim(a.force, dev=True))

@@ -129,12 +129,12 @@ struct HtArgs {
   int rows, hidden, rank, ws;
 };
 
-__device__ __forceinline__ void signal_barrier(const HtArgs& a) {
+__device__ __forceinline__ void signal_barrier(const HtArgs& a, int bid) {
   // block b of rank r <-> block b of every peer (reference high_throughput.cu:37-43, utils.cuh:571-590)
   __syncthreads();
   const int t = threadIdx.x;
   if (t < a.ws) {
-    uint32_t* post = a.sig[t] + blockIdx.x * a.ws + a.rank;  // my flag in peer t's pad
+    uint32_t* post = a.sig[t] + bid * a.ws + a.rank;  // my flag in peer t's pad
     long spins = 0;
     uint32_t expect = 0u;
     while (!__hip_atomic_compare_exchange_strong(post, &expect, 1u, __ATOMIC_RELEASE, __ATOMIC_RELAXED,
@@ -146,7 +146,7 @@ __device__ __forceinline__ void signal_barrier(const HtArgs& a) {
         break;
       }
     }
-    uint32_t* wait = a.sig[a.rank] + blockIdx.x * a.ws + t;  // peer t's flag in my pad
+    uint32_t* wait = a.sig[a.rank] + bid * a.ws + t;  // peer t's flag in my pad
     spins = 0;
     expect = 1u;
     while (!__hip_atomic_compare_exchange_strong(wait, &expect, 0u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
@@ -170,13 +170,14 @@ __device__ __forceinline__ void signal_barrier(const HtArgs& a) {
 // Loads are bounded buffer loads: lanes past the end of the row read 0 without a branch.
 // kVec = 16-byte vectors per thread and row: 4 for hidden <= 8192 (x[4][8] + acc: ~200 VGPRs, two
 // workgroups per CU), 8 up to 16384 (two passes of 4).
+// The body takes the workgroup's index / the grid size as arguments: the product kernel passes blockIdx.x / gridDim.x,
+// the development loopback kernel below runs the workgroups of ALL ranks of a world in one grid (blockIdx.y = rank).
 template <int kWs, int kVec>
-__global__ __launch_bounds__(kThreads) void ht_kernel(const HtArgs a) {
-  __shared__ float red[4];
+__device__ __forceinline__ void ht_body(const HtArgs& a, int bid, int nblk, float* red) {
   const int nvec = a.hidden >> 3;
   const unsigned row_bytes = static_cast<unsigned>(a.hidden) * 2u;
-  signal_barrier(a);  // every rank's input is in place
-  for (int row = blockIdx.x; row < a.rows; row += gridDim.x) {
+  signal_barrier(a, bid);  // every rank's input is in place
+  for (int row = bid; row < a.rows; row += nblk) {
     const long roff = static_cast<long>(row) * a.hidden;
     float acc[kVec][8];
 #pragma unroll
@@ -232,7 +233,12 @@ __global__ __launch_bounds__(kThreads) void ht_kernel(const HtArgs a) {
     }
   }
   __threadfence_system();  // my rows are visible in every peer before I signal
-  signal_barrier(a);       // every rank's rows have landed here
+  signal_barrier(a, bid);  // every rank's rows have landed here
+}
+template <int kWs, int kVec>
+__global__ __launch_bounds__(kThreads) void ht_kernel(const HtArgs a) {
+  __shared__ float red[4];
+  ht_body<kWs, kVec>(a, blockIdx.x, gridDim.x, red);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -253,7 +259,7 @@ struct LlArgs {
   int rows, hidden, rank, ws;
 };
 
-__global__ __launch_bounds__(kThreads) void ll_scatter_kernel(const LlArgs a) {
+__device__ __forceinline__ void ll_scatter_body(const LlArgs& a, int bid, int nblk) {
   const uint32_t cur = a.flags[0] % 3u;
   const uint32_t slot_bytes = a.flags[2];
   const uint32_t nxt = (cur + 1u) % 3u;
@@ -263,13 +269,13 @@ __global__ __launch_bounds__(kThreads) void ll_scatter_kernel(const LlArgs a) {
     const uint32_t dirty = a.flags[4 + nxt];
     uint8_t* base = a.local_ws + static_cast<long>(nxt) * slot_bytes;
     const u32x4 s = u32x4{kSentinel, kSentinel, kSentinel, kSentinel};
-    for (long o = (static_cast<long>(blockIdx.x) * kThreads + threadIdx.x) * 16; o < dirty;
-         o += static_cast<long>(gridDim.x) * kThreads * 16)
+    for (long o = (static_cast<long>(bid) * kThreads + threadIdx.x) * 16; o < dirty;
+         o += static_cast<long>(nblk) * kThreads * 16)
       st16_sys(base + o, s);
   }
   // 2. push my rows to their owners: owner's slot [t / ws][rank][hidden]
   const int nvec = a.hidden >> 3;
-  for (int t = blockIdx.x; t < a.rows; t += gridDim.x) {
+  for (int t = bid; t < a.rows; t += nblk) {
     const int owner = t % a.ws;
     uint8_t* dst = reinterpret_cast<uint8_t*>(a.peers[owner]) + static_cast<long>(cur) * slot_bytes +
                    (static_cast<long>(t / a.ws) * a.ws + a.rank) * a.hidden * 2;
@@ -277,6 +283,7 @@ __global__ __launch_bounds__(kThreads) void ll_scatter_kernel(const LlArgs a) {
     for (int v = threadIdx.x; v < nvec; v += kThreads) st16_sys(dst + v * 16, sanitize(ld16(src + v * 8)));
   }
 }
+__global__ __launch_bounds__(kThreads) void ll_scatter_kernel(const LlArgs a) { ll_scatter_body(a, blockIdx.x, gridDim.x); }
 
 // Poll `kN` x `nper` 16-byte vectors of this thread until none carries the sentinel: every poll round
 // issues ALL the loads before it looks at the first one (local memory, system scope), instead of one
@@ -311,8 +318,7 @@ __device__ __forceinline__ void poll_vectors(u32x4 (&v)[kVec][kN], const uint8_t
 }
 
 template <int kVec>
-__global__ __launch_bounds__(kThreads) void ll_reduce_norm_kernel(const LlArgs a) {
-  __shared__ float red[4];
+__device__ __forceinline__ void ll_reduce_norm_body(const LlArgs& a, int bid, int nblk, float* red) {
   const uint32_t cur = a.flags[0] % 3u;
   const uint32_t slot_bytes = a.flags[2];
   const int nvec = a.hidden >> 3;
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(kThreads) void ll_reduce_norm_kernel(const LlArgs a
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t old = atomicAdd(&a.flags[8], 1u);
-    if (old == gridDim.x - 1) {
+    if (old == static_cast<uint32_t>(nblk) - 1u) {
       a.flags[4 + cur] = static_cast<uint32_t>(2 * n_pad * row_bytes);
       a.flags[8] = 0u;
       a.flags[1] = (cur + 2u) % 3u;
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(kThreads) void ll_reduce_norm_kernel(const LlArgs a
     }
   }
 
-  for (int t = blockIdx.x; t < a.rows; t += gridDim.x) {
+  for (int t = bid; t < a.rows; t += nblk) {
     float acc[kVec][8];
 #pragma unroll
     for (int i = 0; i < kVec; ++i)
@@ -398,6 +404,42 @@ __global__ __launch_bounds__(kThreads) void ll_reduce_norm_kernel(const LlArgs a
     __syncthreads();
   }
 }
+template <int kVec>
+__global__ __launch_bounds__(kThreads) void ll_reduce_norm_kernel(const LlArgs a) {
+  __shared__ float red[4];
+  ll_reduce_norm_body<kVec>(a, blockIdx.x, gridDim.x, red);
+}
+
+#ifdef HPC_DEV
+// ---------------------------------------------------------------------------------------------
+// Development loopback: the workgroups of ALL ranks of a world in ONE grid on one device (blockIdx.y = rank), every
+// rank with its own argument block over ordinary device allocations - the world-size-8 instantiations of the product
+// bodies above run and rendezvous for real on the single GPU of a test box (eight PROCESSES time-slice the device
+// and never make progress together; one grid is co-resident by construction when it is small enough).
+// ---------------------------------------------------------------------------------------------
+template <int kWs, int kVec>
+__global__ __launch_bounds__(kThreads) void ht_loopback_kernel(const HtArgs* all) {
+  __shared__ float red[4];
+  __shared__ HtArgs a;
+  if (threadIdx.x == 0) a = all[blockIdx.y];
+  __syncthreads();
+  ht_body<kWs, kVec>(a, blockIdx.x, gridDim.x, red);
+}
+__global__ __launch_bounds__(kThreads) void ll_scatter_loopback_kernel(const LlArgs* all) {
+  __shared__ LlArgs a;
+  if (threadIdx.x == 0) a = all[blockIdx.y];
+  __syncthreads();
+  ll_scatter_body(a, blockIdx.x, gridDim.x);
+}
+template <int kVec>
+__global__ __launch_bounds__(kThreads) void ll_reduce_norm_loopback_kernel(const LlArgs* all) {
+  __shared__ float red[4];
+  __shared__ LlArgs a;
+  if (threadIdx.x == 0) a = all[blockIdx.y];
+  __syncthreads();
+  ll_reduce_norm_body<kVec>(a, blockIdx.x, gridDim.x, red);
+}
+#endif  // HPC_DEV
 
 }  // namespace ar
 }  // namespace hpc
@@ -545,3 +587,111 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_low_latency_async(
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }
+
+#ifdef HPC_DEV
+// ---- development loopback entries (tests/test_allreduce.py::test_allreduce_rmsnorm_ws8_loopback) ---------------------
+// Tables are rank-major: entry [r * world_size + p] is what rank r would pass as element p of the product entry's
+// table; [r] what rank r would pass as the scalar argument.  One launch runs every rank (see the loopback kernels).
+namespace {
+template <typename T>
+T* loopback_args_on_device(const T* host, int n, hipStream_t stream) {
+  static void* dev = nullptr;  // big enough for either argument block
+  if (!dev && hipMalloc(&dev, 8 * (sizeof(HtArgs) > sizeof(LlArgs) ? sizeof(HtArgs) : sizeof(LlArgs))) != hipSuccess)
+    return nullptr;
+  if (hipMemcpyAsync(dev, host, n * sizeof(T), hipMemcpyHostToDevice, stream) != hipSuccess) return nullptr;
+  return static_cast<T*>(dev);
+}
+}  // namespace
+
+extern "C" int hpc_dev_allreduce_loopback_ht(const void* const* peer_x, void* const* peer_out, void* const* peer_sig,
+                                             const void* const* residual, void* const* out_residual,
+                                             const int* num_rows, const void* weight, float eps, int hidden,
+                                             int world_size, int num_max_blocks, int pad_words, hipStream_t stream) {
+  if (world_size < 1 || world_size > kMaxWs || (hidden & 7) || hidden <= 0 || hidden > kMaxVec * kThreads * 8)
+    return HPC_ERR_UNSUPPORTED;
+  const int grid = hpc_fuse_allreduce_rmsnorm_high_throughput_grid(world_size, num_max_blocks, pad_words);
+  if (grid <= 0) return HPC_ERR_INVALID;
+  static HtArgs host[kMaxWs];
+  for (int r = 0; r < world_size; ++r) {
+    HtArgs& a = host[r];
+    a.timeouts = timeout_word();
+    a.spin_limit = spin_limit();
+    if (!a.timeouts) return HPC_ERR_LAUNCH;
+    for (int p = 0; p < kMaxWs; ++p) {
+      a.in[p] = p < world_size ? static_cast<const uint16_t*>(peer_x[r * world_size + p]) : nullptr;
+      a.out[p] = p < world_size ? static_cast<uint16_t*>(peer_out[r * world_size + p]) : nullptr;
+      a.sig[p] = p < world_size ? static_cast<uint32_t*>(peer_sig[r * world_size + p]) : nullptr;
+    }
+    a.residual = static_cast<const uint16_t*>(residual[r]);
+    a.out_residual = static_cast<uint16_t*>(out_residual[r]);
+    a.w = static_cast<const uint16_t*>(weight);
+    a.eps = eps;
+    a.rows = num_rows[r];
+    a.hidden = hidden;
+    a.rank = r;
+    a.ws = world_size;
+  }
+  const HtArgs* dev = loopback_args_on_device(host, world_size, stream);
+  if (!dev) return HPC_ERR_LAUNCH;
+  const dim3 g(grid, world_size);
+#define HPC_HT_LOOP(WS)                                                  \
+  if (hidden <= 4 * kThreads * 8)                                        \
+    ht_loopback_kernel<WS, 4><<<g, kThreads, 0, stream>>>(dev);          \
+  else                                                                   \
+    ht_loopback_kernel<WS, 8><<<g, kThreads, 0, stream>>>(dev)
+  switch (hpc_dev_tuning_get(9) == 1 ? 0 : world_size) {
+    case 1: HPC_HT_LOOP(1); break;
+    case 2: HPC_HT_LOOP(2); break;
+    case 4: HPC_HT_LOOP(4); break;
+    case 8: HPC_HT_LOOP(8); break;
+    default: HPC_HT_LOOP(0); break;
+  }
+#undef HPC_HT_LOOP
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}
+
+extern "C" int hpc_dev_allreduce_loopback_ll(void* const* output, void* const* residual_out, const void* const* input,
+                                             const void* data_buffer_ptrs_dev, void* const* local_workspace,
+                                             void* const* buffer_flags, const void* const* residual_in,
+                                             const void* weight, float eps, int num_tokens, int hidden, int world_size,
+                                             int64_t workspace_bytes, hipStream_t stream) {
+  if (world_size < 1 || world_size > kMaxWs || (hidden & 7) || hidden <= 0 || hidden > kMaxVec * kThreads * 8)
+    return HPC_ERR_UNSUPPORTED;
+  if (num_tokens <= 0) return HPC_OK;
+  const int64_t n_pad = (num_tokens + world_size - 1) / world_size * world_size;
+  if (workspace_bytes < 3 * 2 * n_pad * hidden * 2) return HPC_ERR_INVALID;
+  static LlArgs host[kMaxWs];
+  for (int r = 0; r < world_size; ++r) {
+    LlArgs& a = host[r];
+    a.timeouts = timeout_word();
+    a.spin_limit = spin_limit();
+    if (!a.timeouts) return HPC_ERR_LAUNCH;
+    a.x = static_cast<const uint16_t*>(input[r]);
+    a.peers = static_cast<const long*>(data_buffer_ptrs_dev);
+    a.local_ws = static_cast<uint8_t*>(local_workspace[r]);
+    a.flags = static_cast<uint32_t*>(buffer_flags[r]);
+    a.residual = static_cast<const uint16_t*>(residual_in[r]);
+    a.residual_out = static_cast<uint16_t*>(residual_out[r]);
+    a.y = static_cast<uint16_t*>(output[r]);
+    a.w = static_cast<const uint16_t*>(weight);
+    a.eps = eps;
+    a.rows = num_tokens;
+    a.hidden = hidden;
+    a.rank = r;
+    a.ws = world_size;
+  }
+  const LlArgs* dev = loopback_args_on_device(host, world_size, stream);
+  if (!dev) return HPC_ERR_LAUNCH;
+  const dim3 g(num_tokens < 2048 ? num_tokens : 2048, world_size);
+  ll_scatter_loopback_kernel<<<g, kThreads, 0, stream>>>(dev);
+  HPC_CHECK_LAUNCH();
+  if (hidden <= 4 * kThreads * 8)
+    ll_reduce_norm_loopback_kernel<4><<<g, kThreads, 0, stream>>>(dev);
+  else
+    ll_reduce_norm_loopback_kernel<8><<<g, kThreads, 0, stream>>>(dev);
+  HPC_CHECK_LAUNCH();
+  return HPC_OK;
+}
+#endif  // HPC_DEV
+

@@ -726,11 +726,15 @@ extern "C" int64_t hpc_attention_decode_workspace_zero_bytes(void) { return hpc:
 
 // development (tools/prof_decode.py): device buffer [workgroups][4 waves][12] uint64 that the profiling build of the
 // second-generation kernel fills with per-wave s_memtime sums; null = the shipped kernel
+#ifdef HPC_DEV
 static void* g_decode_prof = nullptr;
 extern "C" int hpc_dev_decode_prof_buffer(void* p) {
   g_decode_prof = p;
   return 0;
 }
+#else
+static constexpr void* g_decode_prof = nullptr;  // production build: the profiling instantiations are not emitted
+#endif
 
 // Second generation (attention_decode_v2.hip: head pairs per load, deep prefetch, in-kernel plan and merge) when the
 // layout allows it.  Returns HPC_OK when it launched, 1 when the call is not its case (the caller goes on to the

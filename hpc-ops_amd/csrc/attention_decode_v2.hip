@@ -1183,14 +1183,14 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
       decode2_kernel<0, true><<<num_wg, kThreads, 0, stream>>>(a);
     else
       decode2_kernel<2, true><<<num_wg, kThreads, 0, stream>>>(a);
-  } else if (mode == 2) {
+  } else if (kHpcDevBuild && mode == 2) {
     if (a.prof)  // development: per-wave s_memtime sums (hpc_dev_decode_prof_buffer)
       decode2_kernel<2, false, true, true><<<num_wg, kThreads, 0, stream>>>(a);
     else if (temporal)
       decode2_kernel<0, false, false, true><<<num_wg, kThreads, 0, stream>>>(a);
     else
       decode2_kernel<2, false, false, true><<<num_wg, kThreads, 0, stream>>>(a);
-  } else if (a.prof) {  // development: per-wave s_memtime sums (hpc_dev_decode_prof_buffer)
+  } else if (kHpcDevBuild && a.prof) {  // development: per-wave s_memtime sums (hpc_dev_decode_prof_buffer)
     decode2_kernel<2, false, true><<<num_wg, kThreads, 0, stream>>>(a);
   } else if (temporal) {
     decode2_kernel<0><<<num_wg, kThreads, 0, stream>>>(a);

@@ -55,9 +55,11 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float clamp_e4m3(float x) {
   return __builtin_fminf(__builtin_fmaxf(x, -448.0f), 448.0f);
 }
+// A NaN leaves as the CANONICAL positive quiet NaN: v_cvt_pk_fp8_f32 keeps the sign bit of a NaN (a NaN that went
+// through a multiply came out as 0xff on gfx950), the reference's cast and torch's give 0x7f.
 __device__ __forceinline__ float clamp_e4m3_nan(float x) {
   const float c = __builtin_fminf(__builtin_fmaxf(x, -448.0f), 448.0f);
-  return x != x ? x : c;
+  return x != x ? __builtin_bit_cast(float, 0x7fc00000u) : c;
 }
 // packs (a, b) into the low 16 bits of the result.
 __device__ __forceinline__ uint32_t cvt_pk_e4m3(float a, float b) {

@@ -1,11 +1,12 @@
-// Development tuning registers - INTERNAL, not part of the C-ABI of include/hpc_amd.h.
+// Development tuning registers - INTERNAL, not part of the C-ABI of include/hpc_amd.h, and NOT IN THE SHIPPED LIBRARY.
 //
 // 64 small integers that select kernel variants inside the launchers for A/B measurements and for
-// the parity tests that pin one variant (tests/, tools/).  All zero = the shipped configuration.
-// Storage is a set of relaxed atomics (any host thread may read them while another one writes);
-// the environment variable HPC_AMD_TUNING="key=value,key=value" seeds them once at library load,
-// so a deployment never needs to call the setter.  The symbols are exported from libhpc_amd.so
-// for the in-tree tools only; they are deliberately absent from the public header.
+// the parity tests that pin one variant (tests marked `dev`, tools/).  They exist only in the DEVELOPMENT build
+// (-DHPC_DEV -> hpc/libhpc_amd_dev.so, loaded by `HPC_AMD_DEV=1`): there storage is a set of relaxed atomics and the
+// environment variable HPC_AMD_TUNING="key=value,key=value" seeds them once at library load.  In the production
+// build (hpc/libhpc_amd.so) hpc_dev_tuning_get is the constant 0: every variant branch folds away at compile
+// time, no setter is exported, no environment variable is read - the timing-only variants that give wrong results
+// (15, 18) and the all-reduce knobs that must agree on every rank (9, 10, 11) cannot be switched on by accident.
 //   key 0  decode KV load cache policy (1 = temporal instead of nt)
 //   key 1  streaming grouped GEMM: forced tokens-per-pass / waves variant
 //   key 3  grouped GEMM tiled mode (0 auto, 1 never, 2 always 256x128 when possible, 3 always 128x128,
@@ -28,5 +29,11 @@
 //   others: see the launchers that read them
 #pragma once
 
+#ifdef HPC_DEV
+constexpr bool kHpcDevBuild = true;
 extern "C" int hpc_dev_tuning_set(int key, int value);
 extern "C" int hpc_dev_tuning_get(int key);
+#else
+constexpr bool kHpcDevBuild = false;  // launch sites of development-only instantiations test it: they are not emitted
+static constexpr int hpc_dev_tuning_get(int) { return 0; }
+#endif

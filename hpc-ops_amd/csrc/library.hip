@@ -68,6 +68,7 @@ extern "C" long long hpc_stream_capture_id(hipStream_t stream) {
   return static_cast<long long>(id ? id : 1);
 }
 
+#ifdef HPC_DEV
 // Development tuning registers: see csrc/hpc_dev.h (internal; not in include/hpc_amd.h).
 #include <atomic>
 #include <cstdio>
@@ -120,3 +121,4 @@ extern "C" int hpc_dev_tuning_set(int key, int value) {
 extern "C" int hpc_dev_tuning_get(int key) {
   return (key < 0 || key >= Tuning::kKeys) ? 0 : tuning().v[key].load(std::memory_order_relaxed);
 }
+#endif  // HPC_DEV

@@ -9,12 +9,16 @@ object on which the per-module `_entry_*.py` files register the reference's op s
 There is NO fallback: if the library is missing or an entry point is absent, import fails loudly.
 """
 import ctypes
+import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 from pathlib import Path
 
 import torch
 
-_LIB_PATH = Path(__file__).resolve().parent / "libhpc_amd.so"
+# HPC_AMD_DEV=1: the DEVELOPMENT build (libhpc_amd_dev.so, -DHPC_DEV: variant-selection registers and development
+# entry points, csrc/hpc_dev.h) instead of the product - for tools/ and the tests marked `dev`.
+DEV_BUILD = os.environ.get("HPC_AMD_DEV", "0") == "1"
+_LIB_PATH = Path(__file__).resolve().parent / ("libhpc_amd_dev.so" if DEV_BUILD else "libhpc_amd.so")
 if not _LIB_PATH.exists():
     raise ImportError(
         f"{_LIB_PATH} not found: build it first with `python hpc-ops_amd/build.py` "
@@ -40,8 +44,9 @@ def _sig(name, restype, *argtypes):
 _sig("hpc_version", c_char_p)
 _sig("hpc_built_json", c_char_p)
 _sig("hpc_get_cu_count", I, I)
-_sig("hpc_dev_tuning_set", I, I, I)
-_sig("hpc_dev_tuning_get", I, I)
+if DEV_BUILD:  # the product does not export them
+    _sig("hpc_dev_tuning_set", I, I, I)
+    _sig("hpc_dev_tuning_get", I, I)
 _sig("hpc_fused_rmsnorm_with_scale_async", I, P, P, P, P, P, P, F, I, I, I, P)
 IP = ctypes.POINTER(c_int)
 _sig("hpc_attention_decode_num_bins", I, I, I)
@@ -110,9 +115,7 @@ _sig("hpc_allreduce_reset_timeouts", I)
 # registrations + torch.classes.hpc.MulticastCommunicator, like the reference's src/*/entry.cc.  When it is present
 # its ops are the ones that run; the Python entries below it (hpc/_entry_*.py) register everything else and are the
 # fallback for a build without the torch headers (HPC_AMD_PY_ENTRIES=1 forces them, for the tests of that fallback).
-import os
-
-_SHIM_PATH = Path(__file__).resolve().parent / "_hpc_torch.so"
+_SHIM_PATH = Path(__file__).resolve().parent / ("_hpc_torch_dev.so" if DEV_BUILD else "_hpc_torch.so")
 NATIVE_OPS = frozenset()
 if _SHIM_PATH.exists() and os.environ.get("HPC_AMD_PY_ENTRIES", "0") != "1":
     try:

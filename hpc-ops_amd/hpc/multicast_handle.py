@@ -69,18 +69,19 @@ class MulticastHandle:
     def signal_buffer_ptrs_dev(self) -> torch.Tensor:
         return self.signal_buffer_ptrs_dev_
 
-    def _view(self, base, sizes, dtype, storage_offset):
+    def _view(self, base, sizes, dtype, storage_offset, limit=None):
         if len(sizes) == 1 and isinstance(sizes[0], Sequence):
             sizes = tuple(sizes[0])
         else:
             sizes = tuple(sizes)
         if dtype is None:
             dtype = torch.get_default_dtype()
+        limit = self.buffer_size if limit is None else limit
         numel = list(accumulate(sizes, func=mul))[-1]
         ask = numel * dtype.itemsize
-        assert storage_offset + ask <= self.buffer_size, (
-            f"The requested buffer size(got {storage_offset} + {ask}) exceeds the size of the hold "
-            f"buffer(got {self.buffer_size}).")
+        assert storage_offset + ask <= limit, (
+            f"The requested buffer size(got {storage_offset} + {ask} = {storage_offset + ask}) exceeds the size of the "
+            f"hold buffer(got {limit}).")
         return base[storage_offset : storage_offset + ask].view(dtype).view(sizes)
 
     def get_buffer(self, rank: int, *sizes: Any, dtype: Optional[torch.dtype] = None,
@@ -90,11 +91,24 @@ class MulticastHandle:
         assert rank == self.rank, "peer buffers are address-only on xGMI (use data_buffer_ptrs)"
         return self._view(self.data_buffer_list_[rank], sizes, dtype, storage_offset)
 
+    def get_signal(self, rank: int, *sizes: Any, storage_offset: int = 0) -> torch.Tensor:
+        """uint32 view of rank `rank`'s signal pad (reference hpc/multicast_handle.py:128-149); like get_buffer only the
+        local rank's pad is a torch tensor here (peers' pads are reached through signal_buffer_ptrs)."""
+        assert 0 <= rank <= self.world_size
+        assert rank == self.rank, "peer signal pads are address-only on xGMI (use signal_buffer_ptrs)"
+        return self._view(self.signal_buffer_list_[rank], sizes, torch.uint32, storage_offset, self.signal_size)
+
     def get_multimem_buff(self, *sizes: Any, dtype: Optional[torch.dtype] = None,
                           storage_offset: int = 0) -> torch.Tensor:
         """The reference returns a view of the NVLS multicast mapping; xGMI has none, so this is the
         same view of the local buffer - the all-reduce entries translate it to peer addresses."""
         return self._view(self.multimem_data_buffer_, sizes, dtype, storage_offset)
 
-    def barrier(self, channel: int = 0):
+    def get_multimem_signal(self, *sizes: Any, storage_offset: int = 0) -> torch.Tensor:
+        """uint32 view of the "multicast" signal pad (reference :173-194): the local pad, see get_multimem_buff."""
+        return self._view(self.multimem_signal_buffer_, sizes, torch.uint32, storage_offset, self.signal_size)
+
+    def barrier(self, channel: int = 0, timeout_ms: int = 0):
+        """Reference :196-198: a placeholder that launches nothing (`pass`); same signature, same (no) effect.  Ranks
+        synchronise through MulticastCommunicator.Barrier() and the signal-pad barriers inside the fused kernels."""
         return None

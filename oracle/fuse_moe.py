@@ -67,7 +67,8 @@ def group_gemm_blockwise_kernel_arith(x, w, seqlens, cu_seqlens, xscale, wscale)
     The FMA is emulated in float64: the 48-bit product is exact, the sum is rounded once to 53 bits and once more to
     fp32 - a double rounding that differs from a true FMA only when the 53-bit sum lands exactly on an fp32 tie (odds
     2^-29 per operation, and visible in bf16 only on a further 2^-8 coincidence).  HIP's blockwise GEMMs use this
-    arithmetic; tests compare them BIT FOR BIT on inputs whose block partials are exact in fp32
+    arithmetic; what is left between them and this function is the matrix pipe's rounding of the 128-term block sums
+    (here: exact sums rounded once to fp32), which moves ~1e-4 of the bf16 outputs by one ulp
     (tests/test_fuse_moe_blockwise.py::test_group_gemm_blockwise_is_the_reference_kernel_arithmetic)."""
     m, k = x.shape
     num_group, n, _ = w.shape

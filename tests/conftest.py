@@ -15,6 +15,9 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "dev: pins kernel variants through development registers, which only the "
+                                       "development build of the library has (HPC_AMD_DEV=1 -> libhpc_amd_dev.so); "
+                                       "tests/test_dev_build.py re-runs these in a subprocess against that build")
 
 
 def pytest_collection_modifyitems(config, items):

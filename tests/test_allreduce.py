@@ -150,9 +150,12 @@ def _spawn(world_size, one_gpu_per_rank=False, tuning="", cases=None, timeout=60
     ctx = multiprocessing.get_context("spawn")
     q = ctx.Queue()
     name = f"t_ar_{os.getpid()}_{world_size}_{len(tuning)}"
-    old = os.environ.get("HPC_AMD_TUNING")
+    old, old_dev = os.environ.get("HPC_AMD_TUNING"), os.environ.get("HPC_AMD_DEV")
     if tuning:
-        os.environ["HPC_AMD_TUNING"] = tuning  # inherited by the spawned ranks, read at library load
+        # inherited by the spawned ranks: they load the DEVELOPMENT build of the library (the product has no registers),
+        # which reads the variable at load
+        os.environ["HPC_AMD_TUNING"] = tuning
+        os.environ["HPC_AMD_DEV"] = "1"
     ps = [ctx.Process(target=_ar_task, args=(r, world_size, cases or CASES, name, q, r if one_gpu_per_rank else 0))
           for r in range(world_size)]
     for p in ps:
@@ -168,10 +171,11 @@ def _spawn(world_size, one_gpu_per_rank=False, tuning="", cases=None, timeout=60
         if p.is_alive():
             p.kill()
     if tuning:
-        if old is None:
-            os.environ.pop("HPC_AMD_TUNING", None)
-        else:
-            os.environ["HPC_AMD_TUNING"] = old
+        for var, val in (("HPC_AMD_TUNING", old), ("HPC_AMD_DEV", old_dev)):
+            if val is None:
+                os.environ.pop(var, None)
+            else:
+                os.environ[var] = val
     if sorted(res) != [(r, "ok") for r in range(world_size)]:
         import sys
         for r in sorted(res, key=str):
@@ -221,6 +225,122 @@ def test_allreduce_rmsnorm_world2_generic_peer_loop():
     """same protocol through the runtime-world-size kernel (world sizes other than 1/2/4/8 use it):
     development tuning key 9 = 1 selects it at world size 2."""
     _spawn(2, tuning="9=1,11=1")
+
+
+def _ptrs(vals):
+    arr = (ctypes.c_void_p * len(vals))()
+    for i, v in enumerate(vals):
+        arr[i] = v
+    return arr
+
+
+@pytest.mark.dev
+@pytest.mark.gpu
+@pytest.mark.parametrize("world_size", [8, 4, 2])
+def test_allreduce_rmsnorm_ws8_loopback(world_size):
+    """The world-size-8 (and 4, 2) instantiations of BOTH fused all-reduce kernels, executed for real on the one GPU of
+    the test box: the development loopback entries (csrc/allreduce.hip, -DHPC_DEV) run the workgroups of all ranks of
+    a world in ONE grid, every rank with its own argument block - its pointer tables, signal pad, Lamport workspace
+    and slot flags - over ordinary device allocations, through the very kernel bodies the product entries launch
+    (eight PROCESSES on one GPU time-slice and never rendezvous; one small grid is co-resident).  Cases and tolerances
+    as in the multi-process tests / the reference (tests/test_fuse_allreduce_rmsnorm_high_throughput.py:65-105,
+    ..._low_latency.py: seed 10001, atol = rtol = 0.1): even and uneven token slices, hidden 4096 ... 16384 (both
+    vector widths), row counts that change from call to call, the -0.0 sentinel path, slot rotation over five calls."""
+    _paths()
+    import hpc
+    from hpc import _C
+    from oracle import allreduce as oar
+    from utils import allclose, dev_set
+
+    if not _C.DEV_BUILD:
+        pytest.skip("development loopback entries: runs against the development build (tests/test_dev_build.py)")
+    lib, ws = _C.lib, world_size
+    VP, I = ctypes.c_void_p, ctypes.c_int
+    lib.hpc_dev_allreduce_loopback_ht.argtypes = [VP, VP, VP, VP, VP, VP, VP, ctypes.c_float, I, I, I, I, VP]
+    lib.hpc_dev_allreduce_loopback_ll.argtypes = [VP, VP, VP, VP, VP, VP, VP, VP, ctypes.c_float, I, I, I,
+                                                  ctypes.c_int64, VP]
+    dev = torch.device("cuda", 0)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    dev_set(10, 24)  # bounded spins give up after 2^24 rounds: a lost rendezvous is a reported timeout within seconds
+    dev_set(11, 1)   # high-throughput grid = num_max_blocks (the product floor is one workgroup per CU and rank)
+    try:
+        assert lib.hpc_allreduce_reset_timeouts() == 0
+        for mode, N, H, nblk, iters in (("ht", 64, 8192, 4, 3), ("ht", 61, 5120, 3, 2), ("ht_uneven", 96, 4096, 4, 2),
+                                        ("ht", 16, 16384, 2, 2), ("ll", 16, 8192, 4, 5), ("ll", 13, 7168, 4, 4),
+                                        ("ll", 24, 16384, 4, 3)):
+            N_pad = (N + ws - 1) // ws * ws
+            if mode == "ll":
+                M_pad = 2 * math.ceil(N / ws) * ws * 3
+                bufs = [torch.full((M_pad, H // 2), -(2 ** 31), dtype=torch.int32, device=dev) for _ in range(ws)]
+                table = torch.tensor([b.data_ptr() for b in bufs], dtype=torch.int64, device=dev)
+                slot_bytes = (M_pad * H * 2 // 3) // 16 * 16
+                flags = [torch.tensor([0, 2, slot_bytes, 0, 0, 0, 0, 0, 0], dtype=torch.int32, device=dev)
+                         for _ in range(ws)]
+            else:
+                in_x = [torch.zeros((N_pad, H), dtype=torch.bfloat16, device=dev) for _ in range(ws)]
+                out_x = [torch.empty((N_pad, H), dtype=torch.bfloat16, device=dev) for _ in range(ws)]
+                pad_words = 64 * ws
+                sig = [torch.zeros(pad_words, dtype=torch.int32, device=dev) for _ in range(ws)]
+            for it in range(iters):
+                n_it = N if it % 2 == 0 else max(N - 3, 1)
+                torch.manual_seed(10001 + it)
+                inputs = [torch.randn((N_pad, H), dtype=torch.bfloat16) for _ in range(ws)]
+                residual = torch.randn((N_pad, H), dtype=torch.bfloat16)
+                weight = torch.randn((H,), dtype=torch.bfloat16)
+                if it == 1:
+                    for x in inputs:
+                        x[0, :64] = -0.0
+                ref_res, ref_out = oar.ref_allreduce_rmsnorm([x[:n_it] for x in inputs], residual[:n_it], weight, 1e-6)
+                res_d, w_d = residual.to(dev), weight.to(dev)
+                if mode == "ll":
+                    xs = [inputs[r][:n_it].contiguous().to(dev) for r in range(ws)]
+                    outs = [torch.empty_like(xs[0]) for _ in range(ws)]
+                    out_res = [torch.empty_like(xs[0]) for _ in range(ws)]
+                    res_in = res_d[:n_it].contiguous()
+                    rc = lib.hpc_dev_allreduce_loopback_ll(
+                        _ptrs([t.data_ptr() for t in outs]), _ptrs([t.data_ptr() for t in out_res]),
+                        _ptrs([t.data_ptr() for t in xs]), VP(table.data_ptr()), _ptrs([b.data_ptr() for b in bufs]),
+                        _ptrs([f.data_ptr() for f in flags]), _ptrs([res_in.data_ptr()] * ws), VP(w_d.data_ptr()), 1e-6,
+                        n_it, H, ws, M_pad * H * 2, stream)
+                    assert rc == 0, rc
+                    torch.cuda.synchronize()
+                    assert lib.hpc_allreduce_timeouts() == 0, f"{mode} N={N} H={H} it{it}: a bounded spin timed out"
+                    for r in range(ws):
+                        assert allclose(ref_res, out_res[r].cpu(), atol=0.1, rtol=0.1), f"ll residual rank {r} it{it}"
+                        assert allclose(ref_out, outs[r].cpu(), atol=0.1, rtol=0.1), f"ll output rank {r} it{it}"
+                    assert all(int(f[0]) == (it + 1) % 3 for f in flags)  # every rank rotated its slots
+                    continue
+                if mode == "ht_uneven":
+                    assert N_pad // ws >= 5
+                    cuts = [0] + [min(N_pad, (N_pad * (r + 1)) // ws + (3 if r % 2 == 0 else -2)) for r in range(ws - 1)] + [N_pad]
+                else:
+                    cuts = [N_pad // ws * r for r in range(ws + 1)]
+                for r in range(ws):
+                    in_x[r].zero_()
+                    in_x[r][:n_it] = inputs[r][:n_it].to(dev)
+                    out_x[r].fill_(7.0)
+                out_res = [torch.empty_like(res_d) for _ in range(ws)]
+                row = H * 2
+                rc = lib.hpc_dev_allreduce_loopback_ht(
+                    _ptrs([in_x[p].data_ptr() + cuts[r] * row for r in range(ws) for p in range(ws)]),
+                    _ptrs([out_x[p].data_ptr() + cuts[r] * row for r in range(ws) for p in range(ws)]),
+                    _ptrs([sig[p].data_ptr() for r in range(ws) for p in range(ws)]),
+                    _ptrs([res_d.data_ptr() + cuts[r] * row for r in range(ws)]),
+                    _ptrs([out_res[r].data_ptr() + cuts[r] * row for r in range(ws)]),
+                    (ctypes.c_int * ws)(*[cuts[r + 1] - cuts[r] for r in range(ws)]), VP(w_d.data_ptr()), 1e-6, H, ws,
+                    nblk, pad_words, stream)
+                assert rc == 0, rc
+                torch.cuda.synchronize()
+                assert lib.hpc_allreduce_timeouts() == 0, f"{mode} N={N} H={H} it{it}: a bounded spin timed out"
+                for r in range(ws):
+                    lo, hi = cuts[r], min(cuts[r + 1], n_it)
+                    if hi > lo:
+                        assert allclose(ref_res[lo:hi], out_res[r][lo:hi].cpu(), atol=0.1, rtol=0.1), f"ht res rank {r} it{it}"
+                    assert allclose(ref_out, out_x[r][:n_it].cpu(), atol=0.1, rtol=0.1), f"ht output rank {r} it{it}"
+                    assert int(sig[r].abs().sum()) == 0  # both barriers consumed every flag they posted
+    finally:
+        dev_set(10, 0)
+        dev_set(11, 0)
 
 
 @pytest.mark.gpu

@@ -7,7 +7,7 @@ import math
 import pytest
 import torch
 
-from utils import allclose
+from utils import allclose, dev_set
 
 
 def _build_case(num_batch, num_seq_q, lens_before, block_size, kv_head_q_head, kvcache_shape, seed=41):
@@ -110,6 +110,7 @@ def test_attn_bf16_split_requests(lens):
     _run(len(lens), 2, lens, 64, (2, 16), True, False, True, "NHD")
 
 
+@pytest.mark.dev
 @pytest.mark.gpu
 @pytest.mark.parametrize("generation", ["head_pair", "first"])
 @pytest.mark.parametrize("num_batch,heads,num_seq_q,block_size", [(65, (8, 64), 1, 64), (300, (4, 16), 2, 32), (40, (2, 16), 2, 16)])
@@ -124,11 +125,11 @@ def test_attn_bf16_head_pair_kernel(generation, num_batch, heads, num_seq_q, blo
     lens = torch.randint(1, 1200, (num_batch,), dtype=torch.int32, generator=g)
     lens[torch.randperm(num_batch, generator=g)[: num_batch // 8]] = 0
     lens[0], lens[1] = 9000, 63
-    hpc._C.lib.hpc_dev_tuning_set(28, 1 if generation == "first" else 0)
+    dev_set(28, 1 if generation == "first" else 0)
     try:
         _run(num_batch, num_seq_q, lens, block_size, heads, False, False, True, "NHD")
     finally:
-        hpc._C.lib.hpc_dev_tuning_set(28, 0)
+        dev_set(28, 0)
 
 
 @pytest.mark.gpu
@@ -147,6 +148,7 @@ def test_attn_bf16_errors():
         hpc.attention_decode_bf16(q, kv, kv, bid, lens)
 
 
+@pytest.mark.dev
 @pytest.mark.gpu
 @pytest.mark.parametrize("num_seq_q", [1, 2, 5])
 @pytest.mark.parametrize("kvcache_shape", ["NHD", "HND"])
@@ -157,8 +159,8 @@ def test_attn_bf16_bins_of_short_requests(num_seq_q, kvcache_shape, solo):
     import hpc
 
     lens = torch.tensor([3, 64, 65, 128, 200, 250, 17, 1] * 6 + [5000], dtype=torch.int32)
-    hpc._C.lib.hpc_dev_tuning_set(5, 0 if solo else 1)
+    dev_set(5, 0 if solo else 1)
     try:
         _run(len(lens), num_seq_q, lens, 64, (2, 16), True, False, True, kvcache_shape, min_process_len=512)
     finally:
-        hpc._C.lib.hpc_dev_tuning_set(5, 0)
+        dev_set(5, 0)

@@ -7,7 +7,7 @@ import math
 import pytest
 import torch
 
-from utils import allclose
+from utils import allclose, dev_set
 
 
 def _case(num_batch, num_seq_q, lens_before, block_size, kv_head_q_head, k_per_token, seed=41):
@@ -121,6 +121,7 @@ def test_attn_fp8_small_pages_and_split(k_per_token, block_size):
     _run(5, 2, lens, block_size, (2, 16), k_per_token, False, True, "NHD", 0.2 if not k_per_token else 0.1)
 
 
+@pytest.mark.dev
 @pytest.mark.gpu
 @pytest.mark.parametrize("k_per_token", [False, True])
 @pytest.mark.parametrize("num_seq_q", [1, 3])
@@ -131,11 +132,11 @@ def test_attn_fp8_bins_of_short_requests(k_per_token, num_seq_q, solo):
     import hpc
 
     lens = torch.tensor([3, 64, 65, 128, 200, 250, 17, 1] * 6 + [5000], dtype=torch.int32)
-    hpc._C.lib.hpc_dev_tuning_set(5, 0 if solo else 1)
+    dev_set(5, 0 if solo else 1)
     try:
         _run(len(lens), num_seq_q, lens, 64, (2, 16), k_per_token, True, True, "NHD", 0.1 if k_per_token else 0.2)
     finally:
-        hpc._C.lib.hpc_dev_tuning_set(5, 0)
+        dev_set(5, 0)
 
 
 @pytest.mark.gpu
@@ -218,6 +219,7 @@ def test_attn_fp8_single_kv_head(block_size, num_seq_q):
     _run(len(lens), num_seq_q, lens, block_size, (1, 8 if num_seq_q <= 2 else 4), False, True, True, "NHD", 0.2)
 
 
+@pytest.mark.dev
 @pytest.mark.gpu
 @pytest.mark.parametrize("form", ["four_heads"])  # (the head-pair form serves these shapes by default: every other test)
 @pytest.mark.parametrize("num_seq_q,block_size,heads", [(1, 64, (8, 64)), (1, 64, (4, 32)), (2, 32, (4, 16)), (1, 16, (4, 16)),
@@ -230,14 +232,15 @@ def test_attn_fp8_four_heads_per_workgroup(form, num_seq_q, block_size, heads):
     import hpc
 
     lens = torch.tensor([20000, 3, 9000, 130, 64, 63, 65, 4097, 700, 1, 0, 127, 129, 15, 16, 17, 31000, 2], dtype=torch.int32)
-    hpc._C.lib.hpc_dev_tuning_set(29, 0 if form == "head_pairs" else 2)
+    dev_set(29, 0 if form == "head_pairs" else 2)
     try:
         for new_kv_included in (True, False):
             _run(len(lens), num_seq_q, lens, block_size, heads, False, new_kv_included, True, "NHD", 0.2)
     finally:
-        hpc._C.lib.hpc_dev_tuning_set(29, 0)
+        dev_set(29, 0)
 
 
+@pytest.mark.dev
 @pytest.mark.gpu
 @pytest.mark.parametrize("keys", [{32: 115}, {30: 118, 31: 108, 32: 125}])
 @pytest.mark.parametrize("num_batch,hi", [(64, 6000), (200, 1500), (7, 30000)])
@@ -249,12 +252,12 @@ def test_attn_fp8_uneven_ranges(keys, num_batch, hi):
 
     lens = _mixed_lens(num_batch, 7 * num_batch, hi)
     for k, v in keys.items():
-        hpc._C.lib.hpc_dev_tuning_set(k, v)
+        dev_set(k, v)
     try:
         _run(num_batch, 1, lens, 64, (8, 64), False, True, True, "NHD", 0.2)
     finally:
         for k in keys:
-            hpc._C.lib.hpc_dev_tuning_set(k, 0)
+            dev_set(k, 0)
 
 
 @pytest.mark.gpu

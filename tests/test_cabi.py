@@ -116,21 +116,6 @@ def test_ctypes_signatures_match_the_header():
     assert not bad, "\n".join(f"{n}: header {w} vs ctypes {h}" for n, w, h in bad)
 
 
-def test_development_registers_are_internal_and_cover_their_keys():
-    """The variant-selection registers live outside the public header (csrc/hpc_dev.h) and hold 64 keys: keys
-    16-31 were silently dropped by a 16-entry table once and key 32 by a 32-entry one, which turned A/B runs into
-    no-ops."""
-    lib = ctypes.CDLL(str(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so"))
-    header = (ROOT / "include" / "hpc_amd.h").read_text()
-    assert "tuning" not in header
-    for key in (0, 15, 16, 17, 20, 31, 32, 63):
-        assert lib.hpc_dev_tuning_set(key, 7 + key) == 0
-        assert lib.hpc_dev_tuning_get(key) == 7 + key
-        assert lib.hpc_dev_tuning_set(key, 0) == 0
-    assert lib.hpc_dev_tuning_set(64, 1) == -2 and lib.hpc_dev_tuning_get(64) == 0
-    assert lib.hpc_dev_tuning_set(-1, 1) == -2
-
-
 def test_prefill_refuses_strides_the_kernel_cannot_address():
     """Host-side argument checks run before any device call: the FP8 prefill kernels form page offsets as unsigned
     32 x 32 -> 64 products, so a page (block) stride of 4 GB or more is refused - HPC_ERR_UNSUPPORTED, not a launch."""

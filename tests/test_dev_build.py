@@ -1,0 +1,48 @@
+"""The product library (hpc/libhpc_amd.so) carries no development registers: no setter, no HPC_AMD_TUNING, every
+variant branch folded away at compile time (csrc/hpc_dev.h).  The tests that pin kernel variants (marked `dev`) skip
+their variant cases against the product; here they run - all of them, every case - in ONE subprocess against the
+development build (HPC_AMD_DEV=1 -> hpc/libhpc_amd_dev.so, same sources compiled with -DHPC_DEV)."""
+import ctypes
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_product_library_has_no_development_registers():
+    lib = ctypes.CDLL(str(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so"))
+    for sym in ("hpc_dev_tuning_set", "hpc_dev_tuning_get", "hpc_dev_decode_prof_buffer", "hpc_dev_allreduce_loopback"):
+        assert not hasattr(lib, sym), sym + " is exported by the product library"
+    blob = (ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so").read_bytes()
+    assert b"HPC_AMD_TUNING" not in blob
+    header = (ROOT / "include" / "hpc_amd.h").read_text()
+    assert "tuning" not in header and "hpc_dev" not in header
+
+
+def test_development_library_holds_64_registers():
+    """keys 16-31 were silently dropped by a 16-entry table once and key 32 by a 32-entry one, which turned A/B runs
+    into no-ops."""
+    lib = ctypes.CDLL(str(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd_dev.so"))
+    for key in (0, 15, 16, 17, 20, 31, 32, 63):
+        assert lib.hpc_dev_tuning_set(key, 7 + key) == 0
+        assert lib.hpc_dev_tuning_get(key) == 7 + key
+        assert lib.hpc_dev_tuning_set(key, 0) == 0
+    assert lib.hpc_dev_tuning_set(64, 1) == -2 and lib.hpc_dev_tuning_get(64) == 0
+    assert lib.hpc_dev_tuning_set(-1, 1) == -2
+
+
+@pytest.mark.gpu
+def test_dev_build_suite():
+    """every test marked `dev`, against the development build"""
+    if os.environ.get("HPC_AMD_DEV") == "1":
+        pytest.skip("already inside the development-build run")
+    env = dict(os.environ, HPC_AMD_DEV="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests"), "-m", "gpu and dev", "-q", "-x",
+                        "-p", "no:cacheprovider"], env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=3000)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-25:])
+    print(tail)
+    assert r.returncode == 0, tail

@@ -6,7 +6,7 @@ and tests/test_act.py:45-59."""
 import pytest
 import torch
 
-from utils import allclose
+from utils import allclose, dev_set
 
 F8 = torch.float8_e4m3fn
 
@@ -43,6 +43,7 @@ def test_fuse_moe_pertensor(num_seq, hidden, inter, num_expert, rank_ep, size_ep
     assert my2.data_ptr() == out.data_ptr() and torch.equal(my2, my)
 
 
+@pytest.mark.dev
 @pytest.mark.gpu
 @pytest.mark.parametrize("use_bf16_mul", [False, True])
 @pytest.mark.parametrize("num_seq,hidden,inter,num_expert,topk", [(600, 512, 256, 4, 2), (1500, 512, 128, 8, 4), (257, 1024, 384, 2, 2)])
@@ -67,12 +68,12 @@ def test_fuse_moe_pertensor_activation_epilogue(use_bf16_mul, num_seq, hidden, i
     run = lambda: hpc.fuse_moe_pertensor_fp8(c(x), c(guw), c(dw), c(gus), c(ds), c(ams), c(ids), c(sc), 0, num_expert,  # noqa: E731
                                              use_bf16_mul=use_bf16_mul)
     fused = run()
-    hpc._C.lib.hpc_dev_tuning_set(19, 1)
+    dev_set(19, 1)
     try:
         apart = run()
         torch.cuda.synchronize()
     finally:
-        hpc._C.lib.hpc_dev_tuning_set(19, 0)
+        dev_set(19, 0)
     assert torch.equal(fused, apart)
     assert allclose(gt.float(), fused.cpu().float(), rtol=0.08, atol=0.1)
 
@@ -197,6 +198,7 @@ def test_scaled_fp8_quant_reference_benchmark_call_and_errors():
         torch.ops.hpc.scaled_fp8_quant(xc, sc, torch.empty(3, dtype=F8, device="cuda"))
 
 
+@pytest.mark.dev
 @pytest.mark.gpu
 @pytest.mark.parametrize("tiled_mode", [2, 3, 4, 12, 22])  # 12 = LDS-DMA ring kernel with 32-token tiles; 4 = 256x256 kernel
 @pytest.mark.parametrize("k", [1792, 1088, 192])  # 1088 and 192 end in a half k-block (K % 128 == 64)
@@ -213,15 +215,15 @@ def test_group_gemm_pertensor_tiled_kernels(tiled_mode, k):
     scale = torch.rand(G) + 0.5
     cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
     gt = omoe.group_gemm_pertensor(x, w, seqlens, cu, scale)
-    hpc._C.lib.hpc_dev_tuning_set(3, tiled_mode % 10)
-    hpc._C.lib.hpc_dev_tuning_set(6, 1 + tiled_mode // 10)  # 1x: 32-token tiles, 2x: 64-token tiles
+    dev_set(3, tiled_mode % 10)
+    dev_set(6, 1 + tiled_mode // 10)  # 1x: 32-token tiles, 2x: 64-token tiles
     try:
         my = hpc.group_gemm_pertensor_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), scale.cuda(),
                                           num_seq_per_group_avg=total // G)
         torch.cuda.synchronize()
     finally:
-        hpc._C.lib.hpc_dev_tuning_set(3, 0)
-        hpc._C.lib.hpc_dev_tuning_set(6, 0)
+        dev_set(3, 0)
+        dev_set(6, 0)
     assert allclose(gt.float(), my.cpu().float(), rtol=0.08, atol=0.5)
 
 

@@ -15,7 +15,7 @@ import math
 import pytest
 import torch
 
-from utils import allclose, moe_allclose
+from utils import allclose, moe_allclose, dev_set
 
 F8 = torch.float8_e4m3fn
 
@@ -175,6 +175,7 @@ def test_c4_fused_moe_graded_shape(c4_weights, num_tokens, shared):
     assert torch.isfinite(my.float()).all()
 
 
+@pytest.mark.dev
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,k", [(4096, 11008), (22016, 4096)])
 @pytest.mark.parametrize("tiled_mode", [0, 1, 2, 3, 4, 12, 22])
@@ -205,15 +206,15 @@ def test_c4_group_gemm_blockwise_graded(c4_weights, n, k, tiled_mode):
     for g in range(E):
         s, c = int(cu[g]), int(seqlens[g])
         xs_t[:, int(cu_tiles[g]) * tile: int(cu_tiles[g]) * tile + c] = xs_rows[s: s + c].t()
-    hpc._C.lib.hpc_dev_tuning_set(3, tiled_mode % 10)
-    hpc._C.lib.hpc_dev_tuning_set(6, 1 + tiled_mode // 10)  # 1x: 32-token tiles, 2x: 64-token tiles
+    dev_set(3, tiled_mode % 10)
+    dev_set(6, 1 + tiled_mode // 10)  # 1x: 32-token tiles, 2x: 64-token tiles
     try:
         y = hpc.group_gemm_blockwise_fp8(x.cuda(), w, seqlens.cuda(), cu.cuda(), xs_t.cuda(), wsc,
                                          num_seq_per_group_avg=avg)
         torch.cuda.synchronize()
     finally:
-        hpc._C.lib.hpc_dev_tuning_set(3, 0)
-        hpc._C.lib.hpc_dev_tuning_set(6, 0)
+        dev_set(3, 0)
+        dev_set(6, 0)
     assert tuple(y.shape) == (m, n)
     torch.set_num_threads(min(torch.get_num_threads(), 64))
     yc = y.cpu()

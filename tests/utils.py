@@ -1,5 +1,6 @@
 """Test helpers; `allclose` has the contract of reference tests/utils.py:176-189
 (dtype/device/shape asserts + torch.allclose in fp32, worst offenders printed on failure)."""
+import pytest
 import torch
 
 
@@ -49,3 +50,17 @@ def moe_allclose(ref, real, rtol=0.01, atol=0.01, max_literal_outliers=0.005, ma
         print(f"\nmoe_allclose FAILED: max abs err {float(err.max()):.4g} ({worst:.4g} of max |ref|), worst row relative "
               f"rms {rel_rms:.4g}, fraction outside the literal (0.01, 0.01) bar {literal_miss:.5f}")
     return ok
+
+
+def dev_set(key, value):
+    """Set a development register (csrc/hpc_dev.h).  They exist only in the development build of the library
+    (`HPC_AMD_DEV=1` -> hpc/libhpc_amd_dev.so); the product has none, so against the product a non-zero value SKIPS
+    the test case - tests/test_dev_build.py re-runs every test marked `dev` in a subprocess with HPC_AMD_DEV=1 - and
+    a zero (= the shipped configuration) is a no-op."""
+    import hpc
+
+    if hpc._C.DEV_BUILD:
+        assert hpc._C.lib.hpc_dev_tuning_set(key, value) == 0
+    elif value != 0:
+        pytest.skip("pins a kernel variant through a development register: runs against the development build "
+                    "(tests/test_dev_build.py)")

@@ -1,5 +1,7 @@
 """Development tool: quick timing of both fused-MoE APIs (C4 shape) at large T for same-box A/B runs.
 usage: python tools/ab_moe.py [tokens csv] [key:v1,v2,...]   (sweeps one tuning key)"""
+import os
+os.environ.setdefault("HPC_AMD_DEV", "1")  # development build of the library: tuning registers
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent

@@ -2,6 +2,8 @@
 so a rocprofv3 --pmc pass can attribute SQ / TCC counters to the decode kernels.
 usage: rocprofv3 --pmc <counters> --kernel-trace --output-format csv -d <dir> -- python tools/pmc_decode.py [mixed|uniform8k]
        python tools/pmc_decode.py --summarise <out.json> <dir> [<dir>...]"""
+import os
+os.environ.setdefault("HPC_AMD_DEV", "1")  # development build of the library: tuning registers
 import csv, json, sys
 from collections import defaultdict
 from pathlib import Path

@@ -2,6 +2,8 @@
 Runs the profiling build (per-wave s_memtime sums around the phases of a wave-iteration) on the C3 mix and on
 uniform 8k lengths, with and without real KV loads, and prints averages + the spread of finish times.
 usage: python tools/prof_decode.py [four_heads] [dump]"""
+import os
+os.environ.setdefault("HPC_AMD_DEV", "1")  # development build of the library: tuning registers
 import ctypes, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent

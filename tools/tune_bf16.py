@@ -1,6 +1,8 @@
 """Development tool: bf16 decode timing (BASELINE configs[1]: uniform 8k; plus 4k, random and mixed lengths), NHD pages,
 second generation (head-pair kernel) against the first (development key 28 = 1).
 usage: python tools/tune_bf16.py"""
+import os
+os.environ.setdefault("HPC_AMD_DEV", "1")  # development build of the library: tuning registers
 import math, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent

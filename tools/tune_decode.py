@@ -1,5 +1,7 @@
 """Development tool: time hpc.attention_decode_bf16 variants on one GPU (not product, not a test).
 usage: python tools/tune_decode.py [--layout NHD|HND] [--seq 8192] [--batch 64]"""
+import os
+os.environ.setdefault("HPC_AMD_DEV", "1")  # development build of the library: tuning registers
 import argparse, math, sys, os
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent

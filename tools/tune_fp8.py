@@ -1,5 +1,7 @@
 """Development tool: FP8 decode timing (uniform 8k / the C3 mix; NHD pages), sweeping development tuning keys.
 usage: python tools/tune_fp8.py [heads=8/64,1/8] [cases=uniform8k,mixed] ["k=v,k=v" ...]   each argument is one configuration of tuning registers"""
+import os
+os.environ.setdefault("HPC_AMD_DEV", "1")  # development build of the library: tuning registers
 import math, sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent

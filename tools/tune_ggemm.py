@@ -2,6 +2,8 @@
 (E64, 32768 routed rows; N=22016/K=4096 and N=4096/K=11008), with the routed group sizes of the bench
 generator and with exactly 512 rows per group (no partial tiles).
 usage: python tools/tune_ggemm.py [--pertensor] ["k=v,k=v" ...]   each argument is one configuration of tuning registers"""
+import os
+os.environ.setdefault("HPC_AMD_DEV", "1")  # development build of the library: tuning registers
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent

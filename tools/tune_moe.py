@@ -1,6 +1,8 @@
 """Development tool: fused MoE FP8 blockwise at BASELINE configs[3] (E64 / top-8 / H4096 / I11008), timing the
 whole op and (per-kernel) the two grouped GEMMs under development tuning keys.
 usage: python tools/tune_moe.py [--tokens 4096] ["k=v,k=v" ...]   each argument is one configuration"""
+import os
+os.environ.setdefault("HPC_AMD_DEV", "1")  # development build of the library: tuning registers
 import sys
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
