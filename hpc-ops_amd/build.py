@@ -103,31 +103,44 @@ SHIM_DEV = ROOT / "hpc" / "_hpc_torch_dev.so"
 
 
 def build_torch_shim(force: bool = False, dev: bool = False):
-    """hpc/_hpc_torch.so: the C++ host side (csrc/torch_binding.cpp: TORCH_LIBRARY_FRAGMENT(hpc) registrations of the
-    hot-path ops + the MulticastCommunicator torch class) on top of the C-ABI.  Host-only C++ compiled by g++ against
-    the installed torch headers - the reference registers its ops the same way (src/*/entry.cc).  Returns the path, or
-    None when torch's headers are not available (the Python entries in hpc/_entry_*.py then serve every op)."""
-    try:
-        import torch
-        from torch.utils import cpp_extension as ce
-    except Exception:  # noqa: BLE001
-        return None
-    src = CSRC / "torch_binding.cpp"
+    """hpc/_hpc_torch.so: the C++ host side (csrc/torch_*.cpp: TORCH_LIBRARY(hpc) + the registration of every op + the
+    MulticastCommunicator torch class) on top of the C-ABI.  Host-only C++ compiled by g++ against the installed torch
+    headers - the reference registers its ops the same way (src/*/entry.cc).  The objects do not depend on which
+    C-ABI library they are linked against, so the development shim re-links the same objects."""
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    srcs = sorted(CSRC.glob("torch_*.cpp"))
     shim, lib = (SHIM_DEV, LIB_DEV) if dev else (SHIM, LIB)
-    deps = [src, INCLUDE / "hpc_amd.h", Path(__file__)]
+    deps = srcs + [CSRC / "torch_common.h", INCLUDE / "hpc_amd.h", Path(__file__)]
     if not force and shim.exists() and all(d.stat().st_mtime <= shim.stat().st_mtime for d in deps) \
             and shim.stat().st_mtime >= lib.stat().st_mtime:
         return shim
     tlib = Path(ce.library_paths()[0])
     abi = int(getattr(torch._C, "_GLIBCXX_USE_CXX11_ABI", True))
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
-           f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-w"]
-    cmd += ["-I" + p for p in ce.include_paths()] + ["-I/opt/rocm/include", "-I" + str(INCLUDE)]
-    cmd += [str(src), "-o", str(shim), "-L" + str(tlib), "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip",
+    cc = ["g++", "-O2", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+          f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-w"]
+    cc += ["-I" + p for p in ce.include_paths()] + ["-I/opt/rocm/include", "-I" + str(INCLUDE), "-I" + str(CSRC)]
+    (OBJ / "torch").mkdir(parents=True, exist_ok=True)
+
+    def one(src):
+        obj = OBJ / "torch" / (src.stem + ".o")
+        if not force and obj.exists() and all(d.stat().st_mtime <= obj.stat().st_mtime
+                                              for d in (src, CSRC / "torch_common.h", INCLUDE / "hpc_amd.h", Path(__file__))):
+            return obj
+        r = subprocess.run(cc + ["-c", str(src), "-o", str(obj)], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("torch shim build failed (%s):\n%s\n%s" % (src.name, r.stdout[-3000:], r.stderr[-3000:]))
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=len(srcs)) as ex:
+        objs = list(ex.map(one, srcs))
+    cmd = ["g++", "-shared", "-fPIC", "-o", str(shim)] + [str(o) for o in objs]
+    cmd += ["-L" + str(tlib), "-ltorch", "-ltorch_cpu", "-ltorch_hip", "-lc10", "-lc10_hip",
             "-L" + str(lib.parent), "-l:" + lib.name, "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + str(tlib)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("torch shim build failed:\n%s\n%s" % (r.stdout[-3000:], r.stderr[-3000:]))
+        raise RuntimeError("torch shim link failed:\n%s\n%s" % (r.stdout[-3000:], r.stderr[-3000:]))
     return shim
 
 

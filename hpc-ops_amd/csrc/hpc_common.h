@@ -55,17 +55,21 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 __device__ __forceinline__ float clamp_e4m3(float x) {
   return __builtin_fminf(__builtin_fmaxf(x, -448.0f), 448.0f);
 }
-// A NaN leaves as the CANONICAL positive quiet NaN: v_cvt_pk_fp8_f32 keeps the sign bit of a NaN (a NaN that went
-// through a multiply came out as 0xff on gfx950), the reference's cast and torch's give 0x7f.
 __device__ __forceinline__ float clamp_e4m3_nan(float x) {
   const float c = __builtin_fminf(__builtin_fmaxf(x, -448.0f), 448.0f);
-  return x != x ? __builtin_bit_cast(float, 0x7fc00000u) : c;
+  return x != x ? x : c;
+}
+// A NaN leaves as the byte 0x7f, like the reference's cast (cvt.rn.satfinite.e4m3x2.f32) and torch's: on gfx950
+// v_cvt_pk_fp8_f32 was observed to turn a (positive, quiet) NaN into 0xff - the other NaN encoding of e4m3fn.
+__device__ __forceinline__ uint32_t e4m3_nan_byte(uint32_t packed, float x, int shift) {
+  return x != x ? (packed & ~(0xffu << shift)) | (0x7fu << shift) : packed;
 }
 // packs (a, b) into the low 16 bits of the result.
 __device__ __forceinline__ uint32_t cvt_pk_e4m3(float a, float b) {
-  return static_cast<uint32_t>(
-             __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3_nan(a), clamp_e4m3_nan(b), 0, false)) &
-         0xffffu;
+  const uint32_t r = static_cast<uint32_t>(
+                         __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3_nan(a), clamp_e4m3_nan(b), 0, false)) &
+                     0xffffu;
+  return e4m3_nan_byte(e4m3_nan_byte(r, a, 0), b, 8);
 }
 // probabilities (never NaN): the cheap clamp
 __device__ __forceinline__ uint32_t cvt_4xe4m3(float a, float b, float c, float d) {
@@ -77,7 +81,7 @@ __device__ __forceinline__ uint32_t cvt_4xe4m3(float a, float b, float c, float 
 __device__ __forceinline__ uint32_t quant_4xe4m3(float a, float b, float c, float d) {
   int r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3_nan(a), clamp_e4m3_nan(b), 0, false);
   r = __builtin_amdgcn_cvt_pk_fp8_f32(clamp_e4m3_nan(c), clamp_e4m3_nan(d), r, true);
-  return static_cast<uint32_t>(r);
+  return e4m3_nan_byte(e4m3_nan_byte(e4m3_nan_byte(e4m3_nan_byte(static_cast<uint32_t>(r), a, 0), b, 8), c, 16), d, 24);
 }
 // byte `sel` (0..3) of w -> f32
 template <int kSel>

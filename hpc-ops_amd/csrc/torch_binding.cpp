@@ -1,46 +1,25 @@
-// C++ host side of the hot-path ops: TORCH_LIBRARY_FRAGMENT(hpc, ...) registrations + the
-// MulticastCommunicator torch class, on top of the C-ABI of include/hpc_amd.h (libhpc_amd.so).
+// C++ host side, part 1: the library definition, version / built_json, the decode-attention ops and the scheduler,
+// the blockwise fused MoE, RMSNorm + quant, and the MulticastCommunicator torch class - on top of the C-ABI of
+// include/hpc_amd.h (libhpc_amd.so).  Parts 2-4: torch_moe.cpp, torch_prefill.cpp, torch_misc.cpp.  Together they
+// register EVERY op of the package from C++, like the reference does (src/*/entry.cc TORCH_LIBRARY_FRAGMENT blocks):
+// there are no Python-side op implementations.
 //
-// Mirrors the reference's registration blocks - src/attention/entry.cc:822-874 (decode ops + scheduler),
-// src/fuse_moe/entry.cc:644-684 (fuse_moe_blockwise[_fp8]), src/normalization/entry.cc:59-65,
-// src/communicator/entry.cc:79-90 (m.class_<MulticastCommunicator>) - with the same schemas, check messages
-// (TORCH_CHECK -> RuntimeError) and ownership rules (outputs allocated here unless the caller passes one; scratch
-// from the caching allocator).  Built in-tree by hpc-ops_amd/build.py into hpc/_hpc_torch.so and loaded by
-// hpc/_C.py with torch.ops.load_library; the Python entries (hpc/_entry_*.py) stay as the fallback for every op
-// this file does not register and for builds without the torch headers.  No kernels here: host code only.
-#include <ATen/ATen.h>
-#include <c10/hip/HIPStream.h>
+// Mirrors the reference's registration blocks - src/C/C.cc:5 (TORCH_LIBRARY(hpc, m)), src/C/version.cc, built_json.cu,
+// src/attention/entry.cc:822-874 (decode ops + scheduler), src/fuse_moe/entry.cc:644-684 (fuse_moe_blockwise[_fp8]),
+// src/normalization/entry.cc:59-65, src/communicator/entry.cc:79-90 (m.class_<MulticastCommunicator>) - with the same
+// schemas, check messages (TORCH_CHECK -> RuntimeError) and ownership rules (outputs allocated here unless the caller
+// passes one; scratch from the caching allocator).  Built in-tree by hpc-ops_amd/build.py into hpc/_hpc_torch.so and
+// loaded by hpc/_C.py with torch.ops.load_library.  No kernels here: host code only.
 #include <torch/custom_class.h>
-#include <torch/library.h>
 
 #include <map>
 #include <mutex>
-#include <string>
-#include <tuple>
-#include <vector>
 
-#include "hpc_amd.h"
+#include "torch_common.h"
+
+using namespace hpc_torch;
 
 namespace {
-
-hpc_stream_t stream_of(const at::Tensor& t) {
-  // reference: at::cuda::getCurrentCUDAStream(tensor.device) - the current stream of the tensor's device
-  return reinterpret_cast<hpc_stream_t>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
-}
-
-const char* err_text(int code) {
-  switch (code) {
-    case -1: return "unsupported configuration";
-    case -2: return "invalid argument";
-    case -3: return "HIP launch error";
-    case -4: return "an earlier fused all-reduce timed out waiting for a peer";
-    default: return "error";
-  }
-}
-#define HPC_LAUNCH_CHECK(rc, what) TORCH_CHECK((rc) == 0, what, " launch failed! (", err_text(rc), ")")
-
-void* ptr(const at::Tensor& t) { return t.data_ptr(); }
-void* ptr(const c10::optional<at::Tensor>& t) { return t.has_value() ? t->data_ptr() : nullptr; }
 
 // ---- decode attention ---------------------------------------------------------------------------------------
 // Scratch of a decode call: [arrival counters (zero on first use, left zero by every call) | partials].  One
@@ -283,11 +262,6 @@ at::Tensor attention_decode_fp8(const at::Tensor& q, at::Tensor& kcache, at::Ten
 }
 
 // ---- fused MoE, blockwise FP8 (reference fuse_moe_blockwise_entry, src/fuse_moe/entry.cc:445-560) -------------------
-void cuda_contig(const at::Tensor& t, const char* name) {
-  TORCH_CHECK(t.is_cuda(), name, " tensor must be cuda");
-  TORCH_CHECK(t.is_contiguous(), name, " tensor must be contiguous");
-}
-
 at::Tensor fuse_moe_blockwise(const at::Tensor& x, const at::Tensor& x_scale, const at::Tensor& gate_up_weight,
                               const at::Tensor& gate_up_weight_scale, const at::Tensor& down_weight,
                               const at::Tensor& down_weight_scale, const at::Tensor& topk_ids, const at::Tensor& topk_scale,
@@ -416,7 +390,10 @@ struct MulticastCommunicator : torch::CustomClassHolder {
 
 }  // namespace
 
-TORCH_LIBRARY_FRAGMENT(hpc, m) {
+TORCH_LIBRARY(hpc, m) {
+  // reference src/C/version.cc:14, src/C/built_json.cu:45
+  m.def("version", []() { return std::string(hpc_version()); });
+  m.def("built_json", []() { return std::string(hpc_built_json()); });
   m.def(
       "assign_attention_decode_task(Tensor num_seq_kvcache, int num_head_kv, int num_seq_q, bool new_kv_included, "
       "int min_process_len, Tensor? task_map) -> (Tensor)");
@@ -437,11 +414,6 @@ TORCH_LIBRARY_FRAGMENT(hpc, m) {
       "int num_expert_total, Tensor ? output) -> (Tensor)");
   m.def("fused_rmsnorm_with_scale(Tensor input, Tensor weight, Tensor scale, float eps, bool is_moe) -> (Tensor, Tensor, Tensor)");
   m.def("_release_decode_workspaces() -> ()", []() { release_decode_workspaces(); });
-  // names of the ops registered natively: hpc/_C.py skips their Python definitions
-  m.def("_native_ops() -> str[]", []() {
-    return std::vector<std::string>{"assign_attention_decode_task", "attention_decode_bf16", "attention_decode_fp8",
-                                    "fuse_moe_blockwise_fp8", "fuse_moe_blockwise", "fused_rmsnorm_with_scale"};
-  });
   m.class_<MulticastCommunicator>("MulticastCommunicator")
       .def(torch::init<int64_t, int64_t, int64_t, std::string>(), "",
            {torch::arg("rank"), torch::arg("world_size"), torch::arg("device_id") = -1, torch::arg("comm_name") = "hpc_comm"})

@@ -2,9 +2,8 @@
 
 Plays the role of the reference's `hpc/_C.abi3.so` + `torch.ops.load_library`
 (reference hpc/__init__.py:43-45): it opens the in-tree shared library with ctypes, declares the
-argument types of every `extern "C"` entry point, and owns the `torch.library.Library("hpc")`
-object on which the per-module `_entry_*.py` files register the reference's op schemas
-(reference src/*/entry.cc TORCH_LIBRARY_FRAGMENT blocks).
+argument types of every `extern "C"` entry point (tests and tools call the C-ABI directly through them), and
+loads the C++ host library that registers the ops (reference src/*/entry.cc TORCH_LIBRARY_FRAGMENT blocks).
 
 There is NO fallback: if the library is missing or an entry point is absent, import fails loudly.
 """
@@ -111,40 +110,13 @@ _sig("hpc_fuse_allreduce_rmsnorm_low_latency_async", I, P, P, P, P, P, P, P, P, 
 _sig("hpc_allreduce_timeouts", I)
 _sig("hpc_allreduce_reset_timeouts", I)
 
-# C++ host side of the hot-path ops (csrc/torch_binding.cpp -> hpc/_hpc_torch.so): TORCH_LIBRARY_FRAGMENT(hpc)
-# registrations + torch.classes.hpc.MulticastCommunicator, like the reference's src/*/entry.cc.  When it is present
-# its ops are the ones that run; the Python entries below it (hpc/_entry_*.py) register everything else and are the
-# fallback for a build without the torch headers (HPC_AMD_PY_ENTRIES=1 forces them, for the tests of that fallback).
+# C++ host side (csrc/torch_*.cpp -> hpc/_hpc_torch.so): TORCH_LIBRARY(hpc) with EVERY op of the package registered
+# from C++ (+ torch.classes.hpc.MulticastCommunicator), like the reference's src/*/entry.cc -> hpc/_C.abi3.so.  There are
+# no Python-side op implementations: the public modules (hpc/*.py) only wrap torch.ops.hpc.* and register fakes.
 _SHIM_PATH = Path(__file__).resolve().parent / ("_hpc_torch_dev.so" if DEV_BUILD else "_hpc_torch.so")
-NATIVE_OPS = frozenset()
-if _SHIM_PATH.exists() and os.environ.get("HPC_AMD_PY_ENTRIES", "0") != "1":
-    try:
-        torch.ops.load_library(str(_SHIM_PATH))
-        NATIVE_OPS = frozenset(torch.ops.hpc._native_ops())
-    except OSError as exc:  # stale / ABI-mismatched shim (built against another torch): the Python entries serve every op
-        import warnings
-
-        warnings.warn(f"hpc: {_SHIM_PATH.name} could not be loaded ({exc}); falling back to the Python entries - "
-                      "rebuild with `python hpc-ops_amd/build.py --force`")
-
-
-class _OpLibrary:
-    """torch.library.Library("hpc") that leaves the ops the C++ shim has registered alone."""
-
-    def __init__(self):
-        # (reference: TORCH_LIBRARY(hpc, m), src/C/C.cc:5)
-        self._lib = torch.library.Library("hpc", "DEF")
-
-    def define(self, schema: str):
-        if schema.split("(", 1)[0].strip() not in NATIVE_OPS:
-            self._lib.define(schema)
-
-    def impl(self, name, fn, key):
-        if name not in NATIVE_OPS:
-            self._lib.impl(name, fn, key)
-
-
-torch_lib = _OpLibrary()
+if not _SHIM_PATH.exists():
+    raise ImportError(f"{_SHIM_PATH} not found: build it first with `python hpc-ops_amd/build.py`")
+torch.ops.load_library(str(_SHIM_PATH))
 
 _ERR = {-1: "unsupported configuration", -2: "invalid argument", -3: "HIP launch error",
         -4: "an earlier fused all-reduce timed out waiting for a peer: results since then are undefined, "
@@ -185,10 +157,3 @@ def cu_count(device=None) -> int:
 def require(cond: bool, msg: str) -> None:
     if not cond:
         raise RuntimeError(msg)
-
-
-# version / built_json ops (reference src/C/version.cc, src/C/built_json.cu)
-torch_lib.define("version() -> str")
-torch_lib.define("built_json() -> str")
-torch_lib.impl("version", lambda: lib.hpc_version().decode(), "CompositeExplicitAutograd")
-torch_lib.impl("built_json", lambda: lib.hpc_built_json().decode(), "CompositeExplicitAutograd")

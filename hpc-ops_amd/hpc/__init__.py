@@ -14,7 +14,7 @@ import torch
 from . import _C  # loads libhpc_amd.so or raises - there is no fallback path
 
 __all__ = []
-for _src in sorted(Path(__file__).parent.glob("[!_]*.py")):  # _C / _entry_* come in through the public modules
+for _src in sorted(Path(__file__).parent.glob("[!_]*.py")):  # _C comes in through the public modules
     _mod = importlib.import_module(f"{__name__}.{_src.stem}")
     for _name, _obj in vars(_mod).items():
         if callable(_obj) and not _name.startswith("_"):

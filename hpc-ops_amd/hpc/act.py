@@ -5,7 +5,7 @@ from typing import Optional, Tuple
 import torch
 from torch import Tensor
 
-from . import _entry_fuse_moe  # noqa: F401
+from . import _C  # noqa: F401  (loads the libraries that register torch.ops.hpc.*)
 
 
 def act_mul_and_quant(gate_up: Tensor, scale: Tensor, use_bf16_mul: bool = True,

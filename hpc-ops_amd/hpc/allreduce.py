@@ -3,7 +3,7 @@ from typing import Any, Optional, Sequence, Tuple
 
 import torch
 
-from . import _entry_allreduce  # noqa: F401
+from . import _C  # noqa: F401  (loads the libraries that register torch.ops.hpc.*)
 from .multicast_handle import MulticastHandle
 
 

@@ -10,7 +10,7 @@ import torch
 from torch import Tensor
 
 from . import _C
-from . import _entry_attention as _entry
+from . import _C
 
 
 class QuantType(Enum):
@@ -100,9 +100,36 @@ def get_attention_decode_task_workspace(
     """
     dev = torch.device("cuda", torch.cuda.current_device())
     num_cu = torch.cuda.get_device_properties(dev).multi_processor_count
-    return _entry._alloc_task_workspace(
-        dev, num_cu, max_num_batch, max_seqlen, num_head_kv, min_process_len
-    )
+    total, sched = task_workspace_bytes(num_cu, max_num_batch, max_seqlen, num_head_kv, min_process_len)
+    ws = torch.zeros(total, dtype=torch.int8, device=dev)
+    hdr = ws.view(torch.int32)
+    hdr[2] = num_head_kv
+    hdr[3] = max_num_batch
+    hdr[4] = sched
+    return ws
+
+
+def task_workspace_bytes(num_cu, max_num_batch, max_seqlen, num_head_kv, min_process_len):
+    """Byte size + scheduler byte size of the task-map workspace; same arithmetic as reference
+    hpc/attention.py:540-571 (sized for up to 4 bins per CU, so any gfx950 bin count fits)."""
+    k_task, k_max_cta, k_tile = 48, 4, 64
+    max_cta = num_cu * k_max_cta
+    total_tiles = max_num_batch * num_head_kv * ((max_seqlen + k_tile - 1) // k_tile)
+    max_tasks = 0
+    for cta_per_cu in (4, 3, 2, 1):
+        ctas = num_cu * cta_per_cu
+        per = max((total_tiles + ctas - 1) // ctas, min_process_len // k_tile)
+        max_tasks = max(max_tasks, (per + 1) * ctas + 1)
+    chunk_bytes = (max_num_batch * num_head_kv * 4 + k_task - 1) // k_task * k_task
+    cta_pad = (max_cta + 11) // 12 * 12 * 4
+    sched = max_tasks * k_task + chunk_bytes
+    return sched + 2 * cta_pad, sched
+
+
+def release_decode_workspaces():
+    """Drop the decode scratch buffers the host library caches per (device, stream, hipGraph capture) - e.g. after the
+    streams / graphs that used them are gone."""
+    torch.ops.hpc._release_decode_workspaces()
 
 
 def assign_attention_decode_task(

@@ -2,7 +2,7 @@
 import torch
 from torch import Tensor
 
-from . import _entry_fuse_moe  # noqa: F401  (registers the ops)
+from . import _C  # noqa: F401  (loads the libraries that register torch.ops.hpc.*)
 
 
 def reduce(x: Tensor, topk_pos: Tensor, topk_scale: Tensor, shared_output: Tensor = None) -> Tensor:

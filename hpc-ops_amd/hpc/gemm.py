@@ -2,7 +2,7 @@
 import torch
 from torch import Tensor
 
-from . import _entry_gemm  # noqa: F401
+from . import _C  # noqa: F401  (loads the libraries that register torch.ops.hpc.*)
 
 
 def get_gemm_bf16xfp32_workspace(max_weight_hidden_size: int, max_tokens: int = 131072) -> Tensor:

@@ -2,7 +2,16 @@
 import torch
 from torch import Tensor
 
-from . import _entry_fuse_moe  # noqa: F401
+from . import _C  # noqa: F401  (loads the libraries that register torch.ops.hpc.*)
+
+
+def aligned_size(avg: int) -> int:
+    """tileM ladder of the reference (src/fuse_moe/entry.cc:525-543): defines the tile-padded column layout of
+    transposed x_scale tensors (group g starts at column cu_tiles[g] * tileM)."""
+    for lim, val in ((8, 8), (16, 16), (32, 32), (48, 48), (64, 64), (96, 48), (128, 32), (144, 48)):
+        if avg <= lim:
+            return val
+    return 64
 
 
 def group_gemm_blockwise_fp8(

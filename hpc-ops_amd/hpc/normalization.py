@@ -4,7 +4,7 @@ from typing import Tuple, Union
 import torch
 from torch import Tensor
 
-from . import _entry_normalization  # noqa: F401  (registers torch.ops.hpc.fused_rmsnorm_with_scale)
+from . import _C  # noqa: F401  (loads the libraries that register torch.ops.hpc.*)
 
 _F8 = torch.float8_e4m3fn
 

@@ -4,7 +4,7 @@ from typing import Optional, Tuple
 import torch
 from torch import Tensor
 
-from . import _entry_rope  # noqa: F401
+from . import _C  # noqa: F401  (loads the libraries that register torch.ops.hpc.*)
 
 
 def rope_norm_store_kv(

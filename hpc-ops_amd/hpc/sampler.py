@@ -5,7 +5,7 @@ from typing import Optional, Tuple, Union
 import torch
 from torch import Tensor
 
-from . import _entry_sampler  # noqa: F401
+from . import _C  # noqa: F401  (loads the libraries that register torch.ops.hpc.*)
 
 
 class SoftmaxPolicy(IntEnum):

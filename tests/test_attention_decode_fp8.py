@@ -269,7 +269,7 @@ def test_attn_fp8_two_graphs_captured_before_any_replay():
     import hpc
     from oracle import attention as oattn
 
-    hpc._entry_attention.release_decode_workspaces()
+    hpc.release_decode_workspaces()
     cases = []
     for num_batch, hi, seed in ((6, 30000, 1), (9, 20000, 2)):
         torch.manual_seed(seed)
@@ -297,4 +297,4 @@ def test_attn_fp8_two_graphs_captured_before_any_replay():
         graphs[i].replay()
         torch.cuda.synchronize()
         assert allclose(cases[i][1], cases[i][0]["out"].cpu(), atol=0.2), i
-    hpc._entry_attention.release_decode_workspaces()
+    hpc.release_decode_workspaces()

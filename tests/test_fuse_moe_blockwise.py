@@ -136,7 +136,7 @@ def test_group_gemm_blockwise_is_the_reference_kernel_arithmetic(tiled_mode, n, 
     cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
     want = omoe.group_gemm_blockwise_kernel_arith(x, w, seqlens, cu, xs_rows, wscale)
     avg = total // num_group
-    tile_m = hpc._entry_fuse_moe.aligned_size(avg)
+    tile_m = hpc.aligned_size(avg)
     tiles = (seqlens + tile_m - 1) // tile_m
     cu_tiles = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(tiles, 0)])
     xs_t = torch.zeros((kb, int(cu_tiles[-1]) * tile_m + 64))
@@ -256,7 +256,7 @@ def test_group_gemm_blockwise(num_group, actual_m, n, k, forced_mt):
     cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
     gt = omoe.group_gemm_blockwise(x, w, seqlens, cu, xs_rows, wscale)
     # reference layout: [K/128, m_pad_total], group g at column cu_tiles[g]*tileM
-    tile_m = hpc._entry_fuse_moe.aligned_size(actual_m)
+    tile_m = hpc.aligned_size(actual_m)
     tiles = (seqlens + tile_m - 1) // tile_m
     cu_tiles = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(tiles, 0)])
     xs_t = torch.zeros((kb, int(cu_tiles[-1]) * tile_m + 64))
@@ -311,7 +311,7 @@ def test_group_gemm_blockwise_tiled_kernels(tiled_mode, n, k):
     cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
     gt = omoe.group_gemm_blockwise(x, w, seqlens, cu, xs_rows, wscale)
     avg = total // num_group
-    tile_m = hpc._entry_fuse_moe.aligned_size(avg)
+    tile_m = hpc.aligned_size(avg)
     tiles = (seqlens + tile_m - 1) // tile_m
     cu_tiles = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(tiles, 0)])
     xs_t = torch.zeros((kb, int(cu_tiles[-1]) * tile_m + 64))
@@ -358,7 +358,7 @@ def test_group_gemm_blockwise_many_groups(tiled_mode, num_group):
     cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
     gt = omoe.group_gemm_blockwise(x, w, seqlens, cu, xs_rows, wscale)
     avg = total // num_group
-    tile_m = hpc._entry_fuse_moe.aligned_size(avg)
+    tile_m = hpc.aligned_size(avg)
     tiles = (seqlens + tile_m - 1) // tile_m
     cu_tiles = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(tiles, 0)])
     xs_t = torch.zeros((kb, int(cu_tiles[-1]) * tile_m + 64))

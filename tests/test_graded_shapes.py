@@ -197,7 +197,7 @@ def test_c4_group_gemm_blockwise_graded(c4_weights, n, k, tiled_mode):
     m = int(seqlens.sum())
     avg = m // E
     x = (torch.randn(m, k) / 10).to(F8)
-    tile = hpc._entry_fuse_moe.aligned_size(avg)
+    tile = hpc.aligned_size(avg)
     tiles = (seqlens + tile - 1) // tile
     cu_tiles = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(tiles, 0).to(torch.int32)])
     m_pad = int(cu_tiles[-1]) * tile + 64

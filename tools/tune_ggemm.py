@@ -23,7 +23,7 @@ def case(seqlens, wt, wsc):
     n, k = wt.shape[1], wt.shape[2]
     cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
     avg = M // E
-    tile = hpc._entry_fuse_moe.aligned_size(avg)
+    tile = hpc.aligned_size(avg)
     tiles = (seqlens + tile - 1) // tile
     m_pad = int(tiles.sum()) * tile + 64
     x = (torch.randn(M, k, device=dev) / 10).to(F8)
