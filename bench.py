@@ -210,7 +210,7 @@ def c3_cpu_baseline(inp, w=C3, rows=None):
     bounded sample of the same workload."""
     from oracle import attention as oattn
 
-    cores = min(os.cpu_count() or 1, 32)  # more threads than this only adds contention for this op
+    cores = os.cpu_count() or 1  # BASELINE.md section 4: the host cores of the box, count stated
     torch.set_num_threads(cores)
     rows = list(range(w["batch"])) if rows is None else rows  # every request: ~5 s on 32 threads, and the parity
     # check of the timed output covers the whole batch
@@ -259,7 +259,7 @@ def c4_flops(T, w=C4):
     return 2.0 * T * w["topk"] * (2 * w["inter"] * w["hidden"] + w["hidden"] * w["inter"])
 
 
-def c4_parity(m, y, w=C4, nrows=4):
+def c4_parity(m, y, w=C4, nrows=64):
     """sampled token rows of the timed op's output against the CPU oracle, expert weights streamed from the
     device one expert at a time (oracle/fuse_moe.py::fuse_moe_blockwise_fp8_rows); reference tolerance
     rtol = atol = 0.01 (tests/test_fuse_moe_blockwise.py:333)."""
@@ -286,7 +286,7 @@ def c4_cpu_baseline(m, w=C4):
     gate_up GEMM -> SiLU*up + 128-block quant -> down GEMM with the oracle's stage functions."""
     from oracle import fuse_moe as omoe
 
-    cores = min(os.cpu_count() or 1, 64)
+    cores = os.cpu_count() or 1  # BASELINE.md section 4: the host cores of the box, count stated
     torch.set_num_threads(cores)
     ids = m["ids"].cpu()
     counts = torch.bincount(ids.flatten().long(), minlength=w["num_expert"])
@@ -331,7 +331,7 @@ def moe_block(dev, hpc, with_cpu=True, iters=10):
     us_eager = timed(step, iters=iters, warm=1)
     flops = c4_flops(T, w)
     tf = flops / us / 1e6
-    pmc = ROOT / "profiles" / "moe_tiled_gemm_pmc_r2.json"
+    pmc = ROOT / "profiles" / "moe_tiled_gemm_pmc_r4.json"  # rocprofv3 --pmc pass over the kernels that ship (tools/round4_profiles.sh)
     mfma_busy = json.loads(pmc.read_text()).get("mfma_busy_frac") if pmc.exists() else None
     out = {
         "metric": "fuse_moe_blockwise_fp8_tflops", "value": round(tf, 1), "unit": "TFLOP/s", "dtype": "fp8_e4m3",
@@ -980,10 +980,12 @@ def main():
         # committed rocprofv3 --pmc passes over this same command (tools/round3_profiles.sh); the file records the
         # commit it was taken at so that a stale figure is visible
         traffic, traffic_src = None, None
-        pmc = ROOT / "profiles" / "decode_fp8_pmc.json"
+        pmc = ROOT / "profiles" / "decode_fp8_pmc_r4.json"
+        if not pmc.exists():
+            pmc = ROOT / "profiles" / "decode_fp8_pmc.json"
         if pmc.exists():
             pj = json.loads(pmc.read_text())
-            traffic, traffic_src = pj.get("hbm_bytes_per_launch"), f"profiles/decode_fp8_pmc.json ({pj.get('taken_at', 'round 2 kernel')})"
+            traffic, traffic_src = pj.get("hbm_bytes_per_launch"), f"profiles/{pmc.name} ({pj.get('taken_at', 'round 2 kernel')})"
         ar_key = f"fuse_allreduce_rmsnorm_bf16_H8192_ws{world}"
         line = {
             "metric": "attention_decode_fp8_kv_throughput", "value": round(value, 1), "unit": "GB/s",

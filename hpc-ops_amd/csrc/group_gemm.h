@@ -30,6 +30,7 @@ struct Args {
   // the bf16-rounded multiply of the reference when use_bf16_mul (reference src/activation/activation.cu:19-75)
   const float* act_mul_scale = nullptr;
   int use_bf16_mul = 0;
+  int no_half_tile = 0;  // development (key 21 = 1): the 256 x 256 kernel never takes its half-tile body
 };
 
 }  // namespace ggemm

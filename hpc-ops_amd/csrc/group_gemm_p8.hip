@@ -134,27 +134,22 @@ __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, co
 // tests/test_fuse_moe_blockwise.py::test_group_gemm_blockwise_is_the_reference_kernel_arithmetic).  Round 3 shipped
 // a cheaper form (running sums kept in units of the current block's scale, tot' = tot / f_T: +2-6 %): it rounds
 // differently from the reference kernel and clamped tiny scales - removed in round 4, parity first.
-template <bool kHasXs, bool kNoDma = false, bool kAct = false>
-__global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, const int* __restrict__ cu_tiles,
-                                                                  int num_group) {
-  __shared__ __attribute__((aligned(1024))) uint8_t s_mem[kLds];
-
+// kHalf: the HALF-TILE body for a group's last token tile when it holds <= 128 rows (at 512 +- 22 routed rows per
+// expert half the groups end in a third 256-row tile for a dozen rows).  The rows sit in the EARLY 32 slots of every
+// strip - tile row r -> slot (r / 32) * 64 + r % 32 - so the late-token unit (U2) is never fetched, its operand reads
+// and the MFMAs of token blocks 2-3 do not exist: 16 instead of 32 MFMAs, 20 instead of 24 operand reads and 6-7
+// instead of 8-9 DMA pieces per wave and k-tile, and in the fused activation epilogue group 0 finishes everything.
+// The weight units are what they are: a tail tile still re-streams its 256 weight rows.
+template <bool kHasXs, bool kNoDma, bool kAct, bool kHalf>
+__device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, int mt0, int n0, int m_cnt, int m0) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g4 = lane >> 4;
   const int wn = wave >> 2, wm = wave & 3;  // group (weight-row half) / 64-token strip
-
-  const int nt = a.N / kBN;  // kAct: N = 2 * inter, tile tn = columns [tn * 128, +128) of gate and of up
-  const Item it = locate_item(as_const(cu_tiles), a.seqlens, a.cu_seqlens, num_group, nt, lane, blockIdx.x);
-  if (!it.valid) return;
-  const int e = __builtin_amdgcn_readfirstlane(it.e);
-  const int rem = __builtin_amdgcn_readfirstlane(it.rem);
-  const int mtiles = __builtin_amdgcn_readfirstlane(it.mtiles);
-  const int m_cnt = __builtin_amdgcn_readfirstlane(it.m_cnt);
-  const int m0 = __builtin_amdgcn_readfirstlane(it.m0);
-  const int mt0 = (rem % mtiles) * kBM;
-  const int n0 = (rem / mtiles) * kBN;
   const int K = a.K, KB = a.KB;
+  constexpr int kJ = kHalf ? 2 : 4;  // token blocks per strip
+  // tile-local token slot (strip * 64 + 16 j + r) -> row of the tile
+  auto row_of_slot = [](int slot) { return kHalf ? (slot >> 6) * 32 + (slot & 31) : slot; };
 
   // ---- DMA roles: two 8-row pieces of every unit per wave --------------------------------------------------
   // piece pc = wave * 2 + q covers unit rows pc*8 .. +8; lane -> row lane/8, LDS position lane%8 <- source
@@ -198,8 +193,9 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   for (int q = 0; q < 2; ++q) {
     const int ur = (wave * 2 + q) * 8 + p_row;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int slot = mt0 + (ur >> 5) * 64 + (ur & 31) + u * 32;
+    for (int u = 0; u < (kHalf ? 1 : 2); ++u) {
+      // unit row ur of the early (u = 0) / late (u = 1) token unit = tile slot (ur / 32) * 64 + ur % 32 + 32 u
+      const int slot = mt0 + (kHalf ? ur : (ur >> 5) * 64 + (ur & 31) + u * 32);
       const int sc = slot < m_cnt ? slot : m_cnt - 1;
       const int xrow = a.row_index ? a.row_index[m0 + sc] : m0 + sc;
       x_voff[u][q] = static_cast<unsigned>(xrow) * static_cast<unsigned>(K) + p_chunk * 16;
@@ -207,7 +203,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   }
   unsigned xs_voff = 0;
   if constexpr (kHasXs) {
-    const int slot = mt0 + (wave & 3) * 64 + lane;
+    const int slot = mt0 + row_of_slot((wave & 3) * 64 + lane);  // (half tile: lanes 32-63 fetch scales nobody reads)
     const int sc = slot < m_cnt ? slot : m_cnt - 1;
     const long col0 = a.col_base ? static_cast<long>(as_const(a.col_base)[e]) * a.tile_m : 0;
     const long term = a.col_base ? col0 + sc : static_cast<long>(a.row_index ? a.row_index[m0 + sc] : m0 + sc);
@@ -275,8 +271,8 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
                      const float (&f)[4], f32x4 (&tail)[2], auto&& hook) {
     f32x4 prev1 = {0.f, 0.f, 0.f, 0.f}, prev2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int n = 0; n < 16; ++n) {
-      const int i = n >> 2, j = n & 3;
+    for (int n = 0; n < 4 * kJ; ++n) {
+      const int i = n / kJ, j = n % kJ;
       const u32x4(&bf)[2] = j < 2 ? be[j] : bl[j - 2];
       const i32x8 av = {static_cast<int>(af[i][0][0]), static_cast<int>(af[i][0][1]), static_cast<int>(af[i][0][2]),
                         static_cast<int>(af[i][0][3]), static_cast<int>(af[i][1][0]), static_cast<int>(af[i][1][1]),
@@ -289,7 +285,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
                                                                             0, 0);
         __builtin_amdgcn_sched_barrier(0);  // MFMA n first, then the rescale of block n - 2
         if (n > 1) {
-          const int pi = (n - 2) >> 2, pj = (n - 2) & 3;
+          const int pi = (n - 2) / kJ, pj = (n - 2) % kJ;
 #pragma unroll
           for (int r = 0; r < 4; ++r) tot[i0 + pi][pj][r] = fmaf(prev2[r], f[pj], tot[i0 + pi][pj][r]);
         }
@@ -312,12 +308,12 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tot[i0 + 3][2 + t][r] = fmaf(tail[t][r], f[2 + t], tot[i0 + 3][2 + t][r]);
+        for (int r = 0; r < 4; ++r) tot[i0 + 3][kJ - 2 + t][r] = fmaf(tail[t][r], f[kJ - 2 + t], tot[i0 + 3][kJ - 2 + t][r]);
     }
   };
 
   // s_waitcnt immediates: vmcnt = n (split 4 + 2 bits), expcnt untouched, lgkmcnt 0 (or untouched: | 0x0F00)
-  constexpr int kFlyX = kHasXs ? 9 : 8, kFlyY = 6;
+  constexpr int kFlyX = (kHasXs ? 9 : 8) - (kHalf ? 2 : 0), kFlyY = 6;  // half tile: the two late-token pieces do not exist
   auto enter_mma = [&](auto fly) {  // end of a load section
     constexpr int kN = decltype(fly)::value;
     __builtin_amdgcn_sched_barrier(0);
@@ -345,15 +341,19 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   // has landed.  Here the weight pieces went first, so the first wait leaves k-tile 1's token pieces.
   dma_x(0, true, IntC<0>{}, IntC<0>{}, 0);
   dma_x(0, true, IntC<0>{}, IntC<0>{}, 1);
-  dma_x(0, true, IntC<0>{}, IntC<1>{}, 0);
-  dma_x(0, true, IntC<0>{}, IntC<1>{}, 1);
+  if constexpr (!kHalf) {
+    dma_x(0, true, IntC<0>{}, IntC<1>{}, 0);
+    dma_x(0, true, IntC<0>{}, IntC<1>{}, 1);
+  }
   dma_xs(0, true, IntC<0>{});
   dma_x(1, 1 < KB, IntC<1>{}, IntC<0>{}, 0);
   dma_x(1, 1 < KB, IntC<1>{}, IntC<0>{}, 1);
-  dma_x(1, 1 < KB, IntC<1>{}, IntC<1>{}, 0);
-  dma_x(1, 1 < KB, IntC<1>{}, IntC<1>{}, 1);
+  if constexpr (!kHalf) {
+    dma_x(1, 1 < KB, IntC<1>{}, IntC<1>{}, 0);
+    dma_x(1, 1 < KB, IntC<1>{}, IntC<1>{}, 1);
+  }
   dma_xs(1, 1 < KB, IntC<1>{});
-  constexpr int kFly0 = kHasXs ? 5 : 4;
+  constexpr int kFly0 = (kHasXs ? 5 : 4) - (kHalf ? 2 : 0);
   __builtin_amdgcn_s_waitcnt(0x0F70 | kFly0);  // k-tile 0 (and the weight pieces of k-tile 1) have landed
   __builtin_amdgcn_s_barrier();
   if (wn == 1) __builtin_amdgcn_s_barrier();  // the second group runs one barrier behind from here on
@@ -367,13 +367,13 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
     const bool on1 = T + 1 < KB, on2 = T + 2 < KB;
     // ---- section X: rows 0-63 of the wave's half ------------------------------------------------------------
     read_b(buf, 0, b_early);
-    read_b(buf, 1, b_late);
+    if constexpr (!kHalf) read_b(buf, 1, b_late);
     read_a(buf, a_frag);
     float f[4] = {1.f, 1.f, 1.f, 1.f}, xsv[4] = {1.f, 1.f, 1.f, 1.f}, wsk = 1.f;
     if constexpr (kHasXs) {
       wsk = __int_as_float(ws_row[T * a.ws_kb_stride]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < kJ; ++j)
         xsv[j] = *reinterpret_cast<const float*>(s_mem + kXsOff + kP * 1024 + (wm * 64 + j * 16 + r16) * 4);
     }
     if constexpr (!kNoDma) {
@@ -397,9 +397,11 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
     enter_mma(IntC<kFlyY>{});
     section(4, a_frag, b_early, b_late, f, tail, [&](int n) {
       if constexpr (!kNoDma) {
-        if (n == 3) dma_x(T + 2, on2, IntC<kP>{}, IntC<1>{}, 0);
-        if (n == 8) dma_x(T + 2, on2, IntC<kP>{}, IntC<1>{}, 1);
-        if (n == 12) dma_xs(T + 2, on2, IntC<kP>{});
+        if constexpr (!kHalf) {
+          if (n == 3) dma_x(T + 2, on2, IntC<kP>{}, IntC<1>{}, 0);
+          if (n == 8) dma_x(T + 2, on2, IntC<kP>{}, IntC<1>{}, 1);
+        }
+        if (n == (kHalf ? 6 : 12)) dma_xs(T + 2, on2, IntC<kP>{});
       }
     });
     leave_mma();
@@ -429,6 +431,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
     // the arithmetic of act_mul_blockwise_quant_kernel (reference src/activation/activation.cu:282-355), bit for bit.
     __builtin_amdgcn_s_barrier();  // every wave is past its last LDS read and its last (empty) DMA has landed
     uint32_t* xch = reinterpret_cast<uint32_t*>(s_mem) + (wm * 16 * 64 + lane) * 2;  // [strip][i * 2 + jj][lane] of 8 B
+    // (half tile: only token blocks 0-1 exist - group 1 sends its up values, group 0 finishes, nothing else)
     auto send = [&](auto j0c) {  // the two token blocks the OTHER group finishes
       constexpr int j0 = decltype(j0c)::value;
 #pragma unroll
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
         const int j = j0 + jj;
-        const int slot = mt0 + wm * 64 + j * 16 + r16;
+        const int slot = mt0 + row_of_slot(wm * 64 + j * 16 + r16);
         if constexpr (!kHasXs) {
           // per-tensor API: a = silu(g) * u (bf16-rounded factors and product when use_bf16_mul), times one scale -
           // the arithmetic of act_mul_quant_kernel (csrc/fuse_moe.hip), value for value
@@ -504,7 +507,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
     // group 0 sends its gate values of token blocks 2-3 into the first 32 KB, group 1 its up values of blocks 0-1
     // into the second; each then reads the other's region
     if (wn == 0) {
-      send(IntC<2>{});
+      if constexpr (!kHalf) send(IntC<2>{});
     } else {
       xch += 4 * 16 * 64 * 2;
       send(IntC<0>{});
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
     if (wn == 0) {
       xch += 4 * 16 * 64 * 2;
       finish(IntC<0>{}, IntC<1>{});
-    } else {
+    } else if constexpr (!kHalf) {
       xch -= 4 * 16 * 64 * 2;
       finish(IntC<2>{}, IntC<0>{});
     }
@@ -524,8 +527,8 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   // row per block.  v_permlane16_swap on the blocks i, i+1 hands lane quarter q the 8 rows [(q&2)*4, +8) of block
   // i + (q&1): 16 contiguous bytes per store, half as many stores.
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int slot = mt0 + wm * 64 + j * 16 + r16;
+  for (int j = 0; j < kJ; ++j) {
+    const int slot = mt0 + row_of_slot(wm * 64 + j * 16 + r16);
     uint16_t* yrow = a.y + static_cast<long>(m0 + slot) * a.N + n0 + wn * 128 + (g4 & 1) * 16 + (g4 >> 1) * 8;
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
@@ -538,13 +541,36 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   }
 }
 
+template <bool kHasXs, bool kNoDma = false, bool kAct = false>
+__global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, const int* __restrict__ cu_tiles,
+                                                                  int num_group) {
+  __shared__ __attribute__((aligned(1024))) uint8_t s_mem[kLds];
+  const int nt = a.N / kBN;  // kAct: N = 2 * inter, tile tn = columns [tn * 128, +128) of gate and of up
+  const Item it = locate_item(as_const(cu_tiles), a.seqlens, a.cu_seqlens, num_group, nt, threadIdx.x & 63, blockIdx.x);
+  if (!it.valid) return;
+  const int e = __builtin_amdgcn_readfirstlane(it.e);
+  const int rem = __builtin_amdgcn_readfirstlane(it.rem);
+  const int mtiles = __builtin_amdgcn_readfirstlane(it.mtiles);
+  const int m_cnt = __builtin_amdgcn_readfirstlane(it.m_cnt);
+  const int m0 = __builtin_amdgcn_readfirstlane(it.m0);
+  const int mt0 = (rem % mtiles) * kBM;
+  const int n0 = (rem / mtiles) * kBN;
+  // a group's last token tile with <= 128 rows runs the half-tile body (development key 21 = 1: never)
+  if (m_cnt - mt0 <= 128 && !a.no_half_tile)
+    p8_body<kHasXs, kNoDma, kAct, true>(a, s_mem, e, mt0, n0, m_cnt, m0);
+  else
+    p8_body<kHasXs, kNoDma, kAct, false>(a, s_mem, e, mt0, n0, m_cnt, m0);
+}
+
 }  // namespace
 }  // namespace ggemm
 }  // namespace hpc
 
-int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a, const int* cu_tiles, int num_group, int m, int n,
+int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int num_group, int m, int n,
                         hipStream_t stream) {
   using namespace hpc::ggemm;
+  Args a = a_in;
+  a.no_half_tile = hpc_dev_tuning_get(21) == 1;
   if (n % kBN || a.K < kBK) return HPC_ERR_UNSUPPORTED;
   const long max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 256)
   const long items = max_tiles * (n / kBN) + 8;  // + 8: the per-XCD chunks round up

@@ -66,6 +66,13 @@ void release_decode_workspaces() {
   std::lock_guard<std::mutex> lock(ws_mutex());
   ws_cache().clear();
 }
+// the cached buffers themselves (tests look at / poison their contents)
+std::vector<at::Tensor> decode_workspaces() {
+  std::lock_guard<std::mutex> lock(ws_mutex());
+  std::vector<at::Tensor> out;
+  for (auto& kv : ws_cache()) out.push_back(kv.second);
+  return out;
+}
 
 struct DecodeCommon {
   int num_batch, num_seq_q, group;
@@ -414,6 +421,7 @@ TORCH_LIBRARY(hpc, m) {
       "int num_expert_total, Tensor ? output) -> (Tensor)");
   m.def("fused_rmsnorm_with_scale(Tensor input, Tensor weight, Tensor scale, float eps, bool is_moe) -> (Tensor, Tensor, Tensor)");
   m.def("_release_decode_workspaces() -> ()", []() { release_decode_workspaces(); });
+  m.def("_decode_workspaces() -> Tensor[]", []() { return decode_workspaces(); });
   m.class_<MulticastCommunicator>("MulticastCommunicator")
       .def(torch::init<int64_t, int64_t, int64_t, std::string>(), "",
            {torch::arg("rank"), torch::arg("world_size"), torch::arg("device_id") = -1, torch::arg("comm_name") = "hpc_comm"})

@@ -147,14 +147,15 @@ def test_attn_fp8_split_request_merge_variants(mode):
     partial region may hold anything - here words of the form (epoch << 16) | n for every epoch, the pattern a
     tagged counter would take for 'n chunks arrived' - and the same call twice must agree (counters left clean)."""
     import hpc
-    from hpc import _entry_attention as ea
 
     lens = torch.tensor([20000, 3, 9000, 130, 64, 4097, 700, 31000], dtype=torch.int32)
     try:
         if mode == "poisoned_partials":
             _run(len(lens), 1, lens, 64, (4, 32), False, True, True, "NHD", 0.2)  # creates the cached scratch
             zero = hpc._C.lib.hpc_attention_decode_workspace_zero_bytes()
-            for ws in ea._DECODE_WS.values():
+            cached = torch.ops.hpc._decode_workspaces()  # the host library's per-(device, stream) scratch buffers
+            assert len(cached) >= 1
+            for ws in cached:
                 assert int(ws[:zero].view(torch.int32).abs().max()) == 0  # the call left its counters zero
                 words = ws[zero:].view(torch.int32)
                 idx = torch.arange(words.numel(), device=ws.device, dtype=torch.int32)

@@ -13,8 +13,8 @@ REF = json.loads((Path(__file__).parent / "golden" / "ref_schemas.json").read_te
 # ops of the reference that are outside the decode-step path (stem_* block-sparse-attention helpers)
 OUT_OF_SCOPE = {"stem_oam_gemm", "stem_oam_prep_paged_kv", "stem_oam_prep_varlen_q", "stem_tpd"}
 # ops without a reference counterpart (BASELINE north_star asks for a top-k router; the reference stops at the GEMM)
-# internal op of the host library: drop its cached decode scratch (hpc.release_decode_workspaces)
-OURS_ONLY = {"topk_router", "_release_decode_workspaces"}
+# internal ops of the host library: drop / list its cached decode scratch buffers (hpc.release_decode_workspaces)
+OURS_ONLY = {"topk_router", "_release_decode_workspaces", "_decode_workspaces"}
 
 
 def _canon(schema: str) -> str:
