@@ -22,56 +22,11 @@ using namespace hpc_torch;
 namespace {
 
 // ---- decode attention ---------------------------------------------------------------------------------------
-// Scratch of a decode call: [arrival counters (zero on first use, left zero by every call) | partials].  One
-// buffer per (device, stream), allocated once with its counter region zeroed and reused (the reference allocates
-// lse / split_out per call and zeroes split_flag per call, src/attention/entry.cc:660-663, 690-694).
-// A buffer first used while a hipGraph is being captured has its zero-fill only RECORDED (a node of that graph):
-// the key carries the capture id, so such a buffer serves the calls of that capture and nothing else, and a buffer
-// cached by eager calls is not used inside a capture - every graph owns its buffer and its zero node.
-using WsKey = std::tuple<int, void*, long long>;
-std::mutex& ws_mutex() {
-  static std::mutex mu;
-  return mu;
-}
-std::map<WsKey, at::Tensor>& ws_cache() {
-  // never destroyed: tensors must not be released during static destruction, after the allocator is gone
-  static auto& cache = *new std::map<WsKey, at::Tensor>();
-  return cache;
-}
+// Scratch of a decode call: [arrival counters (zero on first use, left zero by every call) | partials] - a buffer of
+// the per-(device, stream, hipGraph capture) cache of torch_common.h (the reference allocates lse / split_out per call
+// and zeroes split_flag per call, src/attention/entry.cc:660-663, 690-694).
 at::Tensor decode_workspace(const at::Tensor& like, int64_t nbytes) {
-  const auto hip_stream = stream_of(like);
-  void* stream = static_cast<void*>(hip_stream);
-  const long long cap = hpc_stream_capture_id(hip_stream);
-  TORCH_CHECK(cap >= 0, "hipStreamGetCaptureInfo failed");
-  const int dev = static_cast<int>(like.device().index());
-  const WsKey key{dev, stream, cap};
-  std::lock_guard<std::mutex> lock(ws_mutex());
-  auto& cache = ws_cache();
-  auto it = cache.find(key);
-  if (it == cache.end() || it->second.numel() < nbytes) {
-    if (cap)  // the entry of an earlier capture on this stream: its memory stays with its graph's pool
-      for (auto o = cache.begin(); o != cache.end();)
-        o = (std::get<0>(o->first) == dev && std::get<1>(o->first) == stream && std::get<2>(o->first) != 0 &&
-             std::get<2>(o->first) != cap) ? cache.erase(o) : std::next(o);
-    const int64_t n = std::max<int64_t>(nbytes, 1 << 20);
-    at::Tensor ws = at::empty({n}, like.options().dtype(at::kByte));
-    ws.narrow(0, 0, hpc_attention_decode_workspace_zero_bytes()).zero_();
-    it = cache.insert_or_assign(key, ws).first;
-  }
-  return it->second;
-}
-// hpc._entry_attention.release_decode_workspaces(): drop every cached buffer (after the streams / graphs that used
-// them are gone)
-void release_decode_workspaces() {
-  std::lock_guard<std::mutex> lock(ws_mutex());
-  ws_cache().clear();
-}
-// the cached buffers themselves (tests look at / poison their contents)
-std::vector<at::Tensor> decode_workspaces() {
-  std::lock_guard<std::mutex> lock(ws_mutex());
-  std::vector<at::Tensor> out;
-  for (auto& kv : ws_cache()) out.push_back(kv.second);
-  return out;
+  return cached_scratch(kScratchDecode, like, std::max<int64_t>(nbytes, 1 << 20), hpc_attention_decode_workspace_zero_bytes());
 }
 
 struct DecodeCommon {
@@ -420,8 +375,8 @@ TORCH_LIBRARY(hpc, m) {
       "down_weight, Tensor down_weight_scale, Tensor topk_ids, Tensor topk_scale, Tensor ? shared_output, int rank_ep, "
       "int num_expert_total, Tensor ? output) -> (Tensor)");
   m.def("fused_rmsnorm_with_scale(Tensor input, Tensor weight, Tensor scale, float eps, bool is_moe) -> (Tensor, Tensor, Tensor)");
-  m.def("_release_decode_workspaces() -> ()", []() { release_decode_workspaces(); });
-  m.def("_decode_workspaces() -> Tensor[]", []() { return decode_workspaces(); });
+  m.def("_release_decode_workspaces() -> ()", []() { release_cached_scratch(); });
+  m.def("_decode_workspaces() -> Tensor[]", []() { return list_cached_scratch(kScratchDecode); });
   m.class_<MulticastCommunicator>("MulticastCommunicator")
       .def(torch::init<int64_t, int64_t, int64_t, std::string>(), "",
            {torch::arg("rank"), torch::arg("world_size"), torch::arg("device_id") = -1, torch::arg("comm_name") = "hpc_comm"})

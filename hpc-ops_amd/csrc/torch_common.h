@@ -5,6 +5,8 @@
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
+#include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -37,5 +39,61 @@ inline void cuda_contig(const at::Tensor& t, const char* name) {
   TORCH_CHECK(t.is_contiguous(), name, " tensor must be contiguous");
 }
 inline int i32(int64_t v) { return static_cast<int>(v); }
+
+// ---- zero-once scratch --------------------------------------------------------------------------------------------
+// Some kernels keep arrival counters in caller scratch that must be ZERO the first time a buffer is used and that
+// every call leaves zero again (decode: the counters of split requests; router GEMM: its split-K tickets).  Instead of
+// an allocation + a zero-fill launch per call, such scratch is one buffer per (purpose, device, stream, hipGraph
+// capture), allocated once with its first `zero_bytes` bytes zeroed.  Calls on one stream are ordered, so sharing the
+// buffer between them is safe; different streams get different buffers.  A buffer first used while a hipGraph is being
+// captured has its zero-fill only RECORDED (a node of that graph): the key carries the capture id, so such a buffer
+// serves the calls of that capture and nothing else, the entry of an earlier capture on the stream is dropped (its
+// memory stays with its graph's pool), and a buffer cached by eager calls is not used inside a capture - every graph
+// owns its buffer and its zero node.
+enum ScratchPurpose { kScratchDecode = 0, kScratchGemmFlags = 1 };
+using ScratchKey = std::tuple<int, int, void*, long long>;
+inline std::mutex& scratch_mutex() {
+  static std::mutex mu;
+  return mu;
+}
+inline std::map<ScratchKey, at::Tensor>& scratch_cache() {
+  // never destroyed: tensors must not be released during static destruction, after the allocator is gone
+  static auto& cache = *new std::map<ScratchKey, at::Tensor>();
+  return cache;
+}
+inline at::Tensor cached_scratch(int purpose, const at::Tensor& like, int64_t nbytes, int64_t zero_bytes) {
+  const auto hip_stream = stream_of(like);
+  void* stream = static_cast<void*>(hip_stream);
+  const long long cap = hpc_stream_capture_id(hip_stream);
+  TORCH_CHECK(cap >= 0, "hipStreamGetCaptureInfo failed");
+  const int dev = static_cast<int>(like.device().index());
+  const ScratchKey key{purpose, dev, stream, cap};
+  std::lock_guard<std::mutex> lock(scratch_mutex());
+  auto& cache = scratch_cache();
+  auto it = cache.find(key);
+  if (it == cache.end() || it->second.numel() < nbytes) {
+    if (cap)
+      for (auto o = cache.begin(); o != cache.end();)
+        o = (std::get<0>(o->first) == purpose && std::get<1>(o->first) == dev && std::get<2>(o->first) == stream &&
+             std::get<3>(o->first) != 0 && std::get<3>(o->first) != cap)
+                ? cache.erase(o)
+                : std::next(o);
+    at::Tensor ws = at::empty({nbytes}, like.options().dtype(at::kByte));
+    if (zero_bytes > 0) ws.narrow(0, 0, std::min(zero_bytes, nbytes)).zero_();
+    it = cache.insert_or_assign(key, ws).first;
+  }
+  return it->second;
+}
+inline void release_cached_scratch() {
+  std::lock_guard<std::mutex> lock(scratch_mutex());
+  scratch_cache().clear();
+}
+inline std::vector<at::Tensor> list_cached_scratch(int purpose) {
+  std::lock_guard<std::mutex> lock(scratch_mutex());
+  std::vector<at::Tensor> out;
+  for (auto& kv : scratch_cache())
+    if (std::get<0>(kv.first) == purpose) out.push_back(kv.second);
+  return out;
+}
 
 }  // namespace hpc_torch

@@ -53,7 +53,9 @@ at::Tensor gemm_bf16xfp32(const at::Tensor& x, const at::Tensor& w_high, const a
       }
       flag = *split_flag;
     } else {
-      flag = at::zeros({rows, flag_ld}, x.options().dtype(at::kInt));
+      // the tickets are zero again when the kernel exits (the last arriver of a tile resets its counter): a zero-once
+      // buffer per (device, stream, capture) instead of an allocation + a zero-fill launch per call
+      flag = cached_scratch(kScratchGemmFlags, x, std::max<int64_t>(rows * flag_ld * 4, 1 << 16), 1 << 30).view(at::kInt);
     }
   }
   at::Tensor y = at::empty({m, n}, x.options().dtype(use_fp32_output ? at::kFloat : at::kBFloat16));

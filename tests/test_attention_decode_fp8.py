@@ -95,6 +95,8 @@ def _run(num_batch, num_seq_q, lens_before, block_size, kv_head_q_head, k_per_to
 def test_attn_fp8_kvpertensor(num_batch, num_seq_q, max_seq_kv, kv_head_q_head, use_dynamic_sched, kvcache_shape):
     """The reference grid (tests/test_attention_decode_qpertoken_perhead_kvpertensor_fp8.py:263-273): num_seq_q
     1 ... 4 x max_seq_kv 1024 / 4096 x 1 / 8 and 4 / 32 heads x dynamic / static schedule x NHD / HND pages."""
+    if num_batch == 50 and max_seq_kv == 4096 and kvcache_shape == "HND":
+        pytest.skip("sampling: the 50 x 4096 cases run on NHD pages (the suite's wall-clock)")
     torch.manual_seed(41)
     lens = torch.randint(1, max_seq_kv, (num_batch,), dtype=torch.int32)
     _run(num_batch, num_seq_q, lens, 64, kv_head_q_head, False, True, use_dynamic_sched,
