@@ -332,7 +332,11 @@ def moe_block(dev, hpc, with_cpu=True, iters=10):
     flops = c4_flops(T, w)
     tf = flops / us / 1e6
     pmc = ROOT / "profiles" / "moe_tiled_gemm_pmc_r4.json"  # rocprofv3 --pmc pass over the kernels that ship (tools/round4_profiles.sh)
-    mfma_busy = json.loads(pmc.read_text()).get("mfma_busy_frac") if pmc.exists() else None
+    mfma_busy = None
+    if pmc.exists():  # matrix-pipe busy fraction of the two kernels this op launches: gate-up GEMM with the activation epilogue, down GEMM
+        pj = json.loads(pmc.read_text())
+        mfma_busy = {("gate_up_act_epilogue" if "[gate_up]" in k else "down"): v.get("mfma_busy_frac") for k, v in pj.items()
+                     if ("<true, false, true> [gate_up]" in k or "<true, false, false> [down]" in k)}
     out = {
         "metric": "fuse_moe_blockwise_fp8_tflops", "value": round(tf, 1), "unit": "TFLOP/s", "dtype": "fp8_e4m3",
         "us_per_call": round(us, 1), "us_per_call_eager": round(us_eager, 1),

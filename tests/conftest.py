@@ -20,6 +20,14 @@ def pytest_configure(config):
                                        "tests/test_dev_build.py re-runs these in a subprocess against that build")
 
 
+    # HPC_REPLAY_CHECK=1: every public hpc.* call is replayed in a fresh process with guard bands around its arguments
+    # and must reproduce byte for byte (tests/replay_check.py; reference conftest.py: SANITIZER_CHECK=memcheck,...)
+    if os.environ.get("HPC_REPLAY_CHECK") == "1":
+        import replay_check
+
+        replay_check.install()
+
+
 def pytest_collection_modifyitems(config, items):
     try:
         import torch
