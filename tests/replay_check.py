@@ -86,7 +86,8 @@ def _equal(a, b, what, bad):
     if isinstance(a, torch.Tensor):
         if not isinstance(b, torch.Tensor) or a.shape != b.shape or a.dtype != b.dtype:
             bad.append(f"{what}: shape / dtype differs")
-        elif a.numel() and not torch.equal(a.contiguous().view(torch.uint8).cpu(), b.contiguous().view(torch.uint8).cpu()):
+        elif a.numel() and not torch.equal(a.reshape(-1).contiguous().view(torch.uint8).cpu(),
+                                           b.reshape(-1).contiguous().view(torch.uint8).cpu()):
             bad.append(f"{what}: bytes differ")
     elif isinstance(a, (list, tuple)):
         if not isinstance(b, (list, tuple)) or len(a) != len(b):

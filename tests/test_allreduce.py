@@ -205,8 +205,9 @@ def test_allreduce_rmsnorm_world2_shared_gpu():
 # flags cannot become resident, and every spin runs into its 2^22-round limit - minutes, not a protocol defect.
 # Here the grids are tiny (key 11 = 1: grid = num_max_blocks), the rows few, and the spin limit short (key 10), so
 # a lost rendezvous would show up as a reported timeout within seconds instead of a hang.
-SHARED_GPU_CASES = [("ht", 16, 8192, 4, 3), ("ht", 13, 5120, 3, 2), ("ht_uneven", 48, 4096, 4, 2), ("ht", 8, 16384, 2, 2),
-                    ("ll", 16, 8192, 4, 5), ("ll", 13, 7168, 4, 4), ("ll", 8, 4096, 4, 4)]
+# (round 4: the in-process loopback test below runs the wider grid - hidden 5120 / 16384, more calls - at world sizes 8 / 4 / 2;
+#  four PROCESSES on one GPU keep the cases that matter for the cross-process path: IPC tables, uneven slices, slot rotation)
+SHARED_GPU_CASES = [("ht", 16, 8192, 4, 2), ("ht_uneven", 48, 4096, 4, 2), ("ll", 16, 8192, 4, 4), ("ll", 13, 7168, 4, 3)]
 
 
 @pytest.mark.gpu

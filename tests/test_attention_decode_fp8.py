@@ -246,7 +246,7 @@ def test_attn_fp8_four_heads_per_workgroup(form, num_seq_q, block_size, heads):
 @pytest.mark.dev
 @pytest.mark.gpu
 @pytest.mark.parametrize("keys", [{32: 115}, {30: 118, 31: 108, 32: 125}])
-@pytest.mark.parametrize("num_batch,hi", [(64, 6000), (200, 1500), (7, 30000)])
+@pytest.mark.parametrize("num_batch,hi", [(64, 6000), (7, 30000)])  # (development variants that lost their A/B: a small grid)
 def test_attn_fp8_uneven_ranges(keys, num_batch, hi):
     """Development variants of the in-kernel plan: longer ranges for the first half of the grid (key 32) and unequal
     numbers of ranges per head pair (keys 30 / 31).  Every request still has to be covered exactly once and split

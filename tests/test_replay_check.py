@@ -25,8 +25,9 @@ def test_replay_catches_a_store_past_the_end_and_nondeterminism():
 @pytest.mark.gpu
 def test_replay_of_hot_path_ops_is_byte_identical_and_in_bounds():
     """decode attention with split requests (arrival counters, in-launch merge), the fused MoE on the 256 x 256 kernel
-    incl. a half tile, RoPE + KV store (mutates its cache arguments), scaled_fp8_quant with a caller-provided output:
-    each call replayed in a fresh process with guard bands around every argument storage."""
+    incl. a half tile, scaled_fp8_quant with a caller-provided output: each call replayed in a fresh process with guard
+    bands around every argument storage.  (`HPC_REPLAY_CHECK=1 pytest tests -m gpu -k ...` replays every public call
+    of the selected tests the same way.)"""
     import hpc
 
     torch.manual_seed(5)
@@ -65,12 +66,3 @@ def test_replay_of_hot_path_ops_is_byte_identical_and_in_bounds():
     x = torch.randn(37, 123, device=dev)
     rc.replay_call("scaled_fp8_quant", (x, torch.full((), 0.01, device=dev), torch.empty(37, 123, dtype=F8, device=dev)), {},
                    hpc.scaled_fp8_quant)
-    # --- RoPE + KV store: the caches are arguments the op writes into
-    from oracle import rope as orope
-
-    cs = orope.generate_cos_sin_cache(512, 128).to(dev)
-    qkv = torch.randn(6, (4 + 2 * 1) * 128, device=dev).bfloat16()
-    kc, vc = torch.zeros(8, 64, 1, 128, dtype=torch.bfloat16, device=dev), torch.zeros(8, 64, 1, 128, dtype=torch.bfloat16, device=dev)
-    ns, qi = torch.tensor([70, 5], dtype=torch.int32, device=dev), torch.tensor([0, 4, 6], dtype=torch.int32, device=dev)
-    ki = torch.tensor([[3, 6], [1, 0]], dtype=torch.int32, device=dev)
-    rc.replay_call("rope_norm_store_kv", (kc, vc, qkv, cs, ns, qi, ki, True), {}, hpc.rope_norm_store_kv)
