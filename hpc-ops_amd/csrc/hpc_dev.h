@@ -24,8 +24,10 @@
 //   key 29 decode fp8: 2 = the four-head form of the head-pair kernel (<= 8 q rows per kv head, kv heads % 4 == 0)
 //   key 30 / 31 decode fp8, 8 kv heads: extra workgroups (value - 100 per 128) for the head pair at byte 256 / 768 of a token row
 //   key 32 decode fp8: ranges of the first half of the grid in percent of the others' (0 = equal)
-//   key 18 256x256 grouped GEMM: 1 = no DMA in the k-loop (timing only - wrong results), 2 = the round-2 FMA form of the
-//          blockwise rescale (same results up to fp32 rounding)
+//   key 18 256x256 grouped GEMM: 1 = no DMA in the k-loop (timing only - wrong results)
+//   key 19 fused MoE: 1 = the activation as a separate kernel instead of the gate-up GEMM's epilogue
+//   key 20 decode v2: minimum cost of a range of the in-kernel plan (default 8)
+//   key 21 256x256 grouped GEMM: 1 = never the half-tile body for tail token tiles
 //   others: see the launchers that read them
 #pragma once
 
