@@ -1197,7 +1197,14 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
   } else {
     decode2_kernel<2><<<num_wg, kThreads, 0, stream>>>(a);
   }
-  HPC_CHECK_LAUNCH();
+  if (hipGetLastError() != hipSuccess) {
+    // the contract of the counter region is "zero on entry, zero on exit": a launch that was refused leaves it as it
+    // found it, but the caller cannot tell a refused launch from one that died half way - restore the invariant in
+    // stream order before reporting (best effort: the stream may be beyond repair)
+    (void)hipMemsetAsync(counters, 0, kCounterBytes, stream);
+    (void)hipGetLastError();
+    return HPC_ERR_LAUNCH;
+  }
   return HPC_OK;
 }
 
