@@ -122,3 +122,17 @@ def fuse_moe_pertensor_fp8_fake(x, gate_up_weight, down_weight, gate_up_scale, d
                                 act_and_mul_scale, topk_ids, topk_scale, shared_output, rank_ep,
                                 num_expert_total, use_bf16_mul, output):
     return torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+
+
+@torch.library.register_fake("hpc::count_and_gather")
+def count_and_gather_fake(x, topk_ids, num_expert, rank_ep, intermediate_size, num_seq_per_group_avg):
+    """nine outputs, as the op's schema and entry say (csrc/torch_moe.cpp::count_and_gather): gathered rows, the gate-up
+    output buffer, topk_pos, seqlens, cu_seqlens, tiles, cu_tiles and the two (unused on gfx950) descriptor buffers"""
+    rows, dev = topk_ids.size(0) * topk_ids.size(1), x.device
+    i32 = dict(dtype=torch.int32, device=dev)
+    return (torch.empty((rows, x.size(1)), dtype=x.dtype, device=dev),
+            torch.empty((rows, intermediate_size), dtype=torch.bfloat16, device=dev),
+            torch.empty(tuple(topk_ids.shape), **i32), torch.empty((num_expert,), **i32), torch.empty((num_expert + 1,), **i32),
+            torch.empty((num_expert,), **i32), torch.empty((num_expert + 1,), **i32),
+            torch.empty((num_expert * 2, 128), dtype=torch.int8, device=dev),
+            torch.empty((num_expert * 2, 128), dtype=torch.int8, device=dev))

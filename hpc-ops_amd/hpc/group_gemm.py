@@ -95,3 +95,19 @@ def _group_gemm_fp8_cp_async_fake(x, weight, y_scale, seqlens, cu_seqlens, tiles
 def _group_gemm_fp8_scatter_cp_async_fake(x, weight, y_scale, row_indices, seqlens, cu_seqlens, tiles, cu_tiles,
                                           use_task_map=False):
     return torch.empty((row_indices.shape[0], weight.shape[1]), dtype=torch.bfloat16, device=x.device)
+
+
+@torch.library.register_fake("hpc::group_gemm_fp8")
+def _group_gemm_fp8_fake(x, weight, seqlens, cu_seqlens, y_scale, num_seq_per_group_avg, output, tma_desc,
+                         task_map_workspace):
+    if output is not None:
+        return output
+    return torch.empty((x.size(0), weight.size(1)), dtype=torch.bfloat16, device=x.device)
+
+
+@torch.library.register_fake("hpc::group_gemm_pertensor_fp8")
+def _group_gemm_pertensor_fp8_fake(x, weight, seqlens, cu_seqlens, y_scale, num_seq_per_group_avg, output, tma_desc,
+                                   task_map_workspace):
+    if output is not None:
+        return output
+    return torch.empty((x.size(0), weight.size(1)), dtype=torch.bfloat16, device=x.device)
