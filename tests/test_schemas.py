@@ -35,3 +35,29 @@ def test_no_unknown_ops():
     assert not extra, extra
     for n in ("version", "built_json"):
         assert n in names
+
+
+# ---- the Python surface: every public function / method of the reference package with the same argument names and defaults
+PY_REF = json.loads((Path(__file__).parent / "golden" / "ref_py_signatures.json").read_text())
+
+
+def _our_signatures():
+    import sys
+
+    sys.path.insert(0, str(Path(__file__).parent / "golden"))
+    from extract_schemas import py_signatures
+
+    ours = {}
+    for f in sorted((Path(hpc.__file__).parent).glob("*.py")):
+        for name, sig in py_signatures(f).items():
+            ours.setdefault(name, sig)
+    return ours
+
+
+@pytest.mark.parametrize("name", sorted(n for n in PY_REF if not n.startswith("stem_")))
+def test_python_signature_equals_reference(name):
+    """call sites written against the reference package (positional or keyword) keep working: same names, same order, same
+    defaults (reference hpc/*.py, extracted by tests/golden/extract_schemas.py)"""
+    ours = _our_signatures()
+    assert name in ours, "hpc.%s (reference hpc/%s) is missing" % (name, PY_REF[name]["module"])
+    assert ours[name] == PY_REF[name]["args"], name
