@@ -230,6 +230,7 @@ __global__ __launch_bounds__(kThreads) void assign_task_kernel(
       task_map[0] = p.per + 1;
       task_map[1] = num_bins;
       task_map[5] = mx;
+      task_map[6] = min_process_len;  // ours: the head-pair decode kernels plan in-kernel and honour it (sched_task_info.h)
     }
   }
 }
@@ -309,6 +310,7 @@ extern "C" int hpc_assign_attention_decode_task_sync(const int* num_seq_kvcache,
   task_map[0] = p.per + 1;
   task_map[1] = num_total_ctas;
   task_map[5] = mx;
+  task_map[6] = min_process_len;
   return rows;
 }
 

@@ -787,6 +787,7 @@ extern "C" int hpc_attention_decode_bf16_async(
     b.vcache = vcache_ptr;
     b.block_ids = block_ids_ptr;
     b.lens = num_seq_kvcache_ptr;
+    b.task_map = task_map_ptr;
     b.y = static_cast<uint16_t*>(y_ptr);
     b.qscale = b.kscale = b.vscale = nullptr;
     b.num_batch = num_batch;
@@ -850,6 +851,7 @@ extern "C" int hpc_attention_decode_fp8_async(
     b.vcache = vcache_ptr;
     b.block_ids = block_ids_ptr;
     b.lens = num_seq_kvcache_ptr;
+    b.task_map = task_map_ptr;
     b.y = static_cast<uint16_t*>(y_ptr);
     b.qscale = qscale_ptr;
     b.kscale = static_cast<const float*>(kscale_ptr);

@@ -13,6 +13,7 @@ struct Args {
   const void* vcache;
   const int* block_ids;
   const int* lens;       // num_seq_kvcache [B]
+  const int* task_map;   // the scheduler's task map: only header int 6 (min_process_len) is read - the plan is in-kernel
   uint16_t* y;
   float* part_o;         // [workgroups][2][2 heads][16][128]
   float* part_lse;       // [workgroups][2][2 heads][16]

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   auto row_ok = [&](int r16) __attribute__((always_inline)) { return (kQuad ? (r16 & 7) : r16) < rows_valid; };
   const int page_mask = (1 << a.page_shift) - 1;
   const cint_ptr lens = as_const(a.lens);
+  const int mpl_tiles = as_const(a.task_map)[6] >> 6;  // scalar load, in flight beside the length loads of the plan
   const int add_new = a.new_kv_included ? 0 : Sq;
   const uint8_t* qbase = static_cast<const uint8_t*>(a.q);
   const auto part_rs = make_rsrc(a.part_o);
@@ -286,7 +287,11 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   const int nbig = a.big_pct > 100 ? (nwg / 2) / npair : 0;
   const long denom = static_cast<long>(nbig) * a.big_pct + static_cast<long>(nrange - nbig) * 100;
   const int per_s_even = static_cast<int>((static_cast<long>(Th) * 100 + denom - 1) / denom);
-  const int per_s = per_s_even > a.min_range_cost ? per_s_even : a.min_range_cost;
+  // ... and never smaller than the caller's min_process_len (tokens one workgroup processes at least: the scheduler
+  // call's argument, which it records in header int 6 of the task map - sched_task_info.h).  The map's bins and split
+  // decisions are not consumed on this path; its lower bound on the split granularity is.
+  const int per_floor = a.min_range_cost > mpl_tiles ? a.min_range_cost : mpl_tiles;
+  const int per_s = per_s_even > per_floor ? per_s_even : per_floor;
   const int per_b = nbig > 0 ? (per_s * a.big_pct + 99) / 100 : per_s;
   const int big_span = nbig * per_b;
   auto range_of = [&](int pos) __attribute__((always_inline)) { return pos < big_span ? pos / per_b : nbig + (pos - big_span) / per_s; };

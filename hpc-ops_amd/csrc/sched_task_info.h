@@ -6,6 +6,10 @@
 //   int32 rows of 12 ("records", 48 bytes):
 //   row 0                      header: [0]=tiles_per_bin+1  [1]=num_bins  [2]=num_head_kv
 //                                      [3]=max_batch  [4]=scheduler bytes  [5]=max chunks of any (h,b)
+//                                      [6]=min_process_len of the scheduler call (ours; the reference leaves it 0):
+//                                          the head-pair decode kernels (attention_decode_v2.hip) plan in closed
+//                                          form inside the launch and read it so that the caller's lower bound on
+//                                          the KV length one workgroup processes holds on that path too
 //   rows 1 + bin*(T+1) + i     task i of bin `bin` (T = tiles_per_bin); list ends at ihead_kv<0
 //   then num_chunks[h*B + b]   (padded to a multiple of 12 ints using max_batch*Hkv)
 //   then finish flags          pad12(num_bins) ints   (unused by this implementation, kept zero)

@@ -47,8 +47,8 @@ inline int i32(int64_t v) { return static_cast<int>(v); }
 // capture), allocated once with its first `zero_bytes` bytes zeroed.  Calls on one stream are ordered, so sharing the
 // buffer between them is safe; different streams get different buffers.  A buffer first used while a hipGraph is being
 // captured has its zero-fill only RECORDED (a node of that graph): the key carries the capture id, so such a buffer
-// serves the calls of that capture and nothing else, the entry of an earlier capture on the stream is dropped (its
-// memory stays with its graph's pool), and a buffer cached by eager calls is not used inside a capture - every graph
+// serves the calls of that capture and nothing else, the entries of earlier (ended) captures on the stream are dropped on
+// the next call (their memory stays with their graph's pool), and a buffer cached by eager calls is not used inside a capture - every graph
 // owns its buffer and its zero node.
 enum ScratchPurpose { kScratchDecode = 0, kScratchGemmFlags = 1 };
 using ScratchKey = std::tuple<int, int, void*, long long>;
@@ -70,20 +70,25 @@ inline at::Tensor cached_scratch(int purpose, const at::Tensor& like, int64_t nb
   const ScratchKey key{purpose, dev, stream, cap};
   std::lock_guard<std::mutex> lock(scratch_mutex());
   auto& cache = scratch_cache();
+  // Entries of captures that have ENDED on this stream are dropped on every call, not only on a miss: a
+  // stream records one capture at a time, so every entry of this (purpose, device, stream) whose capture id is neither
+  // 0 (eager) nor the current one belongs to a finished capture - its tensor lives in that graph's private pool and the
+  // cache must not keep the pool alive after the graph is destroyed.
+  for (auto o = cache.begin(); o != cache.end();)
+    o = (std::get<0>(o->first) == purpose && std::get<1>(o->first) == dev && std::get<2>(o->first) == stream &&
+         std::get<3>(o->first) != 0 && std::get<3>(o->first) != cap)
+            ? cache.erase(o)
+            : std::next(o);
   auto it = cache.find(key);
   if (it == cache.end() || it->second.numel() < nbytes) {
-    if (cap)
-      for (auto o = cache.begin(); o != cache.end();)
-        o = (std::get<0>(o->first) == purpose && std::get<1>(o->first) == dev && std::get<2>(o->first) == stream &&
-             std::get<3>(o->first) != 0 && std::get<3>(o->first) != cap)
-                ? cache.erase(o)
-                : std::next(o);
     at::Tensor ws = at::empty({nbytes}, like.options().dtype(at::kByte));
     if (zero_bytes > 0) ws.narrow(0, 0, std::min(zero_bytes, nbytes)).zero_();
     it = cache.insert_or_assign(key, ws).first;
   }
   return it->second;
 }
+// Drops EVERY cached scratch buffer of every purpose: the decode workspaces AND the router GEMM's split-K ticket
+// buffers (hpc.release_decode_workspaces documents both).
 inline void release_cached_scratch() {
   std::lock_guard<std::mutex> lock(scratch_mutex());
   scratch_cache().clear();

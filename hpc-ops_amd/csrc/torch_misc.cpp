@@ -62,7 +62,7 @@ at::Tensor gemm_bf16xfp32(const at::Tensor& x, const at::Tensor& w_high, const a
   const int rc = hpc_gemm_bf16xfp32_async(ptr(y), split_y.defined() ? split_y.data_ptr() : nullptr,
                                           flag.defined() ? flag.data_ptr() : nullptr, ptr(x), ptr(w_high), ptr(w_low), i32(m), i32(n),
                                           i32(k), static_cast<float>(scale), use_fp32_output ? 1 : 0, splits, i32(flag_ld), stream_of(x));
-  HPC_LAUNCH_CHECK(rc, "gemm_bf16xfp32 launch failed!");
+  HPC_LAUNCH_CHECK(rc, "gemm_bf16xfp32");
   return y;
 }
 

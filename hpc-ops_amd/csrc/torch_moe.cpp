@@ -262,11 +262,25 @@ at::Tensor reformat_x_scale(const at::Tensor& x_scale, const at::Tensor& seqlens
 // ---- activation + quantisation (reference src/activation/entry.cc) ----------------------------------------------------
 at::Tensor act_mul_and_quant(const at::Tensor& gate_up, const at::Tensor& scale, bool use_bf16_mul,
                              const c10::optional<at::Tensor>& output) {
+  // reference act_mul_and_quant_entry, src/activation/entry.cc:17-47: ANY rank - rows = product of the leading dims,
+  // the output has the input's shape with the last dim halved.  The reference writes through a caller's `output`
+  // unchecked; here a wrong dtype / size / layout is refused instead of becoming an out-of-bounds device write.
   cuda_contig(gate_up, "gate_up");
-  TORCH_CHECK(gate_up.scalar_type() == at::kBFloat16 && gate_up.dim() == 2, "gate_up must be bfloat16 [N, 2*C]");
-  TORCH_CHECK(scale.is_cuda() && scale.scalar_type() == at::kFloat, "scale must be a cuda float32 tensor");
-  const int64_t rows = gate_up.size(0), inter = gate_up.size(1) / 2;
-  at::Tensor out = output.has_value() ? *output : at::empty({rows, inter}, gate_up.options().dtype(kF8));
+  TORCH_CHECK(gate_up.scalar_type() == at::kBFloat16 && gate_up.dim() >= 1, "gate_up must be bfloat16 [..., 2*C]");
+  TORCH_CHECK(gate_up.size(-1) % 2 == 0, "the last dim of gate_up must be even (gate | up)");
+  TORCH_CHECK(scale.is_cuda() && scale.scalar_type() == at::kFloat && scale.numel() >= 1,
+              "scale must be a cuda float32 tensor with at least one element");
+  const int64_t inter = gate_up.size(-1) / 2;
+  const int64_t rows = inter > 0 ? gate_up.numel() / (2 * inter) : 0;
+  std::vector<int64_t> out_shape(gate_up.sizes().begin(), gate_up.sizes().end());
+  out_shape.back() = inter;
+  at::Tensor out = output.has_value() ? *output : at::empty(out_shape, gate_up.options().dtype(kF8));
+  if (output.has_value()) {
+    TORCH_CHECK(out.is_cuda() && out.is_contiguous(), "output must be a contiguous cuda tensor");
+    TORCH_CHECK(out.scalar_type() == kF8, "output dtype must be float8_e4m3fn");
+    TORCH_CHECK(out.numel() == rows * inter, "output must hold gate_up's shape with the last dim halved");
+  }
+  if (rows == 0 || inter == 0) return out;
   const int rc = hpc_act_mul_and_quant_async(ptr(out), ptr(gate_up), ptr(scale), nullptr, i32(rows), i32(inter), use_bf16_mul ? 1 : 0,
                                              stream_of(gate_up));
   HPC_LAUNCH_CHECK(rc, "act_mul_and_quant_async");

@@ -41,7 +41,7 @@ def masked_act_mul_and_blockwise_quant(gate_up: Tensor, num_per_expert: Tensor, 
 def _masked_act_mul_and_quant_fake(input, scale, num_per_expert, output=None):
     if output is not None:
         return output
-    return torch.empty((input.shape[0], input.shape[1] // 2), dtype=torch.float8_e4m3fn, device=input.device)
+    return torch.empty(tuple(input.shape[:-1]) + (input.shape[-1] // 2,), dtype=torch.float8_e4m3fn, device=input.device)
 
 
 @torch.library.register_fake("hpc::masked_act_mul_and_blockwise_quant")
@@ -57,7 +57,7 @@ def _masked_act_mul_and_blockwise_quant_fake(input, num_per_expert, output=None,
 def _act_mul_and_quant_fake(input, scale, use_bf16_mul, output):
     if output is not None:
         return output
-    return torch.empty((input.shape[0], input.shape[1] // 2), dtype=torch.float8_e4m3fn, device=input.device)
+    return torch.empty(tuple(input.shape[:-1]) + (input.shape[-1] // 2,), dtype=torch.float8_e4m3fn, device=input.device)
 
 
 @torch.library.register_fake("hpc::scaled_fp8_quant")

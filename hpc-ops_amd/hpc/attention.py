@@ -10,7 +10,6 @@ import torch
 from torch import Tensor
 
 from . import _C
-from . import _C
 
 
 class QuantType(Enum):
@@ -127,8 +126,10 @@ def task_workspace_bytes(num_cu, max_num_batch, max_seqlen, num_head_kv, min_pro
 
 
 def release_decode_workspaces():
-    """Drop the decode scratch buffers the host library caches per (device, stream, hipGraph capture) - e.g. after the
-    streams / graphs that used them are gone."""
+    """Drop EVERY zero-once scratch buffer the host library caches per (purpose, device, stream, hipGraph capture) - the
+    decode workspaces and the router GEMM's split-K ticket buffers alike (csrc/torch_common.h::release_cached_scratch) -
+    e.g. after the streams / graphs that used them are gone.  Buffers of captures that have ended are dropped on the
+    next call on their stream anyway."""
     torch.ops.hpc._release_decode_workspaces()
 
 
@@ -146,14 +147,19 @@ def assign_attention_decode_task(
     num_seq_q = mtp + 1 here, tests/test_attention_decode_bf16.py:105-121 of the reference).
     `num_seq_kvcache` may live on the GPU (device scheduler) or on the CPU (host scheduler, then
     three byte ranges are copied into the device workspace); both give byte-identical maps.
-    """
+
+    `min_process_len` (KV tokens one workgroup processes at least) shapes the map's bins for the kernels that consume
+    the map (HND pages, per-token K scales, odd kv-head counts).  The head-pair kernels (NHD pages, even kv-head count:
+    csrc/attention_decode_v2.hip) plan their ranges in closed form inside the launch - the map's bins and split
+    decisions do not apply there - and honour this lower bound through header int 6 of the map, where the scheduler
+    records it (csrc/sched_task_info.h)."""
     if num_seq_kvcache.device.type == "cpu":
         task_map_host = torch.ops.hpc.assign_attention_decode_task(
             num_seq_kvcache, num_head_kv, mtp, new_kv_included, min_process_len, None
         )
         flat = task_map_host.reshape(-1)
         task_map[:8].copy_(flat[:8], non_blocking=True)
-        task_map[20:24].copy_(flat[20:24], non_blocking=True)  # max chunks per request
+        task_map[20:28].copy_(flat[20:28], non_blocking=True)  # max chunks per request, min_process_len (header int 6)
         task_map[48 : flat.numel()].copy_(flat[48:], non_blocking=True)
         return task_map
     return torch.ops.hpc.assign_attention_decode_task(

@@ -126,8 +126,9 @@ int hpc_attention_decode_bf16_async(void* y_ptr, void* workspace, const int* tas
  * (decode.h:27-35): with them, NHD pages (adjacent kv heads 128 bytes apart), <= 16 q rows per kv head and
  * an even kv head count take the second-generation kernel (attention_decode_v2.hip: 256 contiguous bytes per
  * row and load - two heads of a token - deep prefetch, the schedule planned in-kernel from the lengths in the
- * closed form of the scheduler above: the task map is validated but its bins, min_process_len and split
- * decisions do not apply on that path); an odd kv head count - incl. a single kv head - HND pages and
+ * closed form of the scheduler above: of the task map that path consumes header int 6 = the scheduler call's
+ * min_process_len - a workgroup's range is never shorter than that many KV tokens - while the map's bins and
+ * split decisions do not apply there); an odd kv head count - incl. a single kv head - HND pages and
  * per-token K scales run the first-generation kernel from the task map;
  * num_seq_kvcache_ptr may be NULL, then the task map drives the first-generation kernel as for bf16. */
 int hpc_attention_decode_fp8_async(void* y_ptr, void* workspace, const int* task_map_ptr,

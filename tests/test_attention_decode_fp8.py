@@ -169,6 +169,60 @@ def test_attn_fp8_split_request_merge_variants(mode):
         pass
 
 
+@pytest.mark.gpu
+def test_attn_fp8_head_pair_kernel_honours_min_process_len():
+    """The head-pair kernel plans its ranges inside the launch; of the task map it takes header int 6 = the scheduler
+    call's min_process_len (csrc/sched_task_info.h): a workgroup's range is never shorter than that many KV tokens.
+    With the bound above the batch's total length every head pair is ONE range: no request is cut, so no fp32 partial
+    is written (the poisoned partial region of the cached workspace stays untouched); with the bound at 64 the 9000-token
+    request is cut and partials appear.  Both answers equal the oracle."""
+    import hpc
+    from oracle import attention as oattn
+
+    hpc.release_decode_workspaces()
+    torch.manual_seed(5)
+    lens = torch.tensor([9000, 3000, 500], dtype=torch.int32)
+    heads, P = (4, 32), 64
+    q8, q_scale, kv, block_ids, nblocks = _case(3, 1, lens, P, heads, False)
+    kv8 = kv.to(torch.float8_e4m3fn)
+    ks, vs = torch.rand(1) + 0.5, torch.rand(1) + 0.5
+    gt = oattn.ref_attn_fp8(q8, kv8[:, :, :P], block_ids, nblocks, 1, lens, q_scale, ks, vs, False)
+    kvd = kv8.cuda()
+    lens_in = (lens + 1).cuda()
+    args = (q8.cuda(), kvd[:, 0, :P], kvd[:, 1, :P], block_ids.cuda(), lens_in, q_scale.cuda(), ks.cuda(), vs.cuda())
+    zero = hpc._C.lib.hpc_attention_decode_workspace_zero_bytes()
+
+    def run(mpl):
+        tm = hpc.get_attention_decode_task_workspace(3, int(lens.max()) + 1, heads[0], min_process_len=mpl)
+        hpc.assign_attention_decode_task(lens_in, tm, heads[0], 1, True, min_process_len=mpl)
+        assert int(tm.view(torch.int32)[6]) == mpl
+        y = hpc.attention_decode_fp8(*args, mtp=0, new_kv_included=True,
+                                     quant_type=hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, splitk=True, task_map=tm)
+        torch.cuda.synchronize()
+        assert allclose(gt, y.cpu(), atol=0.2)
+
+    run(64)  # creates the cached scratch
+    cached = torch.ops.hpc._decode_workspaces()
+    assert len(cached) >= 1
+
+    def poison():
+        for ws in cached:
+            ws[zero:].view(torch.int32).fill_(0x7FC12345)
+        torch.cuda.synchronize()
+
+    def touched():
+        return sum(int((ws[zero:].view(torch.int32) != 0x7FC12345).sum()) for ws in cached)
+
+    poison()
+    run(16384)  # >= the 12503 tokens of the batch: one range per head pair, nothing is split
+    assert touched() == 0
+    run(64)     # the long request is cut at range boundaries: partials are written
+    assert touched() > 0
+    for ws in cached:
+        assert int(ws[:zero].view(torch.int32).abs().max()) == 0
+    hpc.release_decode_workspaces()
+
+
 def _mixed_lens(num_batch, seed, hi):
     g = torch.Generator().manual_seed(seed)
     lens = torch.randint(1, hi, (num_batch,), dtype=torch.int32, generator=g)

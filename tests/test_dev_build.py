@@ -13,10 +13,25 @@ import pytest
 ROOT = Path(__file__).resolve().parent.parent
 
 
+def _exported_symbols(path):
+    """names in the ELF dynamic symbol table (nm -D; ctypes' hasattr is an exact dlsym and cannot enumerate)"""
+    out = subprocess.run(["nm", "-D", "--defined-only", str(path)], capture_output=True, text=True, check=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if line.strip()}
+
+
 def test_product_library_has_no_development_registers():
-    lib = ctypes.CDLL(str(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so"))
-    for sym in ("hpc_dev_tuning_set", "hpc_dev_tuning_get", "hpc_dev_decode_prof_buffer", "hpc_dev_allreduce_loopback"):
-        assert not hasattr(lib, sym), sym + " is exported by the product library"
+    """no exported symbol of the product starts with hpc_dev_ (the old probe named
+    `hpc_dev_allreduce_loopback`, which is not a symbol of either build - the real ones end in _ht / _ll - so it could
+    never fail); the development build is checked to export exactly those names, so the scan itself is pinned."""
+    prod = _exported_symbols(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so")
+    leaked = sorted(s for s in prod if s.startswith("hpc_dev_") or s.startswith("hpc_debug_"))
+    assert not leaked, f"development symbols exported by the product library: {leaked}"
+    dev = _exported_symbols(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd_dev.so")
+    for sym in ("hpc_dev_tuning_set", "hpc_dev_tuning_get", "hpc_dev_decode_prof_buffer", "hpc_dev_allreduce_loopback_ht",
+                "hpc_dev_allreduce_loopback_ll"):
+        assert sym in dev, sym + " missing from the development build"
+        assert sym not in prod
+    assert any(s.startswith("hpc_") for s in prod)  # the scan sees the C-ABI at all
     blob = (ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so").read_bytes()
     assert b"HPC_AMD_TUNING" not in blob
     header = (ROOT / "include" / "hpc_amd.h").read_text()

@@ -138,6 +138,34 @@ def test_act_mul_and_quant(use_bf16_mul):
 
 
 @pytest.mark.gpu
+def test_act_mul_and_quant_any_rank_and_output_checks():
+    """reference act_mul_and_quant_entry (src/activation/entry.cc:17-47): rows = product of the leading dims, output =
+    the input's shape with the last dim halved; a caller's `output` of the wrong dtype / size is refused (ADVICE round 4:
+    the 2-D limit and the unchecked write-through were carried over from the old Python entry)."""
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(1)
+    gate_up = torch.randn((3, 5, 2 * 256), dtype=torch.bfloat16)
+    scale = torch.rand(1) + 1.0
+    gt = omoe.act_mul_and_quant(gate_up.reshape(15, 512), scale, True).reshape(3, 5, 256)
+    out = hpc.act_mul_and_quant(gate_up.cuda(), scale.cuda(), use_bf16_mul=True)
+    assert tuple(out.shape) == (3, 5, 256) and out.dtype == torch.float8_e4m3fn
+    assert (gt.view(torch.uint8) == out.cpu().view(torch.uint8)).float().mean().item() > 0.995
+    mine = torch.empty((3, 5, 256), dtype=torch.float8_e4m3fn, device="cuda")
+    again = hpc.act_mul_and_quant(gate_up.cuda(), scale.cuda(), use_bf16_mul=True, output=mine)
+    assert again.data_ptr() == mine.data_ptr() and torch.equal(mine.view(torch.uint8), out.view(torch.uint8))
+    one_d = hpc.act_mul_and_quant(gate_up[0, 0].cuda(), scale.cuda())
+    assert tuple(one_d.shape) == (256,) and torch.equal(one_d.view(torch.uint8), out[0, 0].view(torch.uint8))
+    with pytest.raises(RuntimeError, match="last dim halved"):
+        hpc.act_mul_and_quant(gate_up.cuda(), scale.cuda(), output=torch.empty((3, 5, 128), dtype=torch.float8_e4m3fn, device="cuda"))
+    with pytest.raises(RuntimeError, match="float8_e4m3fn"):
+        hpc.act_mul_and_quant(gate_up.cuda(), scale.cuda(), output=torch.empty((3, 5, 256), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(RuntimeError, match="at least one element"):
+        hpc.act_mul_and_quant(gate_up.cuda(), torch.empty(0, device="cuda"))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("shape", [(513, 4608), (37, 123), (1, 1), (7,), (3, 5, 64)])
 def test_scaled_fp8_quant_vs_oracle(dtype, shape):

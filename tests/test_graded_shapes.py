@@ -101,6 +101,60 @@ def test_c3_bench_generator_matches_oracle():
     assert bench.c3_bytes(c["kv_lens"], w) > int(c["kv_lens"].sum()) * 8 * 256
 
 
+# ======================================================================================= C2
+@pytest.mark.gpu
+@pytest.mark.parametrize("kvcache_shape", ["NHD", "HND"])
+@pytest.mark.parametrize("lengths", ["uniform8192", "randint_1_8192_seed41"])
+def test_c2_bf16_decode_graded_shape(kvcache_shape, lengths):
+    """BASELINE configs[1] itself (missing #3): bf16 decode, batch 64, 8 KV / 64 Q heads, head_dim 128,
+    pages of 64 tokens, uniform 8192 tokens and `randint(1, 8192)` lengths (seed 41), inputs from the reference
+    benchmark's generator (benchmark/attention_decode/bench_attention_decode_bf16.py:125-154 = bench.c2_inputs), NHD
+    pages (head-pair kernel) and HND-backed pages (first-generation kernel), EVERY request against the pinned
+    PyTorch-eager oracle at the reference tolerance (tests/test_attention_decode_bf16.py: atol 0.016); dynamic
+    schedule and the static entry (no task map) give the same answer."""
+    import bench
+    import hpc
+
+    dev = torch.device("cuda")
+    w = dict(bench.C2)
+    B, Hkv = w["batch"], w["num_head_kv"]
+    if lengths == "uniform8192":
+        lens = torch.full((B,), 8192, dtype=torch.int32)
+    else:
+        lens = torch.randint(1, 8192, (B,), dtype=torch.int32, generator=torch.Generator().manual_seed(41))
+    inp = bench.c2_inputs(dev, lens, w, hnd=kvcache_shape == "HND")
+    tm = hpc.get_attention_decode_task_workspace(B, int(lens.max()), Hkv, 64)
+    hpc.assign_attention_decode_task(inp["kv_lens"], tm, Hkv, 1, True, 64)
+    y = hpc.attention_decode_bf16(inp["q"], inp["k_cache"], inp["v_cache"], inp["block_ids"], inp["kv_lens"], 0, True, True, tm)
+    torch.cuda.synchronize()
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == (B, w["num_head_q"], w["head_dim"])
+    # every request on NHD pages (the head-pair kernel = the timed one); every fourth on HND-backed pages, whose
+    # first-generation kernel the bf16 grid of tests/test_attention_decode_bf16.py already covers (suite wall-clock)
+    rows = list(range(B)) if kvcache_shape == "NHD" else list(range(0, B, 4))
+    err = bench.c2_parity(inp, y, w, rows)
+    assert err <= 0.016, err
+    y2 = hpc.attention_decode_bf16(inp["q"], inp["k_cache"], inp["v_cache"], inp["block_ids"], inp["kv_lens"], 0, True, True)
+    torch.cuda.synchronize()
+    assert float((y2.float() - y.float()).abs().max()) <= 0.016
+    assert bench.c2_parity(inp, y2, w, rows=[0, 31, 63]) <= 0.016
+
+
+def test_c2_parity_helper_detects_a_wrong_output():
+    """CPU: bench.c2_parity (the in-run check of bench.py::extra_decode and of the test above) is the pinned oracle on
+    the benchmark generator's layout: zero error on the oracle's own output, and it sees a perturbed row."""
+    import bench
+    from oracle import attention as oattn
+
+    w = dict(bench.C2, batch=3, num_head_kv=2, num_head_q=8)
+    lens = torch.tensor([130, 64, 1], dtype=torch.int32)
+    inp = bench.c2_inputs(torch.device("cpu"), lens, w)
+    ref = oattn.ref_attn_paged_separate(inp["q"], inp["k_cache"], inp["v_cache"], inp["block_ids"], inp["kv_lens"], 1)
+    y = ref.reshape(3, 8, 128).clone()
+    assert bench.c2_parity(inp, y, w) == 0.0
+    y[1, 3, 5] += 0.25
+    assert bench.c2_parity(inp, y, w) >= 0.2 and bench.c2_parity(inp, y, w, rows=[0, 2]) == 0.0
+
+
 def test_fp8_separate_cache_oracle_equals_pinned_oracle():
     """CPU: the separate-cache / row-subset form used at the graded shape is bit-equal to ref_attn_fp8
     (itself bit-equal to the reference's in-file oracle, tests/test_oracle_golden.py)."""

@@ -31,6 +31,8 @@ def _product_host_map(lens, bins, hkv, sq, nkv, minlen):
     got = lib.hpc_assign_attention_decode_task_sync(lp, bins, len(lens), hkv, sq, int(nkv), minlen,
                                                     out.ctypes.data_as(_IP), rows)
     assert got == rows
+    assert out[0, 6] == minlen  # ours: the scheduler records min_process_len for the in-kernel planners (the reference
+    out[0, 6] = 0               # leaves this header int zero - compared as such below)
     return out
 
 
@@ -134,6 +136,8 @@ def test_device_scheduler_matches_host_bytes(case):
     ora = sched.task_map_oracle(lens, bins, hkv, sq, nkv, minlen)
     got = ws_gpu.view(torch.int32).cpu().numpy()[: ora.size].reshape(ora.shape).copy()
     got[0, 2:5] = 0  # allocator-owned header ints
+    assert got[0, 6] == minlen
+    got[0, 6] = 0    # ours: min_process_len for the in-kernel planners (zero in the reference layout)
     assert np.array_equal(got, ora)
 
 
