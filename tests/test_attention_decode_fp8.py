@@ -231,10 +231,13 @@ def _mixed_lens(num_batch, seed, hi):
     return lens
 
 
+_MANY_HEADS = [(1, 64, (4, 32)), (2, 32, (2, 16)), (2, 16, (8, 32)), (1, 64, (1, 8)), (1, 32, (16, 64)), (4, 64, (8, 32))]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("num_batch", [65, 200, 1000])
-@pytest.mark.parametrize("num_seq_q,block_size,heads", [(1, 64, (4, 32)), (2, 32, (2, 16)), (2, 16, (8, 32)), (1, 64, (1, 8)),
-                                                         (1, 32, (16, 64)), (4, 64, (8, 32))])
+@pytest.mark.parametrize("num_batch,num_seq_q,block_size,heads",
+                         [(nb,) + c for nb in (65, 200) for c in _MANY_HEADS] +
+                         [(1000,) + c for c in (_MANY_HEADS[0], _MANY_HEADS[3], _MANY_HEADS[4])])  # (1000 requests: 7-11 s each)
 def test_attn_fp8_many_requests(num_batch, num_seq_q, block_size, heads):
     """More than 64 requests: the in-kernel planner of the second-generation kernel puts several requests on a
     lane of its prefix scan and walks them (reference grid: num_batch = 200,
@@ -300,7 +303,7 @@ def test_attn_fp8_four_heads_per_workgroup(form, num_seq_q, block_size, heads):
 @pytest.mark.dev
 @pytest.mark.gpu
 @pytest.mark.parametrize("keys", [{32: 115}, {30: 118, 31: 108, 32: 125}])
-@pytest.mark.parametrize("num_batch,hi", [(64, 6000), (7, 30000)])  # (development variants that lost their A/B: a small grid)
+@pytest.mark.parametrize("num_batch,hi", [(64, 6000)])  # (development variants that lost their A/B: a small grid)
 def test_attn_fp8_uneven_ranges(keys, num_batch, hi):
     """Development variants of the in-kernel plan: longer ranges for the first half of the grid (key 32) and unequal
     numbers of ranges per head pair (keys 30 / 31).  Every request still has to be covered exactly once and split

@@ -50,13 +50,15 @@ def test_development_library_holds_64_registers():
     assert lib.hpc_dev_tuning_set(-1, 1) == -2
 
 
-@pytest.mark.gpu
+@pytest.mark.gate_free  # the inner tests take the GPU gate of tests/conftest.py themselves (an exclusive inner test would
+@pytest.mark.gpu        # otherwise wait for ever for the shared lock this test holds)
 def test_dev_build_suite():
-    """every test marked `dev`, against the development build"""
+    """every test marked `dev`, against the development build (its own xdist workers: the suite's wall-clock)"""
     if os.environ.get("HPC_AMD_DEV") == "1":
         pytest.skip("already inside the development-build run")
-    env = dict(os.environ, HPC_AMD_DEV="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests"), "-m", "gpu and dev", "-q", "-x",
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTEST_XDIST")}
+    env["HPC_AMD_DEV"] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests"), "-m", "gpu and dev", "-q", "-x", "-n", "4",
                         "-p", "no:cacheprovider"], env=env, cwd=str(ROOT), capture_output=True, text=True, timeout=3000)
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-25:])
     print(tail)

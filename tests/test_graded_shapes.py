@@ -232,8 +232,8 @@ def test_c4_fused_moe_graded_shape(c4_weights, num_tokens, shared):
 @pytest.mark.dev
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,k", [(4096, 11008), (22016, 4096)])
-@pytest.mark.parametrize("tiled_mode", [0, 1, 2, 3, 4, 12, 22])
-def test_c4_group_gemm_blockwise_graded(c4_weights, n, k, tiled_mode):
+@pytest.mark.parametrize("tiled_mode", [0, 1, 2, 4, 12])  # (3 = the 128 x 128 kernel and 22 = the 64-token ring ran here until
+def test_c4_group_gemm_blockwise_graded(c4_weights, n, k, tiled_mode):  # round 4; both stay pinned on the small grids)
     """group_gemm_blockwise_fp8 on the two GEMMs of the graded configuration (down: K = 11008 = 86 k-blocks with
     the pad-4 scale stride 88; gate_up: N = 22016), 64 ragged groups incl. empty / 1 / 129 / 257 / 700 rows, for
     every kernel the launcher can pick (tuning key 3: 0 auto, 1 streaming, 2 tiled 256x128, 3 tiled 128x128;
