@@ -123,6 +123,54 @@ __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, co
   return it;
 }
 
+// ---- variants of the k-loop (development key 22 selects one in the development build; the product is CfgProduct) -------
+// Where a wave issues its DMA pieces of a k-tile: slot 0 = in the load section, slot n + 1 = behind MFMA n of the MMA
+// section that follows it.  X half of k-tile T: U3(T+1) q0 q1 (free since the barrier that ended the other group's load
+// section Y of T-1).  Y half: U0(T+2) q0 q1, U1(T+2) q0 q1, U2(T+2) q0 q1 (full body only), scales(T+2) - their units are
+// read for the last time in the other group's load section X of T, which ends one barrier before this wave's load section Y.
+// The two waits follow from the slots: the wait that ends load section X of T must see U3(T) landed - everything but the
+// Y-half pieces of T-1 and the pieces of this load section; the wait that ends load section Y must see all of k-tile T+1's
+// Y-half pieces landed - everything but the X-half pieces of T and the pieces of this load section.
+struct CfgProduct {
+  static constexpr bool kCarry = false;    // the rescale of a section's last two blocks rides under the next section's first MFMAs
+  static constexpr bool kDmaFirst = false; // load sections issue their DMA pieces before their operand reads
+  static constexpr bool kPrio = true;      // s_setprio 1 around the MFMAs
+  static constexpr bool kProf = false;     // s_memtime log of the section boundaries (development)
+  static constexpr int fx(int i) { constexpr int t[2] = {0, 0}; return t[i]; }
+  static constexpr int fy(int i) { constexpr int t[7] = {0, 0, 0, 0, 4, 9, 13}; return t[i]; }
+  static constexpr int hx(int i) { constexpr int t[2] = {0, 0}; return t[i]; }
+  static constexpr int hy(int i) { constexpr int t[7] = {0, 0, 0, 0, -1, -1, 7}; return t[i]; }
+};
+#ifdef HPC_DEV
+struct CfgProf : CfgProduct { static constexpr bool kProf = true; };
+struct CfgCarry : CfgProduct { static constexpr bool kCarry = true; };
+struct CfgDmaFirst : CfgProduct { static constexpr bool kDmaFirst = true; };
+struct CfgNoPrio : CfgProduct { static constexpr bool kPrio = false; };
+// schedules: S1 = load section X carries no piece (U3 behind MFMAs 4 / 10 of section X)
+struct CfgS1 : CfgProduct {
+  static constexpr int fx(int i) { constexpr int t[2] = {5, 11}; return t[i]; }
+  static constexpr int hx(int i) { constexpr int t[2] = {2, 6}; return t[i]; }
+};
+// S2 = S1 + load section Y carries two pieces instead of four
+struct CfgS2 : CfgS1 {
+  static constexpr int fy(int i) { constexpr int t[7] = {0, 0, 2, 5, 8, 11, 14}; return t[i]; }
+  static constexpr int hy(int i) { constexpr int t[7] = {0, 0, 2, 4, -1, -1, 7}; return t[i]; }
+};
+// S3 = no piece in any load section
+struct CfgS3 : CfgS1 {
+  static constexpr int fy(int i) { constexpr int t[7] = {1, 3, 5, 7, 9, 11, 14}; return t[i]; }
+  static constexpr int hy(int i) { constexpr int t[7] = {1, 2, 4, 5, -1, -1, 7}; return t[i]; }
+};
+// the half-tile body alone on schedule S3 (its MMA sections are half as long as its load sections: the pieces cost nothing there)
+struct CfgH3 : CfgProduct {
+  static constexpr int hx(int i) { return CfgS3::hx(i); }
+  static constexpr int hy(int i) { return CfgS3::hy(i); }
+};
+struct CfgCarryS1 : CfgS1 { static constexpr bool kCarry = true; };
+struct CfgCarryH3 : CfgH3 { static constexpr bool kCarry = true; };
+struct CfgCarryProf : CfgCarry { static constexpr bool kProf = true; };
+#endif
+
 // kNoDma (development key 18 = 1, timing only - results are wrong): no DMA inside the k-loop
 // kAct: the gate-up GEMM of the fused MoE - a tile is 128 gate rows (wave group 0) + the 128 up rows of the same
 // columns (group 1); the epilogue applies SiLU(gate) * up and the 128-block quantisation instead of storing y
@@ -140,7 +188,7 @@ __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, co
 // and the MFMAs of token blocks 2-3 do not exist: 16 instead of 32 MFMAs, 20 instead of 24 operand reads and 6-7
 // instead of 8-9 DMA pieces per wave and k-tile, and in the fused activation epilogue group 0 finishes everything.
 // The weight units are what they are: a tail tile still re-streams its 256 weight rows.
-template <bool kHasXs, bool kNoDma, bool kAct, bool kHalf>
+template <class Cfg, bool kHasXs, bool kNoDma, bool kAct, bool kHalf>
 __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, int mt0, int n0, int m_cnt, int m0) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -263,15 +311,22 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   // One section: 4 row blocks x all 4 token blocks (16 MFMAs), written as the software pipeline it has to be:
   // the rescale of block n follows the MFMA of block n + 2 (its result is ready by then without wait states: with
   // one MFMA in between hipcc pads 7-11 idle cycles per MFMA and the matrix pipe is busy 52-55 % of the time),
-  // `hook(n)` may issue one DMA piece behind them, and the order is pinned.  Blockwise form: fp32 partial of the
+  // `hook(n)` may issue DMA pieces behind them, and the order is pinned.  Blockwise form: fp32 partial of the
   // 128-k block, rescaled into the running sum (reference kernels.cuh:473-476); the rescale of the LAST TWO blocks
   // is the caller's (`tail`), behind the barrier that ends the section - otherwise that barrier would wait for the
   // last MFMA's result and the other wave of the SIMD would start its section ~40 cycles late.
-  auto section = [&](int i0, const u32x4 (&af)[4][2], const u32x4 (&be)[2][2], const u32x4 (&bl)[2][2],
-                     const float (&f)[4], f32x4 (&tail)[2], auto&& hook) {
+  // Cfg::kCarry: the last two blocks' rescale is not done in the load section that follows but rides under the first two
+  // MFMAs of the NEXT section (`pend`, with the scales `fpend` of the k-tile they belong to): the load sections carry no
+  // FMA, a section's head needs no hazard padding (its first FMAs read results that are a whole load section old), and
+  // the new k-tile's four scale products (`pre`) sit behind MFMA 0 instead of in front of it.
+  constexpr int kN = 4 * kJ;  // MFMAs per section
+  f32x4 pend[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  float fpend[4] = {0.f, 0.f, 0.f, 0.f};
+  auto section = [&](int i0, const u32x4 (&af)[4][2], const u32x4 (&be)[2][2], const u32x4 (&bl)[2][2], float (&f)[4],
+                     f32x4 (&tail)[2], auto&& pre, auto&& hook) {
     f32x4 prev1 = {0.f, 0.f, 0.f, 0.f}, prev2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int n = 0; n < 4 * kJ; ++n) {
+    for (int n = 0; n < kN; ++n) {
       const int i = n / kJ, j = n % kJ;
       const u32x4(&bf)[2] = j < 2 ? be[j] : bl[j - 2];
       const i32x8 av = {static_cast<int>(af[i][0][0]), static_cast<int>(af[i][0][1]), static_cast<int>(af[i][0][2]),
@@ -288,6 +343,12 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
           const int pi = (n - 2) / kJ, pj = (n - 2) % kJ;
 #pragma unroll
           for (int r = 0; r < 4; ++r) tot[i0 + pi][pj][r] = fmaf(prev2[r], f[pj], tot[i0 + pi][pj][r]);
+        } else if constexpr (Cfg::kCarry) {
+          // blocks kN - 2 + n of the PREVIOUS section (the other row half: 4 - i0), under the scales of their k-tile
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            tot[4 - i0 + 3][kJ - 2 + n][r] = fmaf(pend[n][r], fpend[kJ - 2 + n], tot[4 - i0 + 3][kJ - 2 + n][r]);
+          if (n == 0) pre();
         }
         prev2 = prev1;
         prev1 = part;
@@ -300,11 +361,18 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       hook(n);
       __builtin_amdgcn_sched_barrier(0);
     }
-    tail[0] = prev2;
-    tail[1] = prev1;
+    if constexpr (Cfg::kCarry && kHasXs) {
+      pend[0] = prev2;
+      pend[1] = prev1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fpend[j] = f[j];
+    } else {
+      tail[0] = prev2;
+      tail[1] = prev1;
+    }
   };
   auto apply_tail = [&](int i0, const float (&f)[4], const f32x4 (&tail)[2]) {
-    if constexpr (kHasXs) {
+    if constexpr (kHasXs && !Cfg::kCarry) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -312,32 +380,79 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     }
   };
 
+  // ---- DMA schedule (see the Cfg structs): slots of this body's pieces and the two waits that follow from them ------
+  auto sx = [](int i) { return kHalf ? Cfg::hx(i) : Cfg::fx(i); };
+  auto sy = [](int i) { return kHalf ? Cfg::hy(i) : Cfg::fy(i); };
+  auto y_exists = [](int i) { return i < 4 || (i < 6 ? !kHalf : kHasXs); };
+  constexpr int kPiecesY = (kHalf ? 4 : 6) + (kHasXs ? 1 : 0);
+  int n_xload = 0, n_yload = 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) n_xload += sx(i) == 0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) n_yload += y_exists(i) && sy(i) == 0;
   // s_waitcnt immediates: vmcnt = n (split 4 + 2 bits), expcnt untouched, lgkmcnt 0 (or untouched: | 0x0F00)
-  constexpr int kFlyX = (kHasXs ? 9 : 8) - (kHalf ? 2 : 0), kFlyY = 6;  // half tile: the two late-token pieces do not exist
-  auto enter_mma = [&](auto fly) {  // end of a load section
-    constexpr int kN = decltype(fly)::value;
+  const int fly_x = kPiecesY + n_xload, fly_y = 2 + n_yload;  // compile-time values after inlining (checked below)
+
+  // ---- development: s_memtime log of the section boundaries (Cfg::kProf) -------------------------------------------
+  // A = first instruction behind the barrier that opens an MMA section, B = behind its last MFMA, C = behind the barrier
+  // that closes it, D = end of the load section's issue (in front of its wait).  The stamps are read where the load
+  // section's own lgkmcnt(0) has retired them; lane 4 e + {0, 1, 2, 3} of `plog` = (A, B, C of the section before, D of
+  // this one) for the 16 sections from k-tile 4 on.
+  unsigned long long ts_a = 0, ts_b = 0, ts_c = 0, ts_d = 0;
+  int plog = 0, sec = 0;
+  auto stamp = [&](unsigned long long& t) {
+    if constexpr (Cfg::kProf) asm volatile("s_memtime %0" : "=s"(t));
+  };
+  auto log4 = [&]() {
+    if constexpr (Cfg::kProf) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int e = sec - 8;
+      const int d = lane - e * 4;  // (e outside 0 .. 15: no lane matches)
+      plog = d == 0 ? static_cast<int>(ts_a) : plog;
+      plog = d == 1 ? static_cast<int>(ts_b) : plog;
+      plog = d == 2 ? static_cast<int>(ts_c) : plog;
+      plog = d == 3 ? static_cast<int>(ts_d) : plog;
+      ++sec;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  auto wait_fly = [&](int n) {  // vmcnt(n), lgkmcnt(0): n is a compile-time value after inlining
+    switch (n) {
+#define HPC_P8_WAIT(N) case N: __builtin_amdgcn_s_waitcnt(0x0070 | ((N) & 15) | (((N) >> 4) << 14)); break;
+      HPC_P8_WAIT(2) HPC_P8_WAIT(3) HPC_P8_WAIT(4) HPC_P8_WAIT(5) HPC_P8_WAIT(6) HPC_P8_WAIT(7) HPC_P8_WAIT(8) HPC_P8_WAIT(9)
+#undef HPC_P8_WAIT
+      default: __builtin_amdgcn_s_waitcnt(0x0070); break;  // vmcnt(0)
+    }
+  };
+  auto enter_mma = [&](int fly) {  // end of a load section
     __builtin_amdgcn_sched_barrier(0);
+    stamp(ts_d);
     // this wave's pieces of the unit(s) read behind the NEXT barrier have landed; its operand reads have retired
     if constexpr (kNoDma)
       __builtin_amdgcn_s_waitcnt(0xC07F);
     else
-      __builtin_amdgcn_s_waitcnt(0x0070 | (kN & 15) | ((kN >> 4) << 14));
+      wait_fly(fly);
+    log4();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (Cfg::kPrio) __builtin_amdgcn_s_setprio(1);
+    stamp(ts_a);
   };
   auto leave_mma = [&]() {
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (Cfg::kPrio) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
+    stamp(ts_b);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    stamp(ts_c);
   };
 
   // ---- prologue: the token pieces of k-tiles 0 and 1 ---------------------------------------------------------
-  // Steady-state issue order per k-tile T: load section Y: U0(T+2), U1(T+2); MFMAs of Y: U2(T+2), scales(T+2);
-  // load section X of T+1: U3(T+2).  Every target's last reads (by either group) retired before the barrier
-  // that precedes the issue.  Waits: end of load section X leaves kFlyX pieces in flight - U3(T), read behind
-  // the next barrier but one, has landed; end of load section Y leaves 6 - all of k-tile T+1 up to its scales
+  // Steady-state issue order per k-tile T (product schedule): load section Y: U0(T+2), U1(T+2); MFMAs of Y: U2(T+2),
+  // scales(T+2); load section X of T+1: U3(T+2).  Every target's last reads (by either group) retired before the barrier
+  // that precedes the issue.  Waits: end of load section X leaves fly_x pieces in flight - U3(T), read behind
+  // the next barrier but one, has landed; end of load section Y leaves fly_y - all of k-tile T+1 up to its scales
   // has landed.  Here the weight pieces went first, so the first wait leaves k-tile 1's token pieces.
   dma_x(0, true, IntC<0>{}, IntC<0>{}, 0);
   dma_x(0, true, IntC<0>{}, IntC<0>{}, 1);
@@ -361,55 +476,87 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
 
   u32x4 a_frag[4][2], b_early[2][2], b_late[2][2];
   f32x4 tail[2];
+  float f[4] = {1.f, 1.f, 1.f, 1.f};
   auto k_tile = [&](int T, auto par) {
     constexpr int kP = decltype(par)::value;
     const uint8_t* buf = s_mem + kP * kBuf;
     const bool on1 = T + 1 < KB, on2 = T + 2 < KB;
+    auto x_piece = [&](int i) { dma_w(T + 1, on1, IntC<1 - kP>{}, IntC<1>{}, i); };  // U3(T + 1), piece q = i
+    auto y_piece = [&](int i) {  // U0(T + 2) q0 q1, U1(T + 2) q0 q1, U2(T + 2) q0 q1, scales(T + 2)
+      if (i < 2) {
+        dma_w(T + 2, on2, IntC<kP>{}, IntC<0>{}, i);
+      } else if (i < 4) {
+        dma_x(T + 2, on2, IntC<kP>{}, IntC<0>{}, i - 2);
+      } else if (i < 6) {
+        if constexpr (!kHalf) dma_x(T + 2, on2, IntC<kP>{}, IntC<1>{}, i - 4);
+      } else {
+        dma_xs(T + 2, on2, IntC<kP>{});
+      }
+    };
+    auto issue_x = [&](int slot) {
+      if constexpr (!kNoDma) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          if (sx(i) == slot) x_piece(i);
+      }
+    };
+    auto issue_y = [&](int slot) {
+      if constexpr (!kNoDma) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+          if (y_exists(i) && sy(i) == slot) y_piece(i);
+      }
+    };
     // ---- section X: rows 0-63 of the wave's half ------------------------------------------------------------
+    if constexpr (Cfg::kDmaFirst) {
+      issue_x(0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     read_b(buf, 0, b_early);
     if constexpr (!kHalf) read_b(buf, 1, b_late);
     read_a(buf, a_frag);
-    float f[4] = {1.f, 1.f, 1.f, 1.f}, xsv[4] = {1.f, 1.f, 1.f, 1.f}, wsk = 1.f;
+    float xsv[4] = {1.f, 1.f, 1.f, 1.f}, wsk = 1.f;
     if constexpr (kHasXs) {
       wsk = __int_as_float(ws_row[T * a.ws_kb_stride]);
 #pragma unroll
       for (int j = 0; j < kJ; ++j)
         xsv[j] = *reinterpret_cast<const float*>(s_mem + kXsOff + kP * 1024 + (wm * 64 + j * 16 + r16) * 4);
     }
-    if constexpr (!kNoDma) {
-      dma_w(T + 1, on1, IntC<1 - kP>{}, IntC<1>{}, 0);
-      dma_w(T + 1, on1, IntC<1 - kP>{}, IntC<1>{}, 1);
-    }
-    enter_mma(IntC<kFlyX>{});
+    if constexpr (!Cfg::kDmaFirst) issue_x(0);
+    enter_mma(fly_x);
+    auto make_f = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) f[j] = wsk * xsv[j];
-    section(0, a_frag, b_early, b_late, f, tail, [&](int) {});
+      for (int j = 0; j < 4; ++j) f[j] = wsk * xsv[j];
+    };
+    if constexpr (!(Cfg::kCarry && kHasXs)) make_f();
+    section(0, a_frag, b_early, b_late, f, tail, make_f, [&](int n) { issue_x(n + 1); });
     leave_mma();
     apply_tail(0, f, tail);
     // ---- section Y: rows 64-127 ----------------------------------------------------------------------------
-    read_a(buf + 3 * kUnit, a_frag);
-    if constexpr (!kNoDma) {
-      dma_w(T + 2, on2, IntC<kP>{}, IntC<0>{}, 0);
-      dma_w(T + 2, on2, IntC<kP>{}, IntC<0>{}, 1);
-      dma_x(T + 2, on2, IntC<kP>{}, IntC<0>{}, 0);
-      dma_x(T + 2, on2, IntC<kP>{}, IntC<0>{}, 1);
+    if constexpr (Cfg::kDmaFirst) {
+      issue_y(0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    enter_mma(IntC<kFlyY>{});
-    section(4, a_frag, b_early, b_late, f, tail, [&](int n) {
-      if constexpr (!kNoDma) {
-        if constexpr (!kHalf) {
-          if (n == 3) dma_x(T + 2, on2, IntC<kP>{}, IntC<1>{}, 0);
-          if (n == 8) dma_x(T + 2, on2, IntC<kP>{}, IntC<1>{}, 1);
-        }
-        if (n == (kHalf ? 6 : 12)) dma_xs(T + 2, on2, IntC<kP>{});
-      }
-    });
+    read_a(buf + 3 * kUnit, a_frag);
+    if constexpr (!Cfg::kDmaFirst) issue_y(0);
+    enter_mma(fly_y);
+    section(4, a_frag, b_early, b_late, f, tail, [] {}, [&](int n) { issue_y(n + 1); });
     leave_mma();
     apply_tail(4, f, tail);
   };
   for (int kb = 0; kb < KB; kb += 2) {
     k_tile(kb, IntC<0>{});
     if (kb + 1 < KB) k_tile(kb + 1, IntC<1>{});
+  }
+  if constexpr (Cfg::kCarry && kHasXs) {  // the last section's last two blocks (row half 4 .. 7)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tot[7][kJ - 2 + t][r] = fmaf(pend[t][r], fpend[kJ - 2 + t], tot[7][kJ - 2 + t][r]);
+  }
+  if constexpr (Cfg::kProf) {
+    if (a.prof && blockIdx.x < 16)
+      reinterpret_cast<int*>(a.prof)[(blockIdx.x * 8 + wave) * 64 + lane] = plog;
   }
   if (wn == 0) __builtin_amdgcn_s_barrier();  // even out the barrier count
   __builtin_amdgcn_s_waitcnt(0x0F70);         // drain the (empty) tail DMAs before the workgroup's LDS is released
@@ -541,7 +688,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   }
 }
 
-template <bool kHasXs, bool kNoDma = false, bool kAct = false>
+template <class Cfg, bool kHasXs, bool kNoDma = false, bool kAct = false>
 __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, const int* __restrict__ cu_tiles,
                                                                   int num_group) {
   __shared__ __attribute__((aligned(1024))) uint8_t s_mem[kLds];
@@ -557,14 +704,33 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   const int n0 = (rem / mtiles) * kBN;
   // a group's last token tile with <= 128 rows runs the half-tile body (development key 21 = 1: never)
   if (m_cnt - mt0 <= 128 && !a.no_half_tile)
-    p8_body<kHasXs, kNoDma, kAct, true>(a, s_mem, e, mt0, n0, m_cnt, m0);
+    p8_body<Cfg, kHasXs, kNoDma, kAct, true>(a, s_mem, e, mt0, n0, m_cnt, m0);
   else
-    p8_body<kHasXs, kNoDma, kAct, false>(a, s_mem, e, mt0, n0, m_cnt, m0);
+    p8_body<Cfg, kHasXs, kNoDma, kAct, false>(a, s_mem, e, mt0, n0, m_cnt, m0);
 }
+
+#ifdef HPC_DEV
+// development key 22: variant of the k-loop for the blockwise kernels (A/B runs, tools/tune_ggemm.py; tools/prof_p8.py)
+template <class Cfg>
+void launch_blockwise_variant(const Args& a, const int* cu_tiles, int num_group, dim3 grid, hipStream_t stream) {
+  if (a.act_out)
+    gemm_fp8_p8_kernel<Cfg, true, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  else
+    gemm_fp8_p8_kernel<Cfg, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+}
+#endif
 
 }  // namespace
 }  // namespace ggemm
 }  // namespace hpc
+
+#ifdef HPC_DEV
+static void* g_p8_prof = nullptr;  // device buffer [16 workgroups][8 waves][64] int32 (tools/prof_p8.py), null = off
+extern "C" int hpc_dev_p8_prof_buffer(void* p) {
+  g_p8_prof = p;
+  return 0;
+}
+#endif
 
 int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int num_group, int m, int n,
                         hipStream_t stream) {
@@ -576,16 +742,38 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int n
   const long items = max_tiles * (n / kBN) + 8;  // + 8: the per-XCD chunks round up
   if (items > 0x7fffffffl) return HPC_ERR_UNSUPPORTED;
   dim3 grid(static_cast<unsigned>(items));
+#ifdef HPC_DEV
+  a.prof = g_p8_prof;
+  if (a.has_xs && hpc_dev_tuning_get(22) > 0) {
+    switch (hpc_dev_tuning_get(22)) {
+      case 1: launch_blockwise_variant<CfgProf>(a, cu_tiles, num_group, grid, stream); break;
+      case 2: launch_blockwise_variant<CfgCarry>(a, cu_tiles, num_group, grid, stream); break;
+      case 3: launch_blockwise_variant<CfgDmaFirst>(a, cu_tiles, num_group, grid, stream); break;
+      case 4: launch_blockwise_variant<CfgNoPrio>(a, cu_tiles, num_group, grid, stream); break;
+      case 5: launch_blockwise_variant<CfgS1>(a, cu_tiles, num_group, grid, stream); break;
+      case 6: launch_blockwise_variant<CfgS2>(a, cu_tiles, num_group, grid, stream); break;
+      case 7: launch_blockwise_variant<CfgS3>(a, cu_tiles, num_group, grid, stream); break;
+      case 8: launch_blockwise_variant<CfgH3>(a, cu_tiles, num_group, grid, stream); break;
+      case 9: launch_blockwise_variant<CfgCarryS1>(a, cu_tiles, num_group, grid, stream); break;
+      case 10: launch_blockwise_variant<CfgCarryH3>(a, cu_tiles, num_group, grid, stream); break;
+      case 11: launch_blockwise_variant<CfgCarryProf>(a, cu_tiles, num_group, grid, stream); break;
+      default: return HPC_ERR_INVALID;
+    }
+    HPC_CHECK_LAUNCH();
+    return HPC_OK;
+  }
+#endif
+  using P = CfgProduct;
   if (a.has_xs && a.act_out)
-    gemm_fp8_p8_kernel<true, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+    gemm_fp8_p8_kernel<P, true, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else if (a.act_out)
-    gemm_fp8_p8_kernel<false, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+    gemm_fp8_p8_kernel<P, false, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else if (kHpcDevBuild && a.has_xs && hpc_dev_tuning_get(18) == 1)
-    gemm_fp8_p8_kernel<true, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+    gemm_fp8_p8_kernel<P, true, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else if (a.has_xs)
-    gemm_fp8_p8_kernel<true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+    gemm_fp8_p8_kernel<P, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else
-    gemm_fp8_p8_kernel<false><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+    gemm_fp8_p8_kernel<P, false><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }

@@ -13,6 +13,9 @@ from hpc import _C
 dev = torch.device("cuda", 0)
 PT = "--pertensor" in sys.argv
 if PT: sys.argv.remove("--pertensor")
+ROWS = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--rows=")]  # extra cases: N rows in every group
+ONLY = [a.split("=")[1] for a in sys.argv if a.startswith("--only=")]      # substring filter on the case names
+sys.argv = [a for a in sys.argv if not a.startswith("--rows=") and not a.startswith("--only=")]
 w = bench.C4
 m_ = bench.c4_inputs(dev, w)
 E, T, topk = w["num_expert"], w["tokens"], w["topk"]
@@ -22,6 +25,7 @@ F8 = torch.float8_e4m3fn
 def case(seqlens, wt, wsc):
     n, k = wt.shape[1], wt.shape[2]
     cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
+    M = int(seqlens.sum())
     avg = M // E
     tile = hpc.aligned_size(avg)
     tiles = (seqlens + tile - 1) // tile
@@ -32,16 +36,26 @@ def case(seqlens, wt, wsc):
     out = torch.empty(M, n, dtype=torch.bfloat16, device=dev)
     ys = torch.rand(E, device=dev) * 0.01 + 0.01
     if PT:
-        return lambda: hpc.group_gemm_pertensor_fp8(x, wt, sl, cud, ys, num_seq_per_group_avg=avg, output=out), 2.0 * M * n * k
-    return lambda: hpc.group_gemm_blockwise_fp8(x, wt, sl, cud, xs_t, wsc, num_seq_per_group_avg=avg, output=out), 2.0 * M * n * k
-cases = []
-for nm, sl in (("routed", routed), ("even512", torch.full((E,), M // E, dtype=torch.int32))):
+        return lambda: hpc.group_gemm_pertensor_fp8(x, wt, sl, cud, ys, num_seq_per_group_avg=avg, output=out), 2.0 * M * n * k, out
+    return lambda: hpc.group_gemm_blockwise_fp8(x, wt, sl, cud, xs_t, wsc, num_seq_per_group_avg=avg, output=out), 2.0 * M * n * k, out
+cases, first = [], {}
+for nm, sl in [("routed", routed), ("even512", torch.full((E,), M // E, dtype=torch.int32))] + \
+              [(f"even{r}", torch.full((E,), r, dtype=torch.int32)) for r in ROWS]:
     cases.append((f"gate_up {nm}",) + case(sl, m_["guw"], m_["guws"]))
     cases.append((f"down    {nm}",) + case(sl, m_["dw"], m_["dws"]))
+if ONLY:
+    cases = [c for c in cases if any(o in c[0] for o in ONLY)]
 for cfg in (sys.argv[1:] or ["3=2", "3=4"]):
     pairs = [tuple(int(x) for x in kv.split("=")) for kv in cfg.split(",") if kv]
     for k, v in pairs: _C.lib.hpc_dev_tuning_set(k, v)
-    for nm, fn, fl in cases:
+    for nm, fn, fl, out in cases:
+        out.zero_()
         us = bench.timed(fn, iters=10, warm=3, graph=True)
-        print(f"[{cfg or 'default':>10}] {nm}: {us:9.1f} us  {fl / us / 1e6:8.1f} TFLOP/s", flush=True)
+        torch.cuda.synchronize()
+        if nm not in first:  # every configuration must reproduce the first one's output (same arithmetic, other schedule)
+            first[nm] = out.clone()
+            same = "reference"
+        else:
+            same = "identical" if torch.equal(first[nm], out) else f"DIFFERS max {float((first[nm].float() - out.float()).abs().max()):.3g}"
+        print(f"[{cfg or 'default':>10}] {nm}: {us:9.1f} us  {fl / us / 1e6:8.1f} TFLOP/s  ({same})", flush=True)
     for k, v in pairs: _C.lib.hpc_dev_tuning_set(k, 0)
