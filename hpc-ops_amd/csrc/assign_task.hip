@@ -20,6 +20,7 @@
 
 #include "../../include/hpc_amd.h"
 #include "hpc_common.h"
+#include "hpc_dev.h"
 #include "sched_task_info.h"
 
 namespace hpc {
@@ -245,6 +246,8 @@ extern "C" int hpc_attention_decode_num_bins(int num_seq_q, int device_id) {
   if (num_seq_q < 1 || num_seq_q > kMaxSeqQ) return HPC_ERR_INVALID;
   const int cus = hpc_get_cu_count(device_id);
   if (cus <= 0) return HPC_ERR_LAUNCH;
+  const int dev_bins = hpc_dev_tuning_get(34);  // development: bin count override (A/B of the bin size on small problems)
+  if (dev_bins > 0 && dev_bins <= 4 * cus) return dev_bins;
   return cus * cta_per_cu(num_seq_q);
 }
 

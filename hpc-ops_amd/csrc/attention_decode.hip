@@ -51,7 +51,9 @@ struct Args {
   uint16_t* y;
   float* part_o;    // [bins][2][16*kNB][128]
   float* part_lse;  // [bins][2][16*kNB]
-  int* first_bin;   // [Hkv*B]
+  int* first_bin;   // [Hkv*B]  (combine-kernel form only)
+  int* arrive;      // [Hkv*B] arrival counters of split requests (zero before the call, left zero), or null: the
+                    // chunks of a request are merged by decode_combine_kernel in a second launch
   const float* qscale;  // fp8: [B*Sq, qscale_stride]
   const float* kscale;  // fp8: [1] (per tensor) or base of the K-scale rows of the cache (per token)
   const float* vscale;  // fp8: [1] or [Hkv]
@@ -110,6 +112,11 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
   const int G = 1 << a.g_shift;
   const int rows_valid = a.num_seq_q << a.g_shift;
   const int page_mask = (1 << a.page_shift) - 1;
+  // fp32 partials of split requests go THROUGH to memory (sc1 stores, aux = 16) and are read back with sc1 loads by the
+  // workgroup that arrives last at the request: per-XCD L2s are not coherent with each other (attention_decode_v2.hip)
+  const auto part_rs = make_rsrc(a.part_o);
+  const auto lse_rs = make_rsrc(a.part_lse);
+  __shared__ int s_ticket;
   const uint8_t* qbase = static_cast<const uint8_t*>(a.q);
   const uint8_t* kbase = static_cast<const uint8_t*>(a.kcache);
   const uint8_t* vbase = static_cast<const uint8_t*>(a.vcache);
@@ -438,11 +445,15 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
         for (int i = 0; i < 4; ++i) pk[i] = pack_bf16x2(acc[2 * i], acc[2 * i + 1]);
         st16(dst, pk);
       } else {
-        const long slot = static_cast<long>(bin) * 2 + (ichunk == 0 ? 1 : 0);
-        float* po = a.part_o + ((slot * kNB * 16) + row) * 128 + c8 * 8;
-        *reinterpret_cast<f32x4*>(po) = f32x4{acc[0], acc[1], acc[2], acc[3]};
-        *reinterpret_cast<f32x4*>(po + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
-        if (c8 == 0) a.part_lse[slot * kNB * 16 + row] = L > 0.f ? M + __builtin_amdgcn_logf(L) : kNegInf;
+        const int slot = bin * 2 + (ichunk == 0 ? 1 : 0);
+        const int prow = slot * kNB * 16 + row;
+        const int off = (prow * 128 + c8 * 8) * 4;
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]),
+                                                     __float_as_uint(acc[3])}, part_rs, off, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(acc[4]), __float_as_uint(acc[5]), __float_as_uint(acc[6]),
+                                                     __float_as_uint(acc[7])}, part_rs, off + 16, 0, 16);
+        if (c8 == 0)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(L > 0.f ? M + __builtin_amdgcn_logf(L) : kNegInf), lse_rs, prow * 4, 0, 16);
       }
     };
 #pragma unroll
@@ -506,7 +517,86 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
         __syncthreads();
       }
     }
-    if ((kSolo ? lane == 0 : tid == 0) && nchunks > 1 && ichunk == 0) {
+    if (nchunks > 1 && a.arrive) {
+      // ---- split request, merged inside the launch (the reference's static path does the same: the last CTA of a
+      // request reduces, static_splitk_kernels.cuh:362-377; math of splitk_combine_kernels.cuh:140-322) ----------------
+      // This chunk's partial has reached memory (sc1 stores, vmcnt(0) above - team: every thread's, behind the
+      // barrier).  One atomic add on the request's counter (zero on first use: the contract of
+      // hpc_attention_decode_workspace_zero_bytes(); the last arriver puts the zero back); the chunk that arrives LAST
+      // folds all of them - chunk c of a request lives in bin (bin - ichunk) + c, slot 1 for c == 0 and slot 0 otherwise -
+      // with 8 chunks' loads in flight per thread and a running maximum (one pass), and writes y.
+      int* cnt = a.arrive + h * a.num_batch + b;
+      int ticket = 0;
+      if constexpr (kSolo) {
+        if (lane == 0) ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        ticket = __builtin_amdgcn_readfirstlane(ticket);
+      } else {
+        if (tid == 0) s_ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        __syncthreads();
+        ticket = s_ticket;
+      }
+      if (ticket == nchunks) {
+        const int fb = bin - ichunk;
+        auto merge_row = [&](int nb, int row16, int c8) {
+          const int row = nb * 16 + row16;
+          if (row >= rows_valid) return;
+          float Mr = kNegInf, W = 0.f, acc[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+          for (int c0 = 0; c0 < nchunks; c0 += 8) {
+            float l8[8];
+            u32x4 x0[8], x1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const int c = c0 + u < nchunks ? c0 + u : nchunks - 1;
+              const int prow = ((fb + c) * 2 + (c == 0 ? 1 : 0)) * kNB * 16 + row;
+              l8[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(lse_rs, prow * 4, 0, 16));
+              const int off = (prow * 128 + c8 * 8) * 4;
+              x0[u] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, off, 0, 16);
+              x1[u] = __builtin_amdgcn_raw_buffer_load_b128(part_rs, off + 16, 0, 16);
+            }
+            float mb = Mr;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) mb = fmaxf(mb, c0 + u < nchunks ? l8[u] : kNegInf);
+            const float mu = mb == kNegInf ? 0.f : mb;
+            const float sc_old = __builtin_amdgcn_exp2f(Mr - mu);  // Mr = -inf: 0 (nothing folded yet)
+            Mr = mb;
+            W *= sc_old;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] *= sc_old;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              const float wgt = c0 + u < nchunks ? __builtin_amdgcn_exp2f(l8[u] - mu) : 0.f;
+              W += wgt;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                acc[i] = fmaf(wgt, __uint_as_float(x0[u][i]), acc[i]);
+                acc[4 + i] = fmaf(wgt, __uint_as_float(x1[u][i]), acc[4 + i]);
+              }
+            }
+          }
+          const float inv = W > 0.f ? 1.0f / W : 0.f;
+          const int rs = row >> a.g_shift;
+          uint16_t* dst = a.y + static_cast<long>(b * a.num_seq_q + rs) * a.ldy + ((h << a.g_shift) + (row & (G - 1))) * 128 + c8 * 8;
+          u32x4 pk;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pk[i] = pack_bf16x2(acc[2 * i] * inv, acc[2 * i + 1] * inv);
+          st16(dst, pk);
+        };
+#pragma unroll 1
+        for (int nb = 0; nb < kNB; ++nb) {
+          if constexpr (kSolo) {
+#pragma unroll 1
+            for (int it = 0; it < 4; ++it) merge_row(nb, it * 4 + (lane >> 4), lane & 15);
+          } else {
+            merge_row(nb, tid >> 4, tid & 15);
+          }
+        }
+        if (kSolo ? lane == 0 : tid == 0) __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next call
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // retire the stores before the next task's loads (vmcnt counts both)
+      }
+      if constexpr (!kSolo) __syncthreads();  // s_ticket is free again
+    } else if ((kSolo ? lane == 0 : tid == 0) && nchunks > 1 && ichunk == 0) {
       a.first_bin[h * a.num_batch + b] = bin;
       __builtin_amdgcn_s_waitcnt(0x0F70);
     }
@@ -623,8 +713,10 @@ int launch(const Args& a, int num_bins, int num_nb, hipStream_t stream) {
   }
 #undef HPC_DECODE_LAUNCH
   HPC_CHECK_LAUNCH();
-  decode_combine_kernel<<<a.num_batch * a.num_head_kv * num_nb, kThreads, 0, stream>>>(a, num_nb);
-  HPC_CHECK_LAUNCH();
+  if (!a.arrive) {  // more (kv head, request) pairs than arrival counters: the chunks are merged by a second launch
+    decode_combine_kernel<<<a.num_batch * a.num_head_kv * num_nb, kThreads, 0, stream>>>(a, num_nb);
+    HPC_CHECK_LAUNCH();
+  }
   return HPC_OK;
 }
 
@@ -670,7 +762,11 @@ inline Common fill_common(Args& a, void* y_ptr, void* workspace, const int* task
   a.block_ids = block_ids_ptr;
   a.task_map = task_map_ptr;
   a.y = static_cast<uint16_t*>(y_ptr);
-  char* ws = static_cast<char*>(workspace) + hpc::decode2::kCounterBytes;  // the workspace starts with the v2 arrival counters
+  // the workspace starts with the arrival counters of split requests (zero-once region, shared with the second
+  // generation: one of the two runs per call); development key 33 = 1: the round-1 form (combine kernel)
+  a.arrive = static_cast<int64_t>(num_batch) * num_head_kv * 4 <= hpc::decode2::kCounterBytes && hpc_dev_tuning_get(33) != 1
+                 ? static_cast<int*>(workspace) : nullptr;
+  char* ws = static_cast<char*>(workspace) + hpc::decode2::kCounterBytes;
   a.part_o = reinterpret_cast<float*>(ws);
   ws += static_cast<int64_t>(num_bins) * 2 * 16 * c.num_nb * 128 * 4;
   a.part_lse = reinterpret_cast<float*>(ws);

@@ -51,70 +51,99 @@ struct IntC {
   static constexpr int value = kN;
 };
 
-// The work item of this workgroup: items are ordered group -> weight tile -> 256-token tile and dealt to the XCDs
-// in contiguous eighths (as in the 256 x 128 kernel).  The 256-token tile counts come from the scan of
-// ceil(len / 128) the callers already have; one pass of loads: lane g holds group g0 + g.
+// The work item of this workgroup.  Items are dealt to the XCDs in contiguous eighths (workgroup `lin` -> XCD lin % 8,
+// position lin / 8 of that XCD's share), so that the token tiles sharing a weight tile meet in one L2.  The 256-token
+// tile counts come from the scan of ceil(len / 128) the callers already have (`cut`): c = cut[g + 1] - cut[g] 128-row
+// tiles = c / 2 FULL 256-token tiles + (c odd) one tail tile of <= 128 rows, which runs the half-tile body.
+//   order 0 (round 2-4): group -> weight tile -> token tile, tail tiles in place;
+//   order 1 (round 5): all full tiles first (group -> weight tile -> token tile), then all tail tiles (group -> weight
+//     tile).  A tail tile costs ~0.7 of a full one, and the dispatcher hands workgroups out in index order: with the
+//     tails in place the last round of a launch mixes full and tail tiles and the launch ends with the CU that drew a
+//     full tile last; with the cheap items last the tail of the launch is filled evenly (the down GEMM of the MoE has
+//     only ~9.4 items per CU: 64 x 2 x 16 = 2048 full tiles = exactly 8 per CU, then 2 tail tiles each).  The tail
+//     tiles then re-read their weight tile from memory instead of meeting it in L2 - 2.7 GB more HBM reads on the
+//     gate-up GEMM, far from the HBM limit at this arithmetic intensity.
+// One round of lane-parallel loads per 64 groups; with <= 64 groups everything comes from one round.
 struct Item {
-  int e, rem, mtiles, m_cnt, m0;
+  int e, mt, wt, m_cnt, m0;  // group, 256-token tile of the group, weight tile, rows of the group, its first row
   bool valid;
 };
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(v, o, 64);
+    v += lane >= o ? u : 0;
+  }
+  return v;
+}
 __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, const int* cu_seqlens, int num_group,
-                                            int nt, int lane, int lin) {
+                                            int nt, int lane, int lin, int order) {
   Item it = {0, 0, 0, 0, 0, false};
-  if (num_group <= 64) {  // the usual case: everything from one round of loads
-    const bool on = lane < num_group;
-    const int t = on ? ((cut[lane + 1] - cut[lane] + 1) >> 1) : 0;
-    const int len = on ? seqlens[lane] : 0, row0 = on ? cu_seqlens[lane] : 0;
-    int inc = t;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(inc, o, 64);
-      inc += lane >= o ? v : 0;
-    }
-    const int total = __shfl(inc, 63, 64) * nt;
-    const int chunk = (total + 7) >> 3;
-    const int item = (lin & 7) * chunk + (lin >> 3);
-    if ((lin >> 3) >= chunk || item >= total) return it;
-    const unsigned long long hit = __ballot(on && item < inc * nt);
-    const int l = __builtin_ctzll(hit);
-    it.e = l;
-    it.mtiles = __shfl(t, l, 64);
-    it.rem = item - (__shfl(inc, l, 64) - it.mtiles) * nt;
-    it.m_cnt = __shfl(len, l, 64);
-    it.m0 = __shfl(row0, l, 64);
-    it.valid = true;
-    return it;
-  }
-  int total = 0;
+  const int x = lin & 7, j = lin >> 3;
+  // round 0 of every per-group quantity is loaded once, side by side
+  const bool on0 = lane < num_group;
+  const int c_first = on0 ? cut[lane + 1] - cut[lane] : 0;
+  const int len_first = on0 ? seqlens[lane] : 0, row_first = on0 ? cu_seqlens[lane] : 0;
+  auto tiles128 = [&](int g0) { return g0 == 0 ? c_first : (g0 + lane < num_group ? cut[g0 + lane + 1] - cut[g0 + lane] : 0); };
+  // pass 1: totals
+  int tot_f = 0, tot_h = 0;
   for (int g0 = 0; g0 < num_group; g0 += 64) {
-    const int g = g0 + lane;
-    int t = g < num_group ? ((cut[g + 1] - cut[g] + 1) >> 1) : 0;
+    const int c = tiles128(g0);
+    int f = c >> 1, h = c & 1;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-    total += t;
+    for (int o = 32; o > 0; o >>= 1) {
+      f += __shfl_xor(f, o, 64);
+      h += __shfl_xor(h, o, 64);
+    }
+    tot_f += f;
+    tot_h += h;
   }
-  total *= nt;
-  const int chunk = (total + 7) >> 3;
-  const int item = (lin & 7) * chunk + (lin >> 3);
-  if ((lin >> 3) >= chunk || item >= total) return it;
+  int idx, kind;  // kind 0: every 256-token tile of a group (order 0), 1: full tiles only, 2: tail tiles only
+  if (order == 0) {
+    const int total = (tot_f + tot_h) * nt, chunk = (total + 7) >> 3;
+    idx = x * chunk + j;
+    kind = 0;
+    if (j >= chunk || idx >= total) return it;
+  } else {
+    const int total_f = tot_f * nt, total_h = tot_h * nt;
+    const int chunk_f = (total_f + 7) >> 3, chunk_h = (total_h + 7) >> 3;
+    if (j < chunk_f) {
+      idx = x * chunk_f + j;
+      kind = 1;
+      if (idx >= total_f) return it;
+    } else {
+      if (j - chunk_f >= chunk_h) return it;
+      idx = x * chunk_h + j - chunk_f;
+      kind = 2;
+      if (idx >= total_h) return it;
+    }
+  }
+  // pass 2: the group that holds item idx
   int base = 0;
   for (int g0 = 0; g0 < num_group; g0 += 64) {
-    const int g = g0 + lane;
-    const int t = g < num_group ? ((cut[g + 1] - cut[g] + 1) >> 1) : 0;
-    int inc = t;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int v = __shfl_up(inc, o, 64);
-      inc += lane >= o ? v : 0;
-    }
-    const unsigned long long hit = __ballot(g < num_group && item < (base + inc) * nt);
+    const int c = tiles128(g0);
+    const int t = kind == 0 ? (c + 1) >> 1 : (kind == 1 ? c >> 1 : c & 1);
+    const int inc = wave_incl_scan(t, lane);
+    const unsigned long long hit = __ballot(g0 + lane < num_group && idx < (base + inc) * nt);
     if (hit) {
       const int l = __builtin_ctzll(hit);
+      const int tl = __shfl(t, l, 64), cl = __shfl(c, l, 64);
+      const int rem = idx - (base + __shfl(inc, l, 64) - tl) * nt;
       it.e = g0 + l;
-      it.mtiles = __shfl(t, l, 64);
-      it.rem = item - (base + __shfl(inc, l, 64) - it.mtiles) * nt;
-      it.m_cnt = as_const(seqlens)[it.e];
-      it.m0 = as_const(cu_seqlens)[it.e];
+      if (kind == 2) {
+        it.wt = rem;
+        it.mt = cl >> 1;
+      } else {
+        it.wt = rem / tl;
+        it.mt = rem % tl;
+      }
+      if (g0 == 0) {
+        it.m_cnt = __shfl(len_first, l, 64);
+        it.m0 = __shfl(row_first, l, 64);
+      } else {
+        it.m_cnt = as_const(seqlens)[it.e];
+        it.m0 = as_const(cu_seqlens)[it.e];
+      }
       it.valid = true;
       return it;
     }
@@ -132,8 +161,14 @@ __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, co
 // Y-half pieces of T-1 and the pieces of this load section; the wait that ends load section Y must see all of k-tile T+1's
 // Y-half pieces landed - everything but the X-half pieces of T and the pieces of this load section.
 struct CfgProduct {
-  static constexpr bool kCarry = false;    // the rescale of a section's last two blocks rides under the next section's first MFMAs
-  static constexpr bool kDmaFirst = false; // load sections issue their DMA pieces before their operand reads
+  // the rescale of a section's last kDist blocks rides under the next section's first MFMAs instead of sitting in the load
+  // section behind the barrier (round 5, measured: gate-up / down GEMM of the MoE 3507 / 1671 -> 3088 / 1548 us routed,
+  // 2.02 / 2.13 -> 2.21 / 2.32 PFLOP/s at 512 rows per expert, bit-identical results - a load section's VALU work loses
+  // every issue slot to the MMA wave of its SIMD)
+  static constexpr bool kCarry = true;
+  static constexpr int kDist = 2;          // the rescale of block n follows the MFMA of block n + kDist
+  static constexpr int kEarly = 0;         // the barrier that ends an MMA section sits in front of its last kEarly MFMAs
+  static constexpr bool kDmaFirst = false; // load sections issue their DMA pieces before their operand reads (measured: -4 %)
   static constexpr bool kPrio = true;      // s_setprio 1 around the MFMAs
   static constexpr bool kProf = false;     // s_memtime log of the section boundaries (development)
   static constexpr int fx(int i) { constexpr int t[2] = {0, 0}; return t[i]; }
@@ -143,32 +178,28 @@ struct CfgProduct {
 };
 #ifdef HPC_DEV
 struct CfgProf : CfgProduct { static constexpr bool kProf = true; };
-struct CfgCarry : CfgProduct { static constexpr bool kCarry = true; };
-struct CfgDmaFirst : CfgProduct { static constexpr bool kDmaFirst = true; };
+struct CfgRound4 : CfgProduct { static constexpr bool kCarry = false; };  // the round-4 loop (tails behind the barrier)
+struct CfgRound4Prof : CfgRound4 { static constexpr bool kProf = true; };
 struct CfgNoPrio : CfgProduct { static constexpr bool kPrio = false; };
-// schedules: S1 = load section X carries no piece (U3 behind MFMAs 4 / 10 of section X)
-struct CfgS1 : CfgProduct {
+struct CfgDist3 : CfgProduct { static constexpr int kDist = 3; };
+struct CfgEarly2 : CfgProduct { static constexpr int kEarly = 2; };
+struct CfgEarly4 : CfgProduct { static constexpr int kEarly = 4; };
+// schedules: S3 = no piece in any load section (U3 behind MFMAs 4 / 10 of section X, the Y half spread over section Y)
+struct CfgS3 : CfgProduct {
   static constexpr int fx(int i) { constexpr int t[2] = {5, 11}; return t[i]; }
   static constexpr int hx(int i) { constexpr int t[2] = {2, 6}; return t[i]; }
-};
-// S2 = S1 + load section Y carries two pieces instead of four
-struct CfgS2 : CfgS1 {
-  static constexpr int fy(int i) { constexpr int t[7] = {0, 0, 2, 5, 8, 11, 14}; return t[i]; }
-  static constexpr int hy(int i) { constexpr int t[7] = {0, 0, 2, 4, -1, -1, 7}; return t[i]; }
-};
-// S3 = no piece in any load section
-struct CfgS3 : CfgS1 {
   static constexpr int fy(int i) { constexpr int t[7] = {1, 3, 5, 7, 9, 11, 14}; return t[i]; }
   static constexpr int hy(int i) { constexpr int t[7] = {1, 2, 4, 5, -1, -1, 7}; return t[i]; }
 };
-// the half-tile body alone on schedule S3 (its MMA sections are half as long as its load sections: the pieces cost nothing there)
-struct CfgH3 : CfgProduct {
-  static constexpr int hx(int i) { return CfgS3::hx(i); }
-  static constexpr int hy(int i) { return CfgS3::hy(i); }
+// S4 = everything in the load sections (the MMA sections carry MFMAs and FMAs only)
+struct CfgS4 : CfgProduct {
+  static constexpr int fy(int i) { constexpr int t[7] = {0, 0, 0, 0, 0, 0, 0}; return t[i]; }
+  static constexpr int hy(int i) { constexpr int t[7] = {0, 0, 0, 0, -1, -1, 0}; return t[i]; }
 };
-struct CfgCarryS1 : CfgS1 { static constexpr bool kCarry = true; };
-struct CfgCarryH3 : CfgH3 { static constexpr bool kCarry = true; };
-struct CfgCarryProf : CfgCarry { static constexpr bool kProf = true; };
+struct CfgNoPrioEarly2 : CfgEarly2 { static constexpr bool kPrio = false; };
+struct CfgNoPrioS3 : CfgS3 { static constexpr bool kPrio = false; };
+struct CfgNoPrioEarly2S3 : CfgNoPrioS3 { static constexpr int kEarly = 2; };
+struct CfgNoPrioDist3 : CfgDist3 { static constexpr bool kPrio = false; };
 #endif
 
 // kNoDma (development key 18 = 1, timing only - results are wrong): no DMA inside the k-loop
@@ -267,11 +298,15 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(base + (wave * 2 + q) * 1024), 16,
                                              k_ok ? x_voff[kLate][q] : 0xffffff00u, koff, 0, 0);
   };
+  const unsigned xs_nrec = __builtin_amdgcn_readfirstlane(wave < 4 ? 0xffffffffu : 0u);
   auto dma_xs = [&](int T, bool on, auto par) {
     constexpr int kP = decltype(par)::value;
     if constexpr (kHasXs) {
       // all eight waves issue it (the vmcnt arithmetic needs equal counts); waves 4-7 fetch nothing
-      const auto rs = make_rsrc(a.xs, __builtin_amdgcn_readfirstlane(on && wave < 4 ? 0xffffffffu : 0u));
+      // (the wave's share of the select is hoisted out of the loop: round 4 evaluated `on && wave < 4` through
+      // v_cndmask + v_readfirstlane per k-tile - VALU work in a load section, which loses every issue slot to the MMA
+      // wave of its SIMD; what is left is a scalar select on `on`)
+      const auto rs = make_rsrc(a.xs, on ? xs_nrec : 0u);
       uint8_t* dst = s_mem + kXsOff + (wave < 4 ? kP * 1024 + wave * 256 : 2048);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 4, xs_voff, T * xs_kb_bytes, 0, 0);
     }
@@ -319,12 +354,17 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   // MFMAs of the NEXT section (`pend`, with the scales `fpend` of the k-tile they belong to): the load sections carry no
   // FMA, a section's head needs no hazard padding (its first FMAs read results that are a whole load section old), and
   // the new k-tile's four scale products (`pre`) sit behind MFMA 0 instead of in front of it.
-  constexpr int kN = 4 * kJ;  // MFMAs per section
-  f32x4 pend[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  constexpr int kN = 4 * kJ;       // MFMAs per section
+  constexpr int kD = Cfg::kDist;   // the rescale of block n follows the MFMA of block n + kD
+  f32x4 pend[kD];
   float fpend[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < kD; ++t) pend[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   auto section = [&](int i0, const u32x4 (&af)[4][2], const u32x4 (&be)[2][2], const u32x4 (&bl)[2][2], float (&f)[4],
-                     f32x4 (&tail)[2], auto&& pre, auto&& hook) {
-    f32x4 prev1 = {0.f, 0.f, 0.f, 0.f}, prev2 = {0.f, 0.f, 0.f, 0.f};
+                     auto&& pre, auto&& hook, auto&& early_leave) {
+    f32x4 pv[kD];  // pv[0] = the newest partial
+#pragma unroll
+    for (int t = 0; t < kD; ++t) pv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int n = 0; n < kN; ++n) {
       const int i = n / kJ, j = n % kJ;
@@ -338,20 +378,21 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       if constexpr (kHasXs) {
         const f32x4 part = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0,
                                                                             0, 0);
-        __builtin_amdgcn_sched_barrier(0);  // MFMA n first, then the rescale of block n - 2
-        if (n > 1) {
-          const int pi = (n - 2) / kJ, pj = (n - 2) % kJ;
+        __builtin_amdgcn_sched_barrier(0);  // MFMA n first, then the rescale of block n - kD
+        if (n >= kD) {
+          const int pi = (n - kD) / kJ, pj = (n - kD) % kJ;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) tot[i0 + pi][pj][r] = fmaf(prev2[r], f[pj], tot[i0 + pi][pj][r]);
+          for (int r = 0; r < 4; ++r) tot[i0 + pi][pj][r] = fmaf(pv[kD - 1][r], f[pj], tot[i0 + pi][pj][r]);
         } else if constexpr (Cfg::kCarry) {
-          // blocks kN - 2 + n of the PREVIOUS section (the other row half: 4 - i0), under the scales of their k-tile
+          // block kN - kD + n of the PREVIOUS section (the other row half: 4 - i0), under the scales of its k-tile
+          const int pi = (kN - kD + n) / kJ, pj = (kN - kD + n) % kJ;
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            tot[4 - i0 + 3][kJ - 2 + n][r] = fmaf(pend[n][r], fpend[kJ - 2 + n], tot[4 - i0 + 3][kJ - 2 + n][r]);
+          for (int r = 0; r < 4; ++r) tot[4 - i0 + pi][pj][r] = fmaf(pend[n][r], fpend[pj], tot[4 - i0 + pi][pj][r]);
           if (n == 0) pre();
         }
-        prev2 = prev1;
-        prev1 = part;
+#pragma unroll
+        for (int t = kD - 1; t > 0; --t) pv[t] = pv[t - 1];
+        pv[0] = part;
       } else {
         // per-tensor: one scale per group: accumulate straight into the running sum, scale once in the epilogue
         // (the reference scales every k-tile: same value up to fp32 rounding)
@@ -360,23 +401,24 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       __builtin_amdgcn_sched_barrier(0);
       hook(n);
       __builtin_amdgcn_sched_barrier(0);
+      if (n == kN - 1 - Cfg::kEarly) early_leave();
     }
-    if constexpr (Cfg::kCarry && kHasXs) {
-      pend[0] = prev2;
-      pend[1] = prev1;
+    if constexpr (kHasXs) {  // the last kD partials: block kN - kD + t <- pv[kD - 1 - t]
+#pragma unroll
+      for (int t = 0; t < kD; ++t) pend[t] = pv[kD - 1 - t];
 #pragma unroll
       for (int j = 0; j < 4; ++j) fpend[j] = f[j];
-    } else {
-      tail[0] = prev2;
-      tail[1] = prev1;
     }
   };
-  auto apply_tail = [&](int i0, const float (&f)[4], const f32x4 (&tail)[2]) {
+  // without Cfg::kCarry the pending blocks are folded right behind the barrier that ends the section (round 2-4 form)
+  auto apply_tail = [&](int i0) {
     if constexpr (kHasXs && !Cfg::kCarry) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < kD; ++t) {
+        const int pi = (kN - kD + t) / kJ, pj = (kN - kD + t) % kJ;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tot[i0 + 3][kJ - 2 + t][r] = fmaf(tail[t][r], f[kJ - 2 + t], tot[i0 + 3][kJ - 2 + t][r]);
+        for (int r = 0; r < 4; ++r) tot[i0 + pi][pj][r] = fmaf(pend[t][r], fpend[pj], tot[i0 + pi][pj][r]);
+      }
     }
   };
 
@@ -439,8 +481,8 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     if constexpr (Cfg::kPrio) __builtin_amdgcn_s_setprio(1);
     stamp(ts_a);
   };
-  auto leave_mma = [&]() {
-    if constexpr (Cfg::kPrio) __builtin_amdgcn_s_setprio(0);
+  auto leave_mma = [&]() {  // (Cfg::kEarly > 0: called in front of the section's last kEarly MFMAs)
+    if constexpr (Cfg::kPrio && Cfg::kEarly == 0) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     stamp(ts_b);
     __builtin_amdgcn_s_barrier();
@@ -475,7 +517,6 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   __builtin_amdgcn_sched_barrier(0);
 
   u32x4 a_frag[4][2], b_early[2][2], b_late[2][2];
-  f32x4 tail[2];
   float f[4] = {1.f, 1.f, 1.f, 1.f};
   auto k_tile = [&](int T, auto par) {
     constexpr int kP = decltype(par)::value;
@@ -529,9 +570,9 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       for (int j = 0; j < 4; ++j) f[j] = wsk * xsv[j];
     };
     if constexpr (!(Cfg::kCarry && kHasXs)) make_f();
-    section(0, a_frag, b_early, b_late, f, tail, make_f, [&](int n) { issue_x(n + 1); });
-    leave_mma();
-    apply_tail(0, f, tail);
+    section(0, a_frag, b_early, b_late, f, make_f, [&](int n) { issue_x(n + 1); }, leave_mma);
+    if constexpr (Cfg::kPrio && Cfg::kEarly > 0) __builtin_amdgcn_s_setprio(0);
+    apply_tail(0);
     // ---- section Y: rows 64-127 ----------------------------------------------------------------------------
     if constexpr (Cfg::kDmaFirst) {
       issue_y(0);
@@ -540,19 +581,21 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     read_a(buf + 3 * kUnit, a_frag);
     if constexpr (!Cfg::kDmaFirst) issue_y(0);
     enter_mma(fly_y);
-    section(4, a_frag, b_early, b_late, f, tail, [] {}, [&](int n) { issue_y(n + 1); });
-    leave_mma();
-    apply_tail(4, f, tail);
+    section(4, a_frag, b_early, b_late, f, [] {}, [&](int n) { issue_y(n + 1); }, leave_mma);
+    if constexpr (Cfg::kPrio && Cfg::kEarly > 0) __builtin_amdgcn_s_setprio(0);
+    apply_tail(4);
   };
   for (int kb = 0; kb < KB; kb += 2) {
     k_tile(kb, IntC<0>{});
     if (kb + 1 < KB) k_tile(kb + 1, IntC<1>{});
   }
-  if constexpr (Cfg::kCarry && kHasXs) {  // the last section's last two blocks (row half 4 .. 7)
+  if constexpr (Cfg::kCarry && kHasXs) {  // the last section's pending blocks (row half 4 .. 7)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < kD; ++t) {
+      const int pi = (kN - kD + t) / kJ, pj = (kN - kD + t) % kJ;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tot[7][kJ - 2 + t][r] = fmaf(pend[t][r], fpend[kJ - 2 + t], tot[7][kJ - 2 + t][r]);
+      for (int r = 0; r < 4; ++r) tot[4 + pi][pj][r] = fmaf(pend[t][r], fpend[pj], tot[4 + pi][pj][r]);
+    }
   }
   if constexpr (Cfg::kProf) {
     if (a.prof && blockIdx.x < 16)
@@ -693,15 +736,14 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
                                                                   int num_group) {
   __shared__ __attribute__((aligned(1024))) uint8_t s_mem[kLds];
   const int nt = a.N / kBN;  // kAct: N = 2 * inter, tile tn = columns [tn * 128, +128) of gate and of up
-  const Item it = locate_item(as_const(cu_tiles), a.seqlens, a.cu_seqlens, num_group, nt, threadIdx.x & 63, blockIdx.x);
+  const Item it = locate_item(as_const(cu_tiles), a.seqlens, a.cu_seqlens, num_group, nt, threadIdx.x & 63, blockIdx.x,
+                              a.item_order);
   if (!it.valid) return;
   const int e = __builtin_amdgcn_readfirstlane(it.e);
-  const int rem = __builtin_amdgcn_readfirstlane(it.rem);
-  const int mtiles = __builtin_amdgcn_readfirstlane(it.mtiles);
   const int m_cnt = __builtin_amdgcn_readfirstlane(it.m_cnt);
   const int m0 = __builtin_amdgcn_readfirstlane(it.m0);
-  const int mt0 = (rem % mtiles) * kBM;
-  const int n0 = (rem / mtiles) * kBN;
+  const int mt0 = __builtin_amdgcn_readfirstlane(it.mt) * kBM;
+  const int n0 = __builtin_amdgcn_readfirstlane(it.wt) * kBN;
   // a group's last token tile with <= 128 rows runs the half-tile body (development key 21 = 1: never)
   if (m_cnt - mt0 <= 128 && !a.no_half_tile)
     p8_body<Cfg, kHasXs, kNoDma, kAct, true>(a, s_mem, e, mt0, n0, m_cnt, m0);
@@ -739,7 +781,8 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int n
   a.no_half_tile = hpc_dev_tuning_get(21) == 1;
   if (n % kBN || a.K < kBK) return HPC_ERR_UNSUPPORTED;
   const long max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 256)
-  const long items = max_tiles * (n / kBN) + 8;  // + 8: the per-XCD chunks round up
+  const long items = max_tiles * (n / kBN) + 16;  // + 16: the per-XCD chunks of the full and of the tail tiles round up
+  a.item_order = hpc_dev_tuning_get(23) == 1 ? 0 : 1;  // development key 23 = 1: the round-4 item order (tail tiles in place)
   if (items > 0x7fffffffl) return HPC_ERR_UNSUPPORTED;
   dim3 grid(static_cast<unsigned>(items));
 #ifdef HPC_DEV
@@ -747,16 +790,18 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int n
   if (a.has_xs && hpc_dev_tuning_get(22) > 0) {
     switch (hpc_dev_tuning_get(22)) {
       case 1: launch_blockwise_variant<CfgProf>(a, cu_tiles, num_group, grid, stream); break;
-      case 2: launch_blockwise_variant<CfgCarry>(a, cu_tiles, num_group, grid, stream); break;
-      case 3: launch_blockwise_variant<CfgDmaFirst>(a, cu_tiles, num_group, grid, stream); break;
+      case 2: launch_blockwise_variant<CfgRound4>(a, cu_tiles, num_group, grid, stream); break;
+      case 3: launch_blockwise_variant<CfgRound4Prof>(a, cu_tiles, num_group, grid, stream); break;
       case 4: launch_blockwise_variant<CfgNoPrio>(a, cu_tiles, num_group, grid, stream); break;
-      case 5: launch_blockwise_variant<CfgS1>(a, cu_tiles, num_group, grid, stream); break;
-      case 6: launch_blockwise_variant<CfgS2>(a, cu_tiles, num_group, grid, stream); break;
-      case 7: launch_blockwise_variant<CfgS3>(a, cu_tiles, num_group, grid, stream); break;
-      case 8: launch_blockwise_variant<CfgH3>(a, cu_tiles, num_group, grid, stream); break;
-      case 9: launch_blockwise_variant<CfgCarryS1>(a, cu_tiles, num_group, grid, stream); break;
-      case 10: launch_blockwise_variant<CfgCarryH3>(a, cu_tiles, num_group, grid, stream); break;
-      case 11: launch_blockwise_variant<CfgCarryProf>(a, cu_tiles, num_group, grid, stream); break;
+      case 5: launch_blockwise_variant<CfgDist3>(a, cu_tiles, num_group, grid, stream); break;
+      case 6: launch_blockwise_variant<CfgEarly2>(a, cu_tiles, num_group, grid, stream); break;
+      case 7: launch_blockwise_variant<CfgEarly4>(a, cu_tiles, num_group, grid, stream); break;
+      case 8: launch_blockwise_variant<CfgS3>(a, cu_tiles, num_group, grid, stream); break;
+      case 9: launch_blockwise_variant<CfgS4>(a, cu_tiles, num_group, grid, stream); break;
+      case 10: launch_blockwise_variant<CfgNoPrioEarly2>(a, cu_tiles, num_group, grid, stream); break;
+      case 11: launch_blockwise_variant<CfgNoPrioS3>(a, cu_tiles, num_group, grid, stream); break;
+      case 12: launch_blockwise_variant<CfgNoPrioEarly2S3>(a, cu_tiles, num_group, grid, stream); break;
+      case 13: launch_blockwise_variant<CfgNoPrioDist3>(a, cu_tiles, num_group, grid, stream); break;
       default: return HPC_ERR_INVALID;
     }
     HPC_CHECK_LAUNCH();

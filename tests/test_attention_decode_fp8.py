@@ -281,6 +281,26 @@ def test_attn_fp8_single_kv_head(block_size, num_seq_q):
 
 @pytest.mark.dev
 @pytest.mark.gpu
+@pytest.mark.parametrize("num_seq_q,heads,k_per_token,shape", [(1, (1, 8), False, "NHD"), (2, (4, 32), False, "HND"), (1, (2, 8), True, "NHD"),
+                                                             (4, (1, 4), False, "NHD")])
+def test_attn_fp8_first_generation_combine_kernel_form(num_seq_q, heads, k_per_token, shape):
+    """The first-generation kernel merges the chunks of a split request inside the launch (round 5: the chunk that
+    arrives last folds all of them - one atomic add per chunk on the zero-once counters at the start of the workspace;
+    team and one-task-per-wave forms, one / two q blocks).  Development key 33 = 1 keeps the round-1 form (fp32 partials
+    + decode_combine_kernel as a second launch), which still serves calls with more (kv head, request) pairs than
+    counters.  Both against the oracle on the same inputs, and the in-launch form twice in a row (counters left zero)."""
+    lens = torch.tensor([20000, 3, 9000, 130, 64, 63, 65, 4097, 700, 1, 127, 129, 31000, 2, 0, 255, 256, 257], dtype=torch.int32)
+    atol = 0.1 if k_per_token else 0.2
+    for key in (1, 0, 0):
+        dev_set(33, key)
+        try:
+            _run(len(lens), num_seq_q, lens, 64, heads, k_per_token, True, True, shape, atol)
+        finally:
+            dev_set(33, 0)
+
+
+@pytest.mark.dev
+@pytest.mark.gpu
 @pytest.mark.parametrize("form", ["four_heads"])  # (the head-pair form serves these shapes by default: every other test)
 @pytest.mark.parametrize("num_seq_q,block_size,heads", [(1, 64, (8, 64)), (1, 64, (4, 32)), (2, 32, (4, 16)), (1, 16, (4, 16)),
                                                          (2, 16, (8, 32)), (1, 32, (12, 48)), (1, 64, (16, 64))])

@@ -2,7 +2,7 @@
 The development build's profiling variants (development key 22 = 1 / 11, Cfg::kProf) log s_memtime stamps at the section
 boundaries of every wave of the first 16 work items: A = behind the barrier that opens an MMA section, B = behind its last
 MFMA, C = behind the barrier that closes it, D = end of the following load section's issue (in front of its wait).
-usage: python tools/prof_p8.py [--half] [key22 ...]      (default: 1 = product loop, 11 = carry variant)"""
+usage: python tools/prof_p8.py [--half] [key22 ...]      (default: 1 = product loop, 3 = round-4 loop)"""
 import os
 os.environ.setdefault("HPC_AMD_DEV", "1")
 import sys
@@ -36,7 +36,7 @@ buf = torch.zeros(16 * 8 * 64, dtype=torch.int32, device=dev)
 _C.lib.hpc_dev_p8_prof_buffer.argtypes = [ctypes.c_void_p]
 if HALF:
     _C.lib.hpc_dev_tuning_set(3, 4)  # always the 256 x 256 kernel: every item is a half tile
-for key in [int(a) for a in args] or [1, 11]:
+for key in [int(a) for a in args] or [1, 3]:
     _C.lib.hpc_dev_tuning_set(22, key)
     _C.lib.hpc_dev_p8_prof_buffer(ctypes.c_void_p(buf.data_ptr()))
     for _ in range(3):
@@ -63,6 +63,12 @@ for key in [int(a) for a in args] or [1, 11]:
                         if val < 100000:
                             acc.setdefault(name, []).append(val)
         res[grp] = {kk: sum(v) / len(v) for kk, v in acc.items()}
+    # raw timeline of workgroup 0: stamps relative to the first one logged, waves 0 and 4 (one per group, same SIMD pairings)
+    t0 = min(int(log[0, wv, 0, 0]) for wv in range(8))
+    for wv in (0, 4, 1, 5):
+        row = " ".join("[" + " ".join(f"{(int(v) - t0) & 0xFFFFFFFF:6d}" for v in log[0, wv, i]) + "]" for i in range(6))
+        print(f"   raw wg0 wave{wv} (A B C of the MMA section before | D of this load section) x 6 entries: {row}")
+    torch.save(log, str(ROOT / "gpurun_out" / f"r5_p8_prof_raw_{key}{'_half' if HALF else ''}.pt"))
     print(f"[22={key}{' half' if HALF else ''}] {us:8.1f} us  {2.0 * M * n * k / us / 1e6:7.1f} TFLOP/s (profiling build)")
     for grp, r in res.items():
         tot = sum(r.values())
