@@ -450,7 +450,9 @@ def moe_block(dev, hpc, with_cpu=True, iters=10):
 # ================================================================================ extras (N = 1)
 def extra_decode(dev, hpc):
     """secondary decode numbers: bf16 C2 (NHD + HND), fp8 uniform 8k, fp8 C3 on HND-backed pages and at the
-    reference benchmark's default heads (1 KV / 8 Q)."""
+    reference benchmark's default heads (1 KV / 8 Q).  `us` = per call with 10 calls per hipGraph replay (the headline's
+    method: these kernels take 20-350 us and a replay costs ~10 us whatever it holds - rounds 1-4 reported the
+    single-call replay here, i.e. kernel + ~10 us); `us_single_step_replay` = the reference benchmark's form."""
     out = {}
     w = dict(C2)
     B, P, D, Hkv, Hq, S = w["batch"], 64, 128, w["num_head_kv"], w["num_head_q"], w["seq_kv"]
@@ -471,9 +473,11 @@ def extra_decode(dev, hpc):
         rows = [0, 7, 21, 42, 63]
         err = c2_parity(inp, o, w, rows)
         assert err <= 0.016, f"bf16 decode ({name}) does not match the oracle: max abs err {err}"
-        us = timed(call, graph=True)
+        us = timed(call, graph=True, reps=10)   # like the headline: 10 calls per replay (a replay costs ~10 us whatever it holds)
+        us1 = timed(call, graph=True)           # the reference benchmark's form: one call per replay
         out[f"decode_bf16_uniform8k_{name}"] = {"us": round(us, 1), "GBps": round(kvb / us / 1e3, 1),
                                                 "hbm_frac_of_8TBps": round(kvb / us / 1e3 / HBM_PEAK_GBPS, 4),
+                                                "us_single_step_replay": round(us1, 1),
                                                 "parity": {"checked_requests": rows, "max_abs_err": round(err, 5), "tolerance": "atol=0.016"}}
         del inp, o
     # fp8 variants
@@ -504,10 +508,15 @@ def extra_decode(dev, hpc):
         us = timed(lambda: hpc.attention_decode_fp8(inp["q"], inp["k_cache"], inp["v_cache"], inp["block_ids"], inp["kv_lens"],
                                                    inp["q_scale"], inp["k_scale"], inp["v_scale"], 0, True,
                                                    hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, True, tm, None, o8),
-                   graph=True)
+                   graph=True, reps=10)
+        us1 = timed(lambda: hpc.attention_decode_fp8(inp["q"], inp["k_cache"], inp["v_cache"], inp["block_ids"], inp["kv_lens"],
+                                                    inp["q_scale"], inp["k_scale"], inp["v_scale"], 0, True,
+                                                    hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, True, tm, None, o8),
+                    graph=True)
         kvb8 = int(lens_c.sum()) * heads[0] * 256
         out[f"decode_fp8_{name}"] = {"us": round(us, 1), "GBps": round(kvb8 / us / 1e3, 1),
                                      "hbm_frac_of_8TBps": round(kvb8 / us / 1e3 / HBM_PEAK_GBPS, 4),
+                                     "us_single_step_replay": round(us1, 1),
                                      "parity_max_abs_err": round(err8, 5)}
         del inp
     return out

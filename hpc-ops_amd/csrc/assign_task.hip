@@ -148,7 +148,7 @@ constexpr int kBinsPerWg = kThreads / kLanesPerBin;
 
 __global__ __launch_bounds__(kThreads) void assign_task_kernel(
     int* __restrict__ task_map, const int* __restrict__ num_seq_kvcache, int num_batch,
-    int num_head_kv, int num_seq_q, int new_kv_included, int min_process_len, int num_bins) {
+    int num_head_kv, int num_seq_q, int new_kv_included, int min_process_len, int max_bins) {
   __shared__ int s_seqkv[kMaxBatch];
   __shared__ int s_tiles[kMaxBatch];
   __shared__ int s_cum[kMaxBatch];
@@ -188,8 +188,9 @@ __global__ __launch_bounds__(kThreads) void assign_task_kernel(
   p.num_head_kv = num_head_kv;
   p.num_seq_q = num_seq_q;
   p.tilen = kTileN;
-  p.num_bins = num_bins;
   const long grand = static_cast<long>(total) * num_head_kv;
+  const int num_bins = effective_bins(grand, max_bins);  // the launch is sized for max_bins; a small batch uses fewer (sched_task_info.h)
+  p.num_bins = num_bins;
   p.per = imax(static_cast<int>((grand + num_bins - 1) / num_bins), min_process_len / kTileN);
 
   const int max_batch = task_map[3];
@@ -252,6 +253,17 @@ extern "C" int hpc_attention_decode_num_bins(int num_seq_q, int device_id) {
 }
 
 extern "C" int hpc_attention_decode_tile_n(void) { return kTileN; }
+
+extern "C" int hpc_attention_decode_effective_bins(const int* num_seq_kvcache, int num_batch, int num_head_kv, int num_seq_q,
+                                                   int new_kv_included, int max_bins) {
+  if (!num_seq_kvcache || num_batch < 0 || num_head_kv <= 0 || max_bins <= 0) return HPC_ERR_INVALID;
+  long total = 0;
+  for (int b = 0; b < num_batch; ++b) {
+    const int n = num_seq_kvcache[b] + (new_kv_included ? 0 : num_seq_q);
+    total += (n + kTileN - 1) / kTileN;
+  }
+  return effective_bins(total * num_head_kv, max_bins);
+}
 
 extern "C" int hpc_assign_attention_decode_task_rows(const int* num_seq_kvcache, int num_total_ctas,
                                                      int num_batch, int num_head_kv, int num_seq_q,

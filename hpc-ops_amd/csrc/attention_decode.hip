@@ -106,6 +106,7 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
   const cint_ptr tmap = as_const(a.task_map);
   const int per1 = tmap[0];
   const int num_bins = tmap[1];
+  if (bin >= num_bins) return;  // the scheduler planned a small batch on fewer bins than the launch holds (sched_task_info.h)
   const cint_ptr chunk_tab = tmap + sched::chunk_table_off(per1 - 1, num_bins);
   cint_ptr task_ptr = tmap + static_cast<long>(kTaskStride) * (1 + static_cast<long>(bin) * per1);
 
@@ -524,7 +525,7 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
       // barrier).  One atomic add on the request's counter (zero on first use: the contract of
       // hpc_attention_decode_workspace_zero_bytes(); the last arriver puts the zero back); the chunk that arrives LAST
       // folds all of them - chunk c of a request lives in bin (bin - ichunk) + c, slot 1 for c == 0 and slot 0 otherwise -
-      // with 8 chunks' loads in flight per thread and a running maximum (one pass), and writes y.
+      // with 8-16 chunks' loads in flight per thread and a running maximum (one pass), and writes y.
       int* cnt = a.arrive + h * a.num_batch + b;
       int ticket = 0;
       if constexpr (kSolo) {
@@ -543,11 +544,15 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
           float Mr = kNegInf, W = 0.f, acc[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-          for (int c0 = 0; c0 < nchunks; c0 += 8) {
-            float l8[8];
-            u32x4 x0[8], x1[8];
+          // chunks in flight per thread: 16 with one q block (144 registers: the tile loop's are dead here), 8 with more
+          // (the two- and three-block kernels sit at 330-506 registers) - a request cut into many chunks (one long request
+          // among short ones on a single kv head: 171 chunks of a 64k request) is merged in chunks / kU round trips
+          constexpr int kU = kNB == 1 ? 16 : 8;
+          for (int c0 = 0; c0 < nchunks; c0 += kU) {
+            float l8[kU];
+            u32x4 x0[kU], x1[kU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < kU; ++u) {
               const int c = c0 + u < nchunks ? c0 + u : nchunks - 1;
               const int prow = ((fb + c) * 2 + (c == 0 ? 1 : 0)) * kNB * 16 + row;
               l8[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(lse_rs, prow * 4, 0, 16));
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
             }
             float mb = Mr;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) mb = fmaxf(mb, c0 + u < nchunks ? l8[u] : kNegInf);
+            for (int u = 0; u < kU; ++u) mb = fmaxf(mb, c0 + u < nchunks ? l8[u] : kNegInf);
             const float mu = mb == kNegInf ? 0.f : mb;
             const float sc_old = __builtin_amdgcn_exp2f(Mr - mu);  // Mr = -inf: 0 (nothing folded yet)
             Mr = mb;
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] *= sc_old;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < kU; ++u) {
               const float wgt = c0 + u < nchunks ? __builtin_amdgcn_exp2f(l8[u] - mu) : 0.f;
               W += wgt;
 #pragma unroll

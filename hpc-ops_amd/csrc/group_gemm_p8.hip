@@ -56,13 +56,10 @@ struct IntC {
 // tile counts come from the scan of ceil(len / 128) the callers already have (`cut`): c = cut[g + 1] - cut[g] 128-row
 // tiles = c / 2 FULL 256-token tiles + (c odd) one tail tile of <= 128 rows, which runs the half-tile body.
 //   order 0 (round 2-4): group -> weight tile -> token tile, tail tiles in place;
-//   order 1 (round 5): all full tiles first (group -> weight tile -> token tile), then all tail tiles (group -> weight
-//     tile).  A tail tile costs ~0.7 of a full one, and the dispatcher hands workgroups out in index order: with the
-//     tails in place the last round of a launch mixes full and tail tiles and the launch ends with the CU that drew a
-//     full tile last; with the cheap items last the tail of the launch is filled evenly (the down GEMM of the MoE has
-//     only ~9.4 items per CU: 64 x 2 x 16 = 2048 full tiles = exactly 8 per CU, then 2 tail tiles each).  The tail
-//     tiles then re-read their weight tile from memory instead of meeting it in L2 - 2.7 GB more HBM reads on the
-//     gate-up GEMM, far from the HBM limit at this arithmetic intensity.
+//   order 1 (round 5, development): all full tiles first (group -> weight tile -> token tile), then all tail tiles (group ->
+//     weight tile).  A tail tile costs ~0.6 of a full one, and the dispatcher hands workgroups out in index order: with
+//     the cheap items last the end of the launch is filled evenly (the down GEMM of the MoE has only ~9.4 items per CU).
+//     Measured slower (the launcher says by how much): the tail tiles no longer meet their weight tile in L2.
 // One round of lane-parallel loads per 64 groups; with <= 64 groups everything comes from one round.
 struct Item {
   int e, mt, wt, m_cnt, m0;  // group, 256-token tile of the group, weight tile, rows of the group, its first row
@@ -219,7 +216,7 @@ struct CfgNoPrioDist3 : CfgDist3 { static constexpr bool kPrio = false; };
 // and the MFMAs of token blocks 2-3 do not exist: 16 instead of 32 MFMAs, 20 instead of 24 operand reads and 6-7
 // instead of 8-9 DMA pieces per wave and k-tile, and in the fused activation epilogue group 0 finishes everything.
 // The weight units are what they are: a tail tile still re-streams its 256 weight rows.
-template <class Cfg, bool kHasXs, bool kNoDma, bool kAct, bool kHalf>
+template <class Cfg, bool kHasXs, bool kNoDma, bool kAct, bool kHalf, bool kKTail>
 __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, int mt0, int n0, int m_cnt, int m0) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -253,8 +250,11 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     constexpr int kP = decltype(par)::value, kLate = decltype(late)::value;
     const int koff = T * kBK;
     const auto rw = make_rsrc(wsrc, on ? w_bytes : 0u);
-    // K % 128 == 64 (per-tensor scales only): the chunks past K get an out-of-range offset and land as zeros
-    const bool k_ok = kHasXs || koff + p_chunk * 16 < K;
+    // K % 128 == 64 (per-tensor scales only; kKTail): the chunks past K get an out-of-range offset and land as zeros.
+    // Its own instantiation: the per-lane compare + select per DMA piece is VALU work in the load sections, which
+    // loses every issue slot to the MMA wave of its SIMD (round 4 paid it on every per-tensor call: matrix pipe busy
+    // 0.85 -> 0.72)
+    const bool k_ok = !kKTail || koff + p_chunk * 16 < K;
     uint8_t* base = s_mem + kP * kBuf + (kLate ? 3 * kUnit : 0);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + (wave * 2 + q) * 1024), 16,
                                              k_ok ? w_voff[q] : 0xffffff00u, koff + (kLate ? late_w : 0), 0, 0);
@@ -293,7 +293,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     constexpr int kP = decltype(par)::value, kLate = decltype(late)::value;
     const int koff = T * kBK;
     const auto rx = make_rsrc(a.x, on ? a.x_bytes : 0u);
-    const bool k_ok = kHasXs || koff + p_chunk * 16 < K;
+    const bool k_ok = !kKTail || koff + p_chunk * 16 < K;
     uint8_t* base = s_mem + kP * kBuf + (1 + kLate) * kUnit;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(base + (wave * 2 + q) * 1024), 16,
                                              k_ok ? x_voff[kLate][q] : 0xffffff00u, koff, 0, 0);
@@ -323,24 +323,34 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
 
   // operand read offsets inside a unit (swizzled): row r, chunk c -> r*128 + ((c ^ (r & 7)) << 4); the rows of a
   // wave's blocks are 16 apart, so (r & 7) does not depend on the block and block offsets are immediates
-  int a_off[2], b_off[2];
+  // Per buffer: the second buffer starts at 64 KB, past the 16-bit offset field of a ds_read - without its own base
+  // registers (made opaque: hipcc would rematerialise them as base + 0x10000) every operand read of an odd k-tile costs
+  // a v_add in a load section, whose VALU work loses every issue slot to the MMA wave of its SIMD.
+  int a_off[2][2], b_off[2][2];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    a_off[c] = (wn * 64 + r16) * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);
-    b_off[c] = kUnit + (wm * 32 + r16) * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);
+    a_off[0][c] = (wn * 64 + r16) * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);
+    b_off[0][c] = kUnit + (wm * 32 + r16) * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);
+    a_off[1][c] = a_off[0][c] + kBuf;
+    b_off[1][c] = b_off[0][c] + kBuf;
+    asm volatile("" : "+v"(a_off[1][c]), "+v"(b_off[1][c]));
   }
-  auto read_a = [&](const uint8_t* unit0, u32x4 (&af)[4][2]) {  // unit0: start of U0 or U3 of the buffer
+  int xs_rd = kXsOff + (wm * 64 + r16) * 4;  // this lane's token scales of token block 0 in scale buffer 0 (opaque base: as above)
+  asm volatile("" : "+v"(xs_rd));
+  auto read_a = [&](auto par, int unit_off, u32x4 (&af)[4][2]) {  // unit_off: 0 = U0, 3 * kUnit = U3 of the buffer
+    constexpr int kP = decltype(par)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) af[i][c] = *reinterpret_cast<const u32x4*>(unit0 + a_off[c] + i * 2048);
+      for (int c = 0; c < 2; ++c) af[i][c] = *reinterpret_cast<const u32x4*>(s_mem + a_off[kP][c] + unit_off + i * 2048);
   };
-  auto read_b = [&](const uint8_t* buf, int late, u32x4 (&bf)[2][2]) {
+  auto read_b = [&](auto par, int late, u32x4 (&bf)[2][2]) {
+    constexpr int kP = decltype(par)::value;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int c = 0; c < 2; ++c)
-        bf[j][c] = *reinterpret_cast<const u32x4*>(buf + b_off[c] + late * kUnit + j * 2048);
+        bf[j][c] = *reinterpret_cast<const u32x4*>(s_mem + b_off[kP][c] + late * kUnit + j * 2048);
   };
 
   // One section: 4 row blocks x all 4 token blocks (16 MFMAs), written as the software pipeline it has to be:
@@ -520,7 +530,6 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   float f[4] = {1.f, 1.f, 1.f, 1.f};
   auto k_tile = [&](int T, auto par) {
     constexpr int kP = decltype(par)::value;
-    const uint8_t* buf = s_mem + kP * kBuf;
     const bool on1 = T + 1 < KB, on2 = T + 2 < KB;
     auto x_piece = [&](int i) { dma_w(T + 1, on1, IntC<1 - kP>{}, IntC<1>{}, i); };  // U3(T + 1), piece q = i
     auto y_piece = [&](int i) {  // U0(T + 2) q0 q1, U1(T + 2) q0 q1, U2(T + 2) q0 q1, scales(T + 2)
@@ -553,15 +562,15 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       issue_x(0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    read_b(buf, 0, b_early);
-    if constexpr (!kHalf) read_b(buf, 1, b_late);
-    read_a(buf, a_frag);
+    read_b(par, 0, b_early);
+    if constexpr (!kHalf) read_b(par, 1, b_late);
+    read_a(par, 0, a_frag);
     float xsv[4] = {1.f, 1.f, 1.f, 1.f}, wsk = 1.f;
     if constexpr (kHasXs) {
       wsk = __int_as_float(ws_row[T * a.ws_kb_stride]);
 #pragma unroll
       for (int j = 0; j < kJ; ++j)
-        xsv[j] = *reinterpret_cast<const float*>(s_mem + kXsOff + kP * 1024 + (wm * 64 + j * 16 + r16) * 4);
+        xsv[j] = *reinterpret_cast<const float*>(s_mem + xs_rd + kP * 1024 + j * 64);
     }
     if constexpr (!Cfg::kDmaFirst) issue_x(0);
     enter_mma(fly_x);
@@ -578,7 +587,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       issue_y(0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    read_a(buf + 3 * kUnit, a_frag);
+    read_a(par, 3 * kUnit, a_frag);
     if constexpr (!Cfg::kDmaFirst) issue_y(0);
     enter_mma(fly_y);
     section(4, a_frag, b_early, b_late, f, [] {}, [&](int n) { issue_y(n + 1); }, leave_mma);
@@ -731,7 +740,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   }
 }
 
-template <class Cfg, bool kHasXs, bool kNoDma = false, bool kAct = false>
+template <class Cfg, bool kHasXs, bool kNoDma = false, bool kAct = false, bool kKTail = false>
 __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, const int* __restrict__ cu_tiles,
                                                                   int num_group) {
   __shared__ __attribute__((aligned(1024))) uint8_t s_mem[kLds];
@@ -746,9 +755,9 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   const int n0 = __builtin_amdgcn_readfirstlane(it.wt) * kBN;
   // a group's last token tile with <= 128 rows runs the half-tile body (development key 21 = 1: never)
   if (m_cnt - mt0 <= 128 && !a.no_half_tile)
-    p8_body<Cfg, kHasXs, kNoDma, kAct, true>(a, s_mem, e, mt0, n0, m_cnt, m0);
+    p8_body<Cfg, kHasXs, kNoDma, kAct, true, kKTail>(a, s_mem, e, mt0, n0, m_cnt, m0);
   else
-    p8_body<Cfg, kHasXs, kNoDma, kAct, false>(a, s_mem, e, mt0, n0, m_cnt, m0);
+    p8_body<Cfg, kHasXs, kNoDma, kAct, false, kKTail>(a, s_mem, e, mt0, n0, m_cnt, m0);
 }
 
 #ifdef HPC_DEV
@@ -782,7 +791,11 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int n
   if (n % kBN || a.K < kBK) return HPC_ERR_UNSUPPORTED;
   const long max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 256)
   const long items = max_tiles * (n / kBN) + 16;  // + 16: the per-XCD chunks of the full and of the tail tiles round up
-  a.item_order = hpc_dev_tuning_get(23) == 1 ? 0 : 1;  // development key 23 = 1: the round-4 item order (tail tiles in place)
+  // tail tiles stay next to their full siblings (order 0).  Order 1 - all full tiles first, tail tiles last, which evens
+  // out the end of a launch (the down GEMM of the MoE has ~9.4 items per CU) - measured SLOWER on the same box: gate-up /
+  // down GEMM 3493 / 1624 us against 3225 / 1583 us: a tail tile that cannot meet its weight tile in L2 streams it from
+  // memory and its DMA pieces land late (development key 23 = 1 selects order 1; profiles/round5_moe_ggemm_ab.txt)
+  a.item_order = hpc_dev_tuning_get(23) == 1 ? 1 : 0;
   if (items > 0x7fffffffl) return HPC_ERR_UNSUPPORTED;
   dim3 grid(static_cast<unsigned>(items));
 #ifdef HPC_DEV
@@ -811,12 +824,16 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int n
   using P = CfgProduct;
   if (a.has_xs && a.act_out)
     gemm_fp8_p8_kernel<P, true, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  else if (a.act_out && a.K % kBK)
+    gemm_fp8_p8_kernel<P, false, false, true, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else if (a.act_out)
     gemm_fp8_p8_kernel<P, false, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else if (kHpcDevBuild && a.has_xs && hpc_dev_tuning_get(18) == 1)
     gemm_fp8_p8_kernel<P, true, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else if (a.has_xs)
     gemm_fp8_p8_kernel<P, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
+  else if (a.K % kBK)  // per-tensor scales, K % 128 == 64: the k-tail instantiation
+    gemm_fp8_p8_kernel<P, false, false, false, true><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   else
     gemm_fp8_p8_kernel<P, false><<<grid, kThreads, 0, stream>>>(a, cu_tiles, num_group);
   HPC_CHECK_LAUNCH();

@@ -31,7 +31,7 @@
 //   key 22 256x256 grouped GEMM, blockwise: variant of the k-loop (group_gemm_p8.hip: 1 section profile, 2 the round-4 loop
 //          (tails behind the barrier), 3 its profile, 4 no s_setprio, 5 rescale distance 3, 6 / 7 barrier in front of the
 //          last 2 / 4 MFMAs of a section, 8 / 9 DMA slot schedules S3 / S4, 10-13 combinations)
-//   key 23 256x256 grouped GEMM: 1 = the round-4 item order (tail tiles in place instead of behind all full tiles)
+//   key 23 256x256 grouped GEMM: 1 = all full tiles first, tail tiles last (measured slower than tails in place)
 //   key 33 decode, first generation: 1 = split requests merged by decode_combine_kernel (second launch) instead of the last arriver
 //   key 34 decode scheduler: bin count override (<= 4 per CU)
 //   others: see the launchers that read them

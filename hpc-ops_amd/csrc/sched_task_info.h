@@ -32,6 +32,21 @@ __host__ __device__ inline int cta_per_cu(int num_seq_q) {
   return num_seq_q <= 2 ? 2 : 1;
 }
 
+// MI355X choice (the reference plans every batch on all of its CTAs): a batch with little work is planned on FEWER bins,
+// so that a bin holds at least kMinTilesPerBin tiles - never fewer than kMinBins bins, never more than the launch has.  With
+// one tile per bin a 16k-token request among a few short ones is cut into 256 chunks whose fp32 partials the last
+// arriver then merges one after the other (reference benchmark case skewed_extreme, one kv head: 31 us; 64 uniform
+// 512-token requests would be cut into 8 chunks each instead of running whole).  The device scheduler and the CPU
+// entry of the op apply it (header int 1 records the count they used; consumers read it from there); the C function
+// hpc_assign_attention_decode_task_sync plans on exactly the bin count its caller passes, like the reference's.
+constexpr int kMinTilesPerBin = 8;
+constexpr int kMinBins = 64;
+__host__ __device__ inline int effective_bins(long grand_tiles, int num_bins) {
+  long want = (grand_tiles + kMinTilesPerBin - 1) / kMinTilesPerBin;
+  if (want < kMinBins) want = kMinBins;
+  return want < num_bins ? static_cast<int>(want) : num_bins;
+}
+
 struct alignas(16) TaskInfo {
   int ihead_kv, ibatch, ichunk, iseq_start;
   int num_seqkv, num_seqkvcache, num_tile_kv, num_tile_full;

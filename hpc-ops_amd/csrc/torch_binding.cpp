@@ -103,10 +103,14 @@ at::Tensor assign_task_cpu(const at::Tensor& num_seq_kvcache, int64_t num_head_k
   TORCH_CHECK(num_seq_kvcache.device().is_cpu(), "num_seq_kvcache tensor must be cpu");
   TORCH_CHECK(num_seq_kvcache.scalar_type() == at::kInt, "num_seq_kvcache dtype must be int32");
   const at::Tensor lens = num_seq_kvcache.contiguous();
-  const int bins = hpc_attention_decode_num_bins(static_cast<int>(num_seq_q), -1);
-  TORCH_CHECK(bins > 0, "we only support num_seq_q 1..5 (and a HIP device must be present)");
+  const int max_bins = hpc_attention_decode_num_bins(static_cast<int>(num_seq_q), -1);
+  TORCH_CHECK(max_bins > 0, "we only support num_seq_q 1..5 (and a HIP device must be present)");
   const int* lp = static_cast<const int*>(lens.data_ptr());
   const int nb = static_cast<int>(lens.numel());
+  // the same bin count the device scheduler picks (a small batch is planned on fewer bins): byte-identical maps
+  const int bins = hpc_attention_decode_effective_bins(lp, nb, static_cast<int>(num_head_kv), static_cast<int>(num_seq_q),
+                                                       new_kv_included ? 1 : 0, max_bins);
+  TORCH_CHECK(bins > 0, "assign_attention_decode_task: invalid arguments");
   const int rows = hpc_assign_attention_decode_task_rows(lp, bins, nb, static_cast<int>(num_head_kv), static_cast<int>(num_seq_q),
                                                          new_kv_included ? 1 : 0, static_cast<int>(min_process_len));
   HPC_LAUNCH_CHECK(rows > 0 ? 0 : (rows < 0 ? rows : -2), "assign_attention_decode_task_sync");

@@ -49,6 +49,7 @@ if DEV_BUILD:  # the product does not export them
 _sig("hpc_fused_rmsnorm_with_scale_async", I, P, P, P, P, P, P, F, I, I, I, P)
 IP = ctypes.POINTER(c_int)
 _sig("hpc_attention_decode_num_bins", I, I, I)
+_sig("hpc_attention_decode_effective_bins", I, P, I, I, I, I, I)
 _sig("hpc_attention_decode_tile_n", I)
 _sig("hpc_assign_attention_decode_task_rows", I, IP, I, I, I, I, I, I)
 _sig("hpc_assign_attention_decode_task_sync", I, IP, I, I, I, I, I, I, IP, I)

@@ -59,8 +59,14 @@ int hpc_fused_rmsnorm_with_scale_async(const void* input, const void* weight, vo
  *   fills `task_map` (>= rows*12 ints) like the reference CPU entry and returns rows.
  * hpc_assign_attention_decode_task_async: device scheduler; `task_map` is the workspace of
  *   hpc.get_attention_decode_task_workspace (header ints 2..4 pre-filled by the allocator),
- *   num_seq_kvcache is a device pointer.  Byte-identical to the host scheduler. */
+ *   num_seq_kvcache is a device pointer.  `num_total_ctas` is the UPPER bound the decode launch is sized for: a
+ *   batch with little work is planned on fewer bins (hpc_attention_decode_effective_bins: at least 8 tiles per bin,
+ *   at least 64 bins) and header int 1 of the map records the count used - consumers read it from there.  Byte-
+ *   identical to the host scheduler run with that count.
+ * hpc_attention_decode_effective_bins: that count from host lengths (what the CPU entry of the op passes to _sync). */
 int hpc_attention_decode_num_bins(int num_seq_q, int device_id);
+int hpc_attention_decode_effective_bins(const int* num_seq_kvcache, int num_batch, int num_head_kv, int num_seq_q,
+                                        int new_kv_included, int max_bins);
 int hpc_attention_decode_tile_n(void);
 int hpc_assign_attention_decode_task_rows(const int* num_seq_kvcache, int num_total_ctas,
                                           int num_batch, int num_head_kv, int num_seq_q,

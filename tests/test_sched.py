@@ -141,6 +141,59 @@ def test_device_scheduler_matches_host_bytes(case):
     assert np.array_equal(got, ora)
 
 
+def test_effective_bins_rule():
+    """CPU: a batch with little work is planned on fewer bins - at least 8 tiles per bin, at least 64 bins, never more
+    than the launch has (csrc/sched_task_info.h::effective_bins; the reference plans every batch on all of its CTAs)."""
+    lib = ctypes.CDLL(str(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so"))
+
+    def eff(lens, hkv, sq=1, nkv=True, max_bins=512):
+        arr = np.ascontiguousarray(lens, dtype=np.int32)
+        return lib.hpc_attention_decode_effective_bins(arr.ctypes.data_as(_IP), len(arr), hkv, sq, int(nkv), max_bins)
+
+    assert eff([64] * 15 + [16384], 1) == 64          # 271 tiles: the floor (one tile per bin cut the long request into 256 chunks)
+    assert eff([512] * 64, 1) == 64                   # 512 tiles: every request whole in its own bin
+    assert eff([128] * 32 + [4096] * 32, 1) == 264    # 2112 tiles / 8
+    assert eff([8192] * 64, 1) == 512                 # enough work: every bin of the launch
+    assert eff([8192] * 64, 8) == 512
+    assert eff([100] * 4, 8, max_bins=40) == 40       # never more than the launch has
+    assert eff([0, 0], 2) == 64 and eff([], 2) == 64
+    assert eff([63, 64, 65], 1, sq=2, nkv=False) == 64
+    assert eff([1], 0) < 0                            # invalid
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lens,hkv", [([64] * 15 + [16384], 1), ([512] * 64, 1), ([128] * 32 + [4096] * 32, 1), ([300, 5000, 77], 2)])
+def test_small_batches_are_planned_on_fewer_bins(lens, hkv):
+    """GPU: the device scheduler and the CPU entry of the op pick the same reduced bin count for a small batch, record it
+    in header int 1, and both maps equal the oracle run with THAT count; decode kernels launched for the full count
+    return at once in the bins the plan does not use (the decode parity tests run through this)."""
+    import torch
+
+    import hpc
+    from oracle import sched
+
+    lens = np.asarray(lens, dtype=np.int32)
+    lens_t = torch.from_numpy(lens)
+    B = len(lens)
+    lib = ctypes.CDLL(str(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so"))
+    max_bins = lib.hpc_attention_decode_num_bins(1, 0)
+    want = lib.hpc_attention_decode_effective_bins(lens.ctypes.data_as(_IP), B, hkv, 1, 1, max_bins)
+    assert 64 <= want < max_bins
+    ws_cpu = hpc.get_attention_decode_task_workspace(B, int(lens.max()) + 65, hkv, 64)
+    ws_gpu = hpc.get_attention_decode_task_workspace(B, int(lens.max()) + 65, hkv, 64)
+    hpc.assign_attention_decode_task(lens_t, ws_cpu, hkv, 1, True, 64)
+    hpc.assign_attention_decode_task(lens_t.cuda(), ws_gpu, hkv, 1, True, 64)
+    torch.cuda.synchronize()
+    assert int(ws_gpu.view(torch.int32)[1]) == want and int(ws_cpu.view(torch.int32)[1]) == want
+    ora = sched.task_map_oracle(lens, want, hkv, 1, True, 64)
+    for ws in (ws_cpu, ws_gpu):
+        got = ws.view(torch.int32).cpu().numpy()[: ora.size].reshape(ora.shape).copy()
+        got[0, 2:5] = 0
+        assert got[0, 6] == 64
+        got[0, 6] = 0
+        assert np.array_equal(got, ora)
+
+
 def test_product_host_scheduler_matches_oracle_on_random_batches():
     """hypothesis: random batch shapes / lengths / bin counts / mtp / min_process_len - the closed-form planner
     of the product (host build of csrc/assign_task.hip's planner) equals the C restatement of the reference's
