@@ -30,7 +30,7 @@ struct Args {
   // the bf16-rounded multiply of the reference when use_bf16_mul (reference src/activation/activation.cu:19-75)
   const float* act_mul_scale = nullptr;
   int use_bf16_mul = 0;
-  int no_half_tile = 0;  // development (key 21 = 1): the 256 x 256 kernel never takes its half-tile body
+  int no_half_tile = 0;  // development (key 21): 1 = the 256 x 256 kernel runs its full body only, 2 = no tail body (<= 64 rows)
   int item_order = 0;    // 256 x 256 kernel: 0 = tail tiles in place, 1 = full tiles first, tail tiles last (group_gemm_p8.hip::locate_item)
   void* prof = nullptr;  // development: s_memtime log of the 256 x 256 kernel's section boundaries (hpc_dev_p8_prof_buffer)
 };

@@ -42,7 +42,16 @@ constexpr int kBN = 256, kBM = 256, kBK = 128;
 constexpr int kUnit = 128 * kBK;       // 16 KB: 128 rows of 128 k-bytes
 constexpr int kBuf = 4 * kUnit;        // [U0 weights early | U1 tokens early | U2 tokens late | U3 weights late]
 constexpr int kXsOff = 2 * kBuf;       // 2 x 1 KB of token scales + 1 KB nobody reads (idle waves' scale DMA)
-constexpr int kLds = kXsOff + 3 * 1024;
+constexpr int kLdsMain = kXsOff + 3 * 1024;
+// the tail body's layout (p8_tail_body): per-wave weight rings, two chunk buffers of token slabs, their scales
+constexpr int kTW = 3;                               // stages of a wave's weight ring = k-tiles of a token chunk
+constexpr int kTWOff = 0;                            // [8 waves][kTW][32 rows x 128 B]
+constexpr int kTXOff = kTWOff + 8 * kTW * 4096;      // [2 chunk buffers][kTW slabs][64 token rows x 128 B]
+constexpr int kTSOff = kTXOff + 2 * kTW * 8192;      // [2][kTW][64 floats]
+constexpr int kTDummy = kTSOff + 2 * kTW * 256;      // 256 B nobody reads (idle waves' scale DMA)
+constexpr int kLdsTail = kTDummy + 256;
+constexpr int kLds = kLdsTail > kLdsMain ? kLdsTail : kLdsMain;
+static_assert(kLds <= 160 * 1024, "one workgroup per CU");
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -740,6 +749,312 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   }
 }
 
+// ---- the TAIL body: a group's last token tile when it holds <= 64 rows ------------------------------------------------
+// At 512 +- 22 routed rows per expert half the groups end in a third token tile of a dozen rows.  The half-tile body
+// above serves it with the staggered-section machinery of a full tile - four barriers per k-tile, 48 KB of staging - and
+// costs ~0.62 of a full tile for 2-20 % of its rows (the routed GEMMs of the MoE take 15-19 % longer than at exactly 512
+// rows per expert).  What such a tile needs is its 256 weight rows streamed past 64 tokens: DMA-bound work, 8 MFMAs per
+// wave and k-tile.  This body is built for that:
+//   * wave w owns weight rows 32 w .. 32 w + 31 of the tile (gate-up form: waves 0-3 gate columns, 4-7 the up rows of
+//     the same columns) x all 64 tokens: 2 x 4 blocks, 32 accumulator registers;
+//   * a wave fetches exactly the weight rows it consumes, into a PRIVATE three-stage LDS ring (4 pieces per k-tile, two
+//     k-tiles ahead): no barrier guards the weight stream, only the wave's own counted vmcnt;
+//   * the 64 token rows are shared: chunks of kTW = 3 k-slabs (24 KB) in two buffers, one DMA piece per wave and slab,
+//     refilled a whole chunk ahead - ONE barrier per three k-tiles, so the two waves of a SIMD drift apart and cover each
+//     other's LDS latency;
+//   * same operand conventions, swizzle and arithmetic as the full body (one FMA per k block, the last two blocks of a
+//     k-tile folded under the first MFMAs of the next): results are bit-identical to the half-tile body's
+//     (tests/test_fuse_moe_blockwise.py::test_group_gemm_tail_body_is_bit_identical, development key 21 = 2);
+//   * VMEM order per k-tile T (q = T % 3): [W(T+2) x 4] and, behind the chunk barrier at q = 0, [X chunk T/3 + 1 x 3,
+//     scales x 1]; the wait in front of k-tile T leaves 4 (q = 0) or 8 + 3 + (scales) pieces in flight.
+template <bool kHasXs, bool kAct, bool kKTail>
+__device__ __forceinline__ void p8_tail_body(const Args& a, uint8_t* s_mem, int e, int mt0, int n0, int m_cnt, int m0) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int K = a.K, KB = a.KB;
+  const int inter = a.N >> 1;  // kAct only
+  const int col0 = n0 >> 1;    // kAct only: first activation column of the tile
+  const int p_row = lane >> 3, p_chunk = (lane & 7) ^ (lane >> 3);
+
+  // ---- DMA roles -------------------------------------------------------------------------------------------------
+  const int wrow0 = kAct ? (wave >> 2) * inter + col0 + (wave & 3) * 32 : n0 + wave * 32;  // first weight row (in the group)
+  const uint8_t* wsrc = a.w + static_cast<long>(e) * a.N * K;
+  const unsigned w_bytes = static_cast<unsigned>(a.N) * static_cast<unsigned>(K);
+  unsigned w_voff[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) w_voff[q] = static_cast<unsigned>(wrow0 + q * 8 + p_row) * static_cast<unsigned>(K) + p_chunk * 16;
+  auto dma_w = [&](int T, bool on, auto stage, int q) {  // piece q of k-tile T's 32 rows -> stage
+    constexpr int kS = decltype(stage)::value;
+    const int koff = T * kBK;
+    const auto rw = make_rsrc(wsrc, on ? w_bytes : 0u);
+    const bool k_ok = !kKTail || koff + p_chunk * 16 < K;
+    uint8_t* dst = s_mem + kTWOff + (wave * kTW + kS) * 4096 + q * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)dst, 16, k_ok ? w_voff[q] : 0xffffff00u, koff, 0, 0);
+  };
+  // the weight pieces of k-tiles 0 and 1 do not depend on the token rows: they could go first, but the wait arithmetic of
+  // the loop wants the token chunk OLDER than them - the row-index load below is one L2 round trip
+  unsigned x_voff;
+  {
+    const int slot = mt0 + wave * 8 + p_row;
+    const int sc = slot < m_cnt ? slot : m_cnt - 1;
+    const int xrow = a.row_index ? a.row_index[m0 + sc] : m0 + sc;
+    x_voff = static_cast<unsigned>(xrow) * static_cast<unsigned>(K) + p_chunk * 16;
+  }
+  auto dma_x = [&](int T, auto buf, auto slab) {  // this wave's 8 token rows of k-tile T -> chunk buffer, slab
+    constexpr int kP = decltype(buf)::value, kT = decltype(slab)::value;
+    const int koff = T * kBK;
+    const auto rx = make_rsrc(a.x, T < KB ? a.x_bytes : 0u);
+    const bool k_ok = !kKTail || koff + p_chunk * 16 < K;
+    uint8_t* dst = s_mem + kTXOff + (kP * kTW + kT) * 8192 + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)dst, 16, k_ok ? x_voff : 0xffffff00u, koff, 0, 0);
+  };
+  unsigned xs_voff = 0;
+  if constexpr (kHasXs) {
+    const int slot = mt0 + lane;
+    const int sc = slot < m_cnt ? slot : m_cnt - 1;
+    const long cb = a.col_base ? static_cast<long>(as_const(a.col_base)[e]) * a.tile_m : 0;
+    const long term = a.col_base ? cb + sc : static_cast<long>(a.row_index ? a.row_index[m0 + sc] : m0 + sc);
+    xs_voff = static_cast<unsigned>(term * a.xs_row_stride * 4);
+  }
+  const int xs_kb_bytes = static_cast<int>(a.xs_kb_stride * 4);
+  const unsigned xs_nrec = __builtin_amdgcn_readfirstlane(wave < kTW ? 0xffffffffu : 0u);
+  auto dma_xs = [&](int chunk, auto buf) {  // every wave issues one piece per chunk (equal vmcnt counts); wave t < kTW fetches slab t's scales
+    constexpr int kP = decltype(buf)::value;
+    if constexpr (kHasXs) {
+      const int T = chunk * kTW + wave;
+      const auto rs = make_rsrc(a.xs, T < KB ? xs_nrec : 0u);
+      uint8_t* dst = s_mem + (wave < kTW ? kTSOff + (kP * kTW + wave) * 256 : kTDummy);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 4, xs_voff, T * xs_kb_bytes, 0, 0);
+    }
+  };
+  const cint_ptr ws_row = as_const(reinterpret_cast<const int*>(a.ws)) + static_cast<long>(e) * a.ws_group_stride +
+                          ((kAct ? (wave >> 2) * inter + col0 : n0 + wave * 32) >> 7) * a.ws_ntile_stride;
+
+  f32x4 tot[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // operand read bases (opaque: no v_add per read): row r, chunk c -> r * 128 + ((c ^ (r & 7)) << 4)
+  int a_rd[2], b_rd[2], xs_rd;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    a_rd[c] = kTWOff + wave * kTW * 4096 + r16 * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);  // + stage * 4096 + i * 2048
+    b_rd[c] = kTXOff + r16 * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);                      // + (buffer * kTW + slab) * 8192 + j * 2048
+    asm volatile("" : "+v"(a_rd[c]), "+v"(b_rd[c]));
+  }
+  xs_rd = kTSOff + r16 * 4;  // + (buffer * kTW + slab) * 256 + j * 64
+  asm volatile("" : "+v"(xs_rd));
+
+  // ---- prologue: token chunk 0 (+ its scales), then the weight pieces of k-tiles 0 and 1 -------------------------------
+  dma_x(0, IntC<0>{}, IntC<0>{});
+  dma_x(1, IntC<0>{}, IntC<1>{});
+  dma_x(2, IntC<0>{}, IntC<2>{});
+  dma_xs(0, IntC<0>{});
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma_w(0, true, IntC<0>{}, q);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) dma_w(1, 1 < KB, IntC<1>{}, q);
+  __builtin_amdgcn_sched_barrier(0);
+
+  constexpr int kNx = kTW + (kHasXs ? 1 : 0);  // pieces of a token chunk per wave
+  f32x4 pend[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  float fpend[4] = {0.f, 0.f, 0.f, 0.f};
+  auto k_tile = [&](int T, auto qc, auto pc) {
+    constexpr int kQ = decltype(qc)::value, kP = decltype(pc)::value;  // weight stage = slab of the chunk; chunk buffer
+    const bool on2 = T + 2 < KB;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (kQ == 0) {
+      // W(T) landed (everything older too: this chunk's token slabs); all waves' slabs landed and the other buffer is free
+      __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma_w(T + 2, on2, IntC<2>{}, q);
+      dma_x(T + 3, IntC<1 - kP>{}, IntC<0>{});
+      dma_x(T + 4, IntC<1 - kP>{}, IntC<1>{});
+      dma_x(T + 5, IntC<1 - kP>{}, IntC<2>{});
+      dma_xs(T / kTW + 1, IntC<1 - kP>{});
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dma_w(T + 2, on2, IntC<(kQ + 2) % kTW>{}, q);
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int kFly = 8 + kNx;
+      __builtin_amdgcn_s_waitcnt(0x0F70 | (kFly & 15) | ((kFly >> 4) << 14));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4 af[2][2], bf[4][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) af[i][c] = *reinterpret_cast<const u32x4*>(s_mem + a_rd[c] + kQ * 4096 + i * 2048);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) bf[j][c] = *reinterpret_cast<const u32x4*>(s_mem + b_rd[c] + (kP * kTW + kQ) * 8192 + j * 2048);
+    float f[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (kHasXs) {
+      const float wsk = __int_as_float(ws_row[T * a.ws_kb_stride]);
+      float xsv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xsv[j] = *reinterpret_cast<const float*>(s_mem + xs_rd + (kP * kTW + kQ) * 256 + j * 64);
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = wsk * xsv[j];
+    } else {
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 pv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const int i = n >> 2, j = n & 3;
+      const i32x8 av = {static_cast<int>(af[i][0][0]), static_cast<int>(af[i][0][1]), static_cast<int>(af[i][0][2]),
+                        static_cast<int>(af[i][0][3]), static_cast<int>(af[i][1][0]), static_cast<int>(af[i][1][1]),
+                        static_cast<int>(af[i][1][2]), static_cast<int>(af[i][1][3])};
+      const i32x8 bv = {static_cast<int>(bf[j][0][0]), static_cast<int>(bf[j][0][1]), static_cast<int>(bf[j][0][2]),
+                        static_cast<int>(bf[j][0][3]), static_cast<int>(bf[j][1][0]), static_cast<int>(bf[j][1][1]),
+                        static_cast<int>(bf[j][1][2]), static_cast<int>(bf[j][1][3])};
+      if constexpr (kHasXs) {
+        const f32x4 part = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (n >= 2) {
+          const int pi = (n - 2) >> 2, pj = (n - 2) & 3;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tot[pi][pj][r] = fmaf(pv[1][r], f[pj], tot[pi][pj][r]);
+        } else {  // blocks 6, 7 of the previous k-tile, under its scales
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tot[1][2 + n][r] = fmaf(pend[n][r], fpend[2 + n], tot[1][2 + n][r]);
+        }
+        pv[1] = pv[0];
+        pv[0] = part;
+      } else {
+        tot[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, tot[i][j], 0, 0, 0, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (kHasXs) {
+      pend[0] = pv[1];
+      pend[1] = pv[0];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fpend[j] = f[j];
+    }
+  };
+  for (int kb = 0; kb < KB; kb += 2 * kTW) {
+    k_tile(kb, IntC<0>{}, IntC<0>{});
+    if (kb + 1 < KB) k_tile(kb + 1, IntC<1>{}, IntC<0>{});
+    if (kb + 2 < KB) k_tile(kb + 2, IntC<2>{}, IntC<0>{});
+    if (kb + 3 < KB) k_tile(kb + 3, IntC<0>{}, IntC<1>{});
+    if (kb + 4 < KB) k_tile(kb + 4, IntC<1>{}, IntC<1>{});
+    if (kb + 5 < KB) k_tile(kb + 5, IntC<2>{}, IntC<1>{});
+  }
+  if constexpr (kHasXs) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tot[1][2 + t][r] = fmaf(pend[t][r], fpend[2 + t], tot[1][2 + t][r]);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the (empty) tail DMAs before the workgroup's LDS is reused / released
+
+  if constexpr (!kHasXs) {
+    const float gs = __int_as_float(ws_row[0]);  // per-tensor form: strides are zero, one scale per group
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tot[i][j] *= gs;
+  }
+  if constexpr (kAct) {
+    // ---- fused activation epilogue: waves 4-7 hand their up values (bf16-rounded like the GEMM output the separate kernel
+    // would read) to the gate wave of the same columns; blockwise form: the 128-column abs-max of a token is the maximum
+    // over the four gate waves' 32 columns, through LDS.  Arithmetic of the full body's epilogue, value for value.
+    __syncthreads();  // every wave is past its last LDS read; its last (empty) DMA has landed
+    uint32_t* xch = reinterpret_cast<uint32_t*>(s_mem) + (((wave & 3) * 8) * 64 + lane) * 2;  // [gate wave][i * 4 + j][lane] of 8 B
+    float* red = reinterpret_cast<float*>(s_mem + 16384);                                      // [gate wave][64 tokens]
+    if (wave >= 4) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<u32x2*>(xch + (i * 4 + j) * 128) =
+              u32x2{pack_bf16x2(tot[i][j][0], tot[i][j][1]), pack_bf16x2(tot[i][j][2], tot[i][j][3])};
+    }
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const u32x2 ov = *reinterpret_cast<const u32x2*>(xch + (i * 4 + j) * 128);
+          const uint32_t m01 = pack_bf16x2(tot[i][j][0], tot[i][j][1]), m23 = pack_bf16x2(tot[i][j][2], tot[i][j][3]);
+          const float gv[4] = {bf16lo_to_f32(m01), bf16hi_to_f32(m01), bf16lo_to_f32(m23), bf16hi_to_f32(m23)};
+          const float uv[4] = {bf16lo_to_f32(ov[0]), bf16hi_to_f32(ov[0]), bf16lo_to_f32(ov[1]), bf16hi_to_f32(ov[1])};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float g = gv[r], u = uv[r];
+            float v;
+            if constexpr (kHasXs) {
+              v = g / (1.0f + __expf(-g)) * u;
+            } else {
+              float sv = g / (1.0f + __expf(-g));
+              if (a.use_bf16_mul)
+                sv = bf16_to_f32(f32_to_bf16(bf16_to_f32(f32_to_bf16(sv)) * u));
+              else
+                sv *= u;
+              v = sv * a.act_mul_scale[0];
+            }
+            tot[i][j][r] = v;
+            amax = fmaxf(amax, fabsf(v));
+          }
+        }
+        if constexpr (kHasXs) {
+          amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+          amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+          if (g4 == 0) red[wave * 64 + j * 16 + r16] = amax;
+        }
+      }
+    }
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int slot = mt0 + j * 16 + r16;
+        float inv = 1.0f, scale = 0.f;
+        if constexpr (kHasXs) {
+          const int t = j * 16 + r16;
+          const float amax = fmaxf(fmaxf(red[t], red[64 + t]), fmaxf(red[128 + t], red[192 + t]));
+          scale = amax / 448.0f;
+          inv = 1.0f / (scale + 1e-8f);
+        }
+        if (slot < m_cnt) {
+          uint8_t* orow = a.act_out + static_cast<long>(m0 + slot) * inter + col0 + wave * 32 + g4 * 4;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<uint32_t*>(orow + i * 16) =
+                quant_4xe4m3(tot[i][j][0] * inv, tot[i][j][1] * inv, tot[i][j][2] * inv, tot[i][j][3] * inv);
+          if constexpr (kHasXs) {
+            if (wave == 0 && g4 == 0) a.act_scale[static_cast<long>(m0 + slot) * (inter >> 7) + (col0 >> 7)] = scale;
+          }
+        }
+      }
+    }
+    return;
+  }
+  // ---- plain epilogue: 16-byte stores through v_permlane16_swap (as in the full body) ---------------------------------
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int slot = mt0 + j * 16 + r16;
+    uint16_t* yrow = a.y + static_cast<long>(m0 + slot) * a.N + n0 + wave * 32 + (g4 & 1) * 16 + (g4 >> 1) * 8;
+    const uint32_t a0 = pack_bf16x2(tot[0][j][0], tot[0][j][1]), a1 = pack_bf16x2(tot[0][j][2], tot[0][j][3]);
+    const uint32_t b0 = pack_bf16x2(tot[1][j][0], tot[1][j][1]), b1 = pack_bf16x2(tot[1][j][2], tot[1][j][3]);
+    const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+    if (slot < m_cnt) *reinterpret_cast<u32x4*>(yrow) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+  }
+}
+
 template <class Cfg, bool kHasXs, bool kNoDma = false, bool kAct = false, bool kKTail = false>
 __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, const int* __restrict__ cu_tiles,
                                                                   int num_group) {
@@ -753,8 +1068,11 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   const int m0 = __builtin_amdgcn_readfirstlane(it.m0);
   const int mt0 = __builtin_amdgcn_readfirstlane(it.mt) * kBM;
   const int n0 = __builtin_amdgcn_readfirstlane(it.wt) * kBN;
-  // a group's last token tile with <= 128 rows runs the half-tile body (development key 21 = 1: never)
-  if (m_cnt - mt0 <= 128 && !a.no_half_tile)
+  // a group's last token tile: <= 64 rows the tail body, <= 128 rows the half-tile body (development key 21 = 1: neither,
+  // 2: no tail body)
+  if (m_cnt - mt0 <= 64 && a.no_half_tile == 0 && !kNoDma)
+    p8_tail_body<kHasXs, kAct, kKTail>(a, s_mem, e, mt0, n0, m_cnt, m0);
+  else if (m_cnt - mt0 <= 128 && a.no_half_tile != 1)
     p8_body<Cfg, kHasXs, kNoDma, kAct, true, kKTail>(a, s_mem, e, mt0, n0, m_cnt, m0);
   else
     p8_body<Cfg, kHasXs, kNoDma, kAct, false, kKTail>(a, s_mem, e, mt0, n0, m_cnt, m0);
@@ -787,7 +1105,7 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int n
                         hipStream_t stream) {
   using namespace hpc::ggemm;
   Args a = a_in;
-  a.no_half_tile = hpc_dev_tuning_get(21) == 1;
+  a.no_half_tile = hpc_dev_tuning_get(21);  // development: 1 = full body only, 2 = no tail body
   if (n % kBN || a.K < kBK) return HPC_ERR_UNSUPPORTED;
   const long max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 256)
   const long items = max_tiles * (n / kBN) + 16;  // + 16: the per-XCD chunks of the full and of the tail tiles round up

@@ -379,6 +379,81 @@ def test_group_gemm_blockwise_many_groups(tiled_mode, num_group):
     assert allclose(gt.float(), my.cpu().float(), rtol=0.01, atol=0.02)
 
 
+@pytest.mark.dev
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,k", [(512, 512), (768, 1408)])  # 4 k-tiles (shorter than the ring's period of 6) and 11 (11 % 3 = 2)
+def test_group_gemm_tail_body_is_bit_identical(n, k):
+    """A group's last token tile with <= 64 rows runs the TAIL body of the 256 x 256 kernel (round 5: per-wave weight
+    rings, 64-token chunks of three k-slabs, one barrier per three k-tiles).  Same operand conventions and the same
+    arithmetic order as the full / half-tile bodies, so the output must be BIT-IDENTICAL to the round-4 dispatch
+    (development key 21 = 2: tails on the half-tile body) - groups of every tail size 1 ... 64 next to 65, 128, 129 and
+    empty groups, blockwise scales of either sign; and within the reference tolerance of the oracle."""
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(n + k)
+    tails = [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 128, 129, 0, 200]
+    seqlens = torch.tensor([256 * (i % 3) + t for i, t in enumerate(tails)], dtype=torch.int32)
+    num_group, total = len(seqlens), int(seqlens.sum())
+    x = (torch.randn((total, k)) / 10).to(F8)
+    w = (torch.randn((num_group, n, k)) / 10).to(F8)
+    kb = k // 128
+    xs_rows = torch.randn((total, kb))
+    wscale = torch.randn((num_group, n // 128, (kb + 3) // 4 * 4))
+    cu = torch.cat([torch.zeros(1, dtype=torch.int32), torch.cumsum(seqlens, 0).to(torch.int32)])
+    gt = omoe.group_gemm_blockwise(x, w, seqlens, cu, xs_rows, wscale)
+    avg = total // num_group
+    tile_m = hpc.aligned_size(avg)
+    tiles = (seqlens + tile_m - 1) // tile_m
+    cu_tiles = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(tiles, 0)])
+    xs_t = torch.zeros((kb, int(cu_tiles[-1]) * tile_m + 64))
+    for g in range(num_group):
+        c0 = int(cu_tiles[g]) * tile_m
+        xs_t[:, c0: c0 + int(seqlens[g])] = xs_rows[int(cu[g]): int(cu[g]) + int(seqlens[g])].t()
+    outs = {}
+    dev_set(3, 4)  # the 256 x 256 kernel
+    try:
+        for key in (2, 0, 1):  # half-tile body for the tails / tail body (the product) / full body only
+            dev_set(21, key)
+            outs[key] = hpc.group_gemm_blockwise_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), xs_t.cuda(), wscale.cuda(),
+                                                     num_seq_per_group_avg=avg).cpu()
+    finally:
+        dev_set(21, 0)
+        dev_set(3, 0)
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[1])
+    assert allclose(gt.float(), outs[0].float(), rtol=0.01, atol=0.02)
+
+
+@pytest.mark.dev
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_tokens,hidden,inter,num_expert,topk", [(530, 512, 256, 4, 2), (1100, 1024, 384, 8, 2), (300, 512, 128, 2, 2)])
+def test_fuse_moe_blockwise_tail_body_is_bit_identical(num_tokens, hidden, inter, num_expert, topk):
+    """The fused op with experts whose row counts end in a short tail (~265 / ~275 / 300 rows per expert): gate-up GEMM
+    with the activation + 128-block quantisation in the tail body's epilogue (up values handed to the gate wave of the
+    same columns through LDS, the token's abs-max folded over the four gate waves) and the down GEMM, against the
+    round-4 dispatch (development key 21 = 2) bit for bit, and against the oracle."""
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    args = _inputs(num_tokens, topk, hidden, inter, num_expert, 1, False, seed=num_tokens)
+    x, x_scale, guw, guws, dw, dws, topk_ids, topk_scale, _ = args
+    counts = torch.bincount(topk_ids.flatten().long(), minlength=num_expert)
+    assert int((counts % 256).min()) <= 64 or int((counts % 256 > 0).sum()) > 0
+    gt = omoe.fuse_moe_blockwise_fp8(x, x_scale, guw, guws, dw, dws, topk_ids, topk_scale, 0, num_expert, None)
+    dev = [t.cuda() for t in args[:8]]
+    outs = {}
+    dev_set(3, 4)
+    try:
+        for key in (2, 0):
+            dev_set(21, key)
+            outs[key] = hpc.fuse_moe_blockwise_fp8(*dev, 0, num_expert).cpu()
+    finally:
+        dev_set(21, 0)
+        dev_set(3, 0)
+    assert torch.equal(outs[0], outs[2])
+    assert allclose(gt.float(), outs[0].float(), rtol=0.01, atol=0.01)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("num_expert,num_topk", [(128, 8), (256, 8)])
 def test_fuse_moe_blockwise_fp8_many_experts(num_expert, num_topk):

@@ -78,6 +78,41 @@ def test_fuse_moe_pertensor_activation_epilogue(use_bf16_mul, num_seq, hidden, i
     assert allclose(gt.float(), fused.cpu().float(), rtol=0.08, atol=0.1)
 
 
+@pytest.mark.dev
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_bf16_mul", [False, True])
+@pytest.mark.parametrize("num_seq,hidden,inter,num_expert,topk", [(530, 512, 256, 4, 2), (300, 1088, 128, 2, 2)])  # 1088: K % 128 == 64
+def test_fuse_moe_pertensor_tail_body_is_bit_identical(use_bf16_mul, num_seq, hidden, inter, num_expert, topk):
+    """Per-tensor fused op with experts that end in a short tail: the tail body of the 256 x 256 kernel (gate-up GEMM with
+    silu(gate) * up * scale -> e4m3 in its epilogue, down GEMM; K % 128 == 64 through the k-tail instantiation) against
+    the round-4 dispatch (development key 21 = 2: tails on the half-tile body), bit for bit."""
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    torch.manual_seed(num_seq)
+    ids = torch.sort(torch.multinomial(torch.ones(num_seq, num_expert), topk, replacement=False).to(torch.int32), dim=1)[0]
+    x = (torch.randn((num_seq, hidden)) / 100).to(F8)
+    guw = torch.randn((num_expert, inter * 2, hidden)).to(F8)
+    dw = torch.randn((num_expert, hidden, inter)).to(F8)
+    gus, ds, ams = torch.rand(num_expert) + 0.5, torch.rand(num_expert) + 0.5, torch.rand(1) + 0.5
+    sc = torch.rand((num_seq, topk)) / topk
+    gt = omoe.fuse_moe_pertensor_fp8(x, guw, dw, gus, ds, ams, ids, sc, 0, None, use_bf16_mul)
+    c = lambda t: t.cuda()  # noqa: E731
+    run = lambda: hpc.fuse_moe_pertensor_fp8(c(x), c(guw), c(dw), c(gus), c(ds), c(ams), c(ids), c(sc), 0, num_expert,  # noqa: E731
+                                             use_bf16_mul=use_bf16_mul).cpu()
+    outs = {}
+    dev_set(3, 4)
+    try:
+        for key in (2, 0):
+            dev_set(21, key)
+            outs[key] = run()
+    finally:
+        dev_set(21, 0)
+        dev_set(3, 0)
+    assert torch.equal(outs[0], outs[2])
+    assert allclose(gt.float(), outs[0].float(), rtol=0.08, atol=0.1)
+
+
 @pytest.mark.gpu
 def test_count_and_gather_bit_exact():
     import hpc
