@@ -187,25 +187,9 @@ struct CfgProf : CfgProduct { static constexpr bool kProf = true; };
 struct CfgRound4 : CfgProduct { static constexpr bool kCarry = false; };  // the round-4 loop (tails behind the barrier)
 struct CfgRound4Prof : CfgRound4 { static constexpr bool kProf = true; };
 struct CfgNoPrio : CfgProduct { static constexpr bool kPrio = false; };
-struct CfgDist3 : CfgProduct { static constexpr int kDist = 3; };
-struct CfgEarly2 : CfgProduct { static constexpr int kEarly = 2; };
-struct CfgEarly4 : CfgProduct { static constexpr int kEarly = 4; };
-// schedules: S3 = no piece in any load section (U3 behind MFMAs 4 / 10 of section X, the Y half spread over section Y)
-struct CfgS3 : CfgProduct {
-  static constexpr int fx(int i) { constexpr int t[2] = {5, 11}; return t[i]; }
-  static constexpr int hx(int i) { constexpr int t[2] = {2, 6}; return t[i]; }
-  static constexpr int fy(int i) { constexpr int t[7] = {1, 3, 5, 7, 9, 11, 14}; return t[i]; }
-  static constexpr int hy(int i) { constexpr int t[7] = {1, 2, 4, 5, -1, -1, 7}; return t[i]; }
-};
-// S4 = everything in the load sections (the MMA sections carry MFMAs and FMAs only)
-struct CfgS4 : CfgProduct {
-  static constexpr int fy(int i) { constexpr int t[7] = {0, 0, 0, 0, 0, 0, 0}; return t[i]; }
-  static constexpr int hy(int i) { constexpr int t[7] = {0, 0, 0, 0, -1, -1, 0}; return t[i]; }
-};
-struct CfgNoPrioEarly2 : CfgEarly2 { static constexpr bool kPrio = false; };
-struct CfgNoPrioS3 : CfgS3 { static constexpr bool kPrio = false; };
-struct CfgNoPrioEarly2S3 : CfgNoPrioS3 { static constexpr int kEarly = 2; };
-struct CfgNoPrioDist3 : CfgDist3 { static constexpr bool kPrio = false; };
+// (measured and removed, profiles/round5_moe_ggemm_ab.txt: rescale distance 3, the barrier in front of a section's last 2 / 4
+//  MFMAs, DMA pieces before the operand reads, DMA slot schedules with no piece in a load section / in an MMA section -
+//  all within noise of or behind the product loop once the carried tails were in)
 #endif
 
 // kNoDma (development key 18 = 1, timing only - results are wrong): no DMA inside the k-loop
@@ -1124,15 +1108,6 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int n
       case 2: launch_blockwise_variant<CfgRound4>(a, cu_tiles, num_group, grid, stream); break;
       case 3: launch_blockwise_variant<CfgRound4Prof>(a, cu_tiles, num_group, grid, stream); break;
       case 4: launch_blockwise_variant<CfgNoPrio>(a, cu_tiles, num_group, grid, stream); break;
-      case 5: launch_blockwise_variant<CfgDist3>(a, cu_tiles, num_group, grid, stream); break;
-      case 6: launch_blockwise_variant<CfgEarly2>(a, cu_tiles, num_group, grid, stream); break;
-      case 7: launch_blockwise_variant<CfgEarly4>(a, cu_tiles, num_group, grid, stream); break;
-      case 8: launch_blockwise_variant<CfgS3>(a, cu_tiles, num_group, grid, stream); break;
-      case 9: launch_blockwise_variant<CfgS4>(a, cu_tiles, num_group, grid, stream); break;
-      case 10: launch_blockwise_variant<CfgNoPrioEarly2>(a, cu_tiles, num_group, grid, stream); break;
-      case 11: launch_blockwise_variant<CfgNoPrioS3>(a, cu_tiles, num_group, grid, stream); break;
-      case 12: launch_blockwise_variant<CfgNoPrioEarly2S3>(a, cu_tiles, num_group, grid, stream); break;
-      case 13: launch_blockwise_variant<CfgNoPrioDist3>(a, cu_tiles, num_group, grid, stream); break;
       default: return HPC_ERR_INVALID;
     }
     HPC_CHECK_LAUNCH();

@@ -29,8 +29,7 @@
 //   key 20 decode v2: minimum cost of a range of the in-kernel plan (default 8)
 //   key 21 256x256 grouped GEMM: 1 = never the half-tile / tail body for a group's last token tile, 2 = no tail body (<= 64 rows)
 //   key 22 256x256 grouped GEMM, blockwise: variant of the k-loop (group_gemm_p8.hip: 1 section profile, 2 the round-4 loop
-//          (tails behind the barrier), 3 its profile, 4 no s_setprio, 5 rescale distance 3, 6 / 7 barrier in front of the
-//          last 2 / 4 MFMAs of a section, 8 / 9 DMA slot schedules S3 / S4, 10-13 combinations)
+//          (tails behind the barrier), 3 its profile, 4 no s_setprio)
 //   key 23 256x256 grouped GEMM: 1 = all full tiles first, tail tiles last (measured slower than tails in place)
 //   key 33 decode, first generation: 1 = split requests merged by decode_combine_kernel (second launch) instead of the last arriver
 //   key 34 decode scheduler: bin count override (<= 4 per CU)
