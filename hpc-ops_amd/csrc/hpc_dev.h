@@ -33,6 +33,7 @@
 //   key 23 256x256 grouped GEMM: 1 = all full tiles first, tail tiles last (measured slower than tails in place)
 //   key 33 decode, first generation: 1 = split requests merged by decode_combine_kernel (second launch) instead of the last arriver
 //   key 34 decode scheduler: bin count override (<= 4 per CU)
+//   key 35 decode, head-pair kernels: s_setprio 2 around a wave-iteration's load issue (1) / its whole memory phase (2), s_setprio 1 around its compute phase (3)
 //   others: see the launchers that read them
 #pragma once
 
