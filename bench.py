@@ -412,12 +412,24 @@ def moe_block(dev, hpc, with_cpu=True, iters=10):
     us_eager = timed(step, iters=iters, warm=1)
     flops = c4_flops(T, w)
     tf = flops / us / 1e6
-    pmc = ROOT / "profiles" / "moe_tiled_gemm_pmc_r4.json"  # rocprofv3 --pmc pass over the kernels that ship (tools/round4_profiles.sh)
+    pmc = ROOT / "profiles" / "moe_tiled_gemm_pmc_r5.json"  # rocprofv3 --pmc pass over the kernels that ship (tools/round5_profiles.sh)
+    if not pmc.exists():
+        pmc = ROOT / "profiles" / "moe_tiled_gemm_pmc_r4.json"
     mfma_busy = None
     if pmc.exists():  # matrix-pipe busy fraction of the two kernels this op launches: gate-up GEMM with the activation epilogue, down GEMM
         pj = json.loads(pmc.read_text())
-        mfma_busy = {("gate_up_act_epilogue" if "[gate_up]" in k else "down"): v.get("mfma_busy_frac") for k, v in pj.items()
-                     if ("<true, false, true> [gate_up]" in k or "<true, false, false> [down]" in k)}
+        def flags(k):  # template arguments of the kernel name: (has_xs, no_dma, act) after an optional Cfg type
+            inner = k[k.index("<") + 1: k.rindex(">")] if "<" in k and ">" in k else ""
+            return [t.strip() for t in inner.split(",") if t.strip() in ("true", "false")][:3]
+        mfma_busy = {}
+        for k, v in pj.items():
+            if "gemm_fp8_p8_kernel" not in k or ("Cfg" in k and "CfgProduct" not in k):
+                continue
+            if flags(k) == ["true", "false", "true"] and "[gate_up]" in k:
+                mfma_busy["gate_up_act_epilogue"] = v.get("mfma_busy_frac")
+            if flags(k) == ["true", "false", "false"] and "[down]" in k:
+                mfma_busy["down"] = v.get("mfma_busy_frac")
+        mfma_busy["source"] = f"profiles/{pmc.name}"
     out = {
         "metric": "fuse_moe_blockwise_fp8_tflops", "value": round(tf, 1), "unit": "TFLOP/s", "dtype": "fp8_e4m3",
         "us_per_call": round(us, 1), "us_per_call_eager": round(us_eager, 1),
@@ -1085,12 +1097,11 @@ def main():
         value = whole_job_value(nbytes, world, wall, args.steps)
         achieved = nbytes / (kern_ms_avg * 1e-3) / 1e9
         # HBM bytes per launch from the PMC counters cannot be collected inside this process: they come from the
-        # committed rocprofv3 --pmc passes over this same command (tools/round3_profiles.sh); the file records the
+        # committed rocprofv3 --pmc passes over this same command (tools/round5_profiles.sh); the file records the
         # commit it was taken at so that a stale figure is visible
         traffic, traffic_src = None, None
-        pmc = ROOT / "profiles" / "decode_fp8_pmc_r4.json"
-        if not pmc.exists():
-            pmc = ROOT / "profiles" / "decode_fp8_pmc.json"
+        pmc = next((q for q in (ROOT / "profiles" / n for n in ("decode_fp8_pmc_r5.json", "decode_fp8_pmc_r4.json", "decode_fp8_pmc.json"))
+                    if q.exists()), ROOT / "profiles" / "decode_fp8_pmc.json")
         if pmc.exists():
             pj = json.loads(pmc.read_text())
             traffic, traffic_src = pj.get("hbm_bytes_per_launch"), f"profiles/{pmc.name} ({pj.get('taken_at', 'round 2 kernel')})"

@@ -846,7 +846,6 @@ static int try_second_generation(hpc::decode2::Args& b, void* workspace, int num
   b.part_o = b.part_lse = nullptr;
   b.arrive = nullptr;
   b.dev_nomem = hpc_dev_tuning_get(15);
-  b.prio_mode = hpc_dev_tuning_get(35);  // development: s_setprio placement in the head-pair kernels (attention_decode_v2.h)
   b.min_range_cost = hpc_dev_tuning_get(20) > 0 ? hpc_dev_tuning_get(20) : 8;  // development key 20 overrides (15 x 64 + 1 x 16k tokens: 87 us without a floor, 47 / 49 / 61 / 105 us at 8 / 16 / 32 / 64)
   b.prof = g_decode_prof;
   if (hpc_dev_tuning_get(12) == 1) return 1;  // development key 12 = 1: first generation only

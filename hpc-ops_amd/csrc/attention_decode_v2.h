@@ -27,7 +27,6 @@ struct Args {
   int bf16;       // 1: bf16 q / K / V (no scales; ldq and every stride in BYTES), 0: fp8 e4m3
   int pair_wgs[4];  // fp8, 4 head pairs: workgroups (= ranges) per pair, [0] = 0: equal shares
   int big_pct;      // > 100: ranges of the first half of the grid are this many percent of the others' length
-  int prio_mode;  // development key 35: s_setprio around the load-issue phase of a wave-iteration (1), around its whole memory phase (2), around its compute phase (3)
   int dev_nomem;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing; results are wrong)
   long k_block_stride, k_token_stride;  // bytes
   long v_block_stride, v_token_stride;

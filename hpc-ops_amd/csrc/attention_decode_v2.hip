@@ -828,7 +828,6 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     };
     // registers -> the wave's LDS stage (rows of 256 B, chunks swizzled); a register set is free again as soon as
     // it has been written out: the next WI (of this or the next task) goes in flight
-    if (kHpcDevBuild && a.prio_mode == 2) __builtin_amdgcn_s_setprio(2);
     wait_x4x4<12>(kr[0]);
     wait_x4x4<8>(kr[1]);
     if constexpr (kProf) { const uint64_t t = now(); pf_wk += t - pf_last; pf_last = t; }
@@ -841,15 +840,15 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     write_v(0);
     write_v(1);
     if constexpr (kProf) { const uint64_t t = now(); pf_wr += t - pf_last; pf_last = t; }
-    if (kHpcDevBuild && a.prio_mode == 1) __builtin_amdgcn_s_setprio(2);
+    // (round 5: s_setprio 2 around this load issue, around the whole memory phase of a wave-iteration, or s_setprio 1
+    //  around its compute phase change nothing - C3 mix 140.1-141.0 us against 140.3-141.9 us, uniform 8k 185.3-185.6
+    //  against 180.2-185.5 us, profiles/round5_decode_ab.txt: the waves wait for the memory pipeline, not for issue slots)
     issue_k0();
     issue_k1();
     issue_v0();
     issue_v1();
     q_ready();
     step(p2_tok, p2_fl, p2_pid0, p2_pid1);  // the WI after the one just issued: its page ids are on their way while this one computes
-    if (kHpcDevBuild && (a.prio_mode == 1 || a.prio_mode == 2)) __builtin_amdgcn_s_setprio(0);
-    if (kHpcDevBuild && a.prio_mode == 3) __builtin_amdgcn_s_setprio(1);
     if constexpr (kProf) { const uint64_t t = now(); pf_is += t - pf_last; pf_last = t; }
 
     if constexpr (kBf16) {
@@ -1104,7 +1103,6 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
       pf_last = t;
       ++pf_n;
     }
-    if (kHpcDevBuild && a.prio_mode == 3) __builtin_amdgcn_s_setprio(0);
     if (d_fl & kFLast) {
       finish_task();
       if constexpr (kProf) { const uint64_t t = now(); pf_fin += t - pf_last; pf_last = t; }

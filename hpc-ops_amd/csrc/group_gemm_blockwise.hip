@@ -245,8 +245,15 @@ bool hpc_ggemm_p8_selected(int num_group, int m, int n, int k, const void* cu_ti
   const int tiled_mode = hpc_dev_tuning_get(3);
   // (up to 64 groups the kernel finds its work item from one round of lane-parallel loads, above that from one round
   // per 64 groups: tests/test_fuse_moe_blockwise.py::test_group_gemm_blockwise_many_groups, 65 ... 256 groups)
+  // From 16 rows per group on (round 5; rounds 2-4: from 192): with the carried tails, the tail body for <= 64 rows and the
+  // half-tile body the 256 x 256 kernel overtakes the 256 x 128 ring kernel everywhere and the streaming kernel from
+  // ~16 rows per group (fused MoE, E64 / top-8 / H4096 / I11008, us: T = 128 1554-1561 against 1564-1676, T = 256
+  // 1590-1596 against 1711-1836, T = 512 1753-1755 against 1876-1978, T = 1024 2069-2102 against 2432-2607; below
+  // it loses: T = 64 1552-1563 against 1396-1461 - profiles/round5_moe_kernel_choice.txt).  Development key 25 restores
+  // the old threshold.
+  const int p8_from = hpc_dev_tuning_get(25) == 1 ? 192 : 16;
   return cu_tiles128 && n % 256 == 0 && k >= 128 &&
-         (tiled_mode == 4 || (tiled_mode == 0 && m / num_group >= 192));
+         (tiled_mode == 4 || (tiled_mode == 0 && m / num_group >= p8_from));
 }
 
 namespace {
@@ -260,10 +267,10 @@ int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const v
   // development key 3: 0 auto, 1 never tiled, 2 always 256 x 128 (when possible), 3 always 128 x 128,
   // 4 always 256 x 256 (when possible)
   const int tiled_mode = hpc_dev_tuning_get(3);
+  // the 256 x 256 kernel from 16 rows per group on (hpc_ggemm_p8_selected: tail body for <= 64 rows, half-tile body for <= 128)
+  if (tiled_mode != 1 && hpc_ggemm_p8_selected(num_group, m, n, a.K, cu_tiles128))
+    return hpc_ggemm_launch_p8(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);
   if (cu_tiles128 && n % 128 == 0 && tiled_mode != 1 && (tiled_mode >= 2 || m / num_group > 20)) {
-    // 256-token tiles from ~192 tokens per group on: below that most of a second half-tile would be padding
-    if (hpc_ggemm_p8_selected(num_group, m, n, a.K, cu_tiles128))
-      return hpc_ggemm_launch_p8(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);
     if (n % 256 == 0 && a.K >= 128 && tiled_mode != 3)
       return hpc_ggemm_launch_tiled256(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);
     return hpc_ggemm_launch_tiled(a, static_cast<const int*>(cu_tiles128), num_group, m, n, stream);

@@ -751,7 +751,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
 //     (tests/test_fuse_moe_blockwise.py::test_group_gemm_tail_body_is_bit_identical, development key 21 = 2);
 //   * VMEM order per k-tile T (q = T % 3): [W(T+2) x 4] and, behind the chunk barrier at q = 0, [X chunk T/3 + 1 x 3,
 //     scales x 1]; the wait in front of k-tile T leaves 4 (q = 0) or 8 + 3 + (scales) pieces in flight.
-template <bool kHasXs, bool kAct, bool kKTail>
+template <bool kHasXs, bool kAct, bool kKTail, bool kNt>
 __device__ __forceinline__ void p8_tail_body(const Args& a, uint8_t* s_mem, int e, int mt0, int n0, int m_cnt, int m0) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -774,7 +774,8 @@ __device__ __forceinline__ void p8_tail_body(const Args& a, uint8_t* s_mem, int 
     const auto rw = make_rsrc(wsrc, on ? w_bytes : 0u);
     const bool k_ok = !kKTail || koff + p_chunk * 16 < K;
     uint8_t* dst = s_mem + kTWOff + (wave * kTW + kS) * 4096 + q * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)dst, 16, k_ok ? w_voff[q] : 0xffffff00u, koff, 0, 0);
+    // kNt: the group's ONLY token tile - nobody else reads these weight rows: non-temporal (streamed once, read by one CU)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)dst, 16, k_ok ? w_voff[q] : 0xffffff00u, koff, 0, kNt ? 2 : 0);
   };
   // the weight pieces of k-tiles 0 and 1 do not depend on the token rows: they could go first, but the wait arithmetic of
   // the loop wants the token chunk OLDER than them - the row-index load below is one L2 round trip
@@ -1054,8 +1055,10 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   const int n0 = __builtin_amdgcn_readfirstlane(it.wt) * kBN;
   // a group's last token tile: <= 64 rows the tail body, <= 128 rows the half-tile body (development key 21 = 1: neither,
   // 2: no tail body)
-  if (m_cnt - mt0 <= 64 && a.no_half_tile == 0 && !kNoDma)
-    p8_tail_body<kHasXs, kAct, kKTail>(a, s_mem, e, mt0, n0, m_cnt, m0);
+  if (m_cnt <= 64 && a.no_half_tile == 0 && !kNoDma && a.nt_single)
+    p8_tail_body<kHasXs, kAct, kKTail, true>(a, s_mem, e, mt0, n0, m_cnt, m0);
+  else if (m_cnt - mt0 <= 64 && a.no_half_tile == 0 && !kNoDma)
+    p8_tail_body<kHasXs, kAct, kKTail, false>(a, s_mem, e, mt0, n0, m_cnt, m0);
   else if (m_cnt - mt0 <= 128 && a.no_half_tile != 1)
     p8_body<Cfg, kHasXs, kNoDma, kAct, true, kKTail>(a, s_mem, e, mt0, n0, m_cnt, m0);
   else
@@ -1090,6 +1093,7 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int n
   using namespace hpc::ggemm;
   Args a = a_in;
   a.no_half_tile = hpc_dev_tuning_get(21);  // development: 1 = full body only, 2 = no tail body
+  a.nt_single = hpc_dev_tuning_get(24) != 1;  // development key 24 = 1: default cache policy for a single-tile group's weights
   if (n % kBN || a.K < kBK) return HPC_ERR_UNSUPPORTED;
   const long max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 256)
   const long items = max_tiles * (n / kBN) + 16;  // + 16: the per-XCD chunks of the full and of the tail tiles round up
