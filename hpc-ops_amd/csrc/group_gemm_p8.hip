@@ -50,14 +50,7 @@ constexpr int kTXOff = kTWOff + 8 * kTW * 4096;      // [2 chunk buffers][kTW sl
 constexpr int kTSOff = kTXOff + 2 * kTW * 8192;      // [2][kTW][64 floats]
 constexpr int kTDummy = kTSOff + 2 * kTW * 256;      // 256 B nobody reads (idle waves' scale DMA)
 constexpr int kLdsTail = kTDummy + 256;
-// the stream body's layout (p8_stream_body): FOUR-stage weight rings, a three-stage ring of single token slabs
-constexpr int kSW = 4;                               // stages of a wave's weight ring
-constexpr int kSX = 3;                               // stages of the token-slab ring
-constexpr int kSXOff = 8 * kSW * 4096;               // 128 KB: [kSX][64 token rows x 128 B]
-constexpr int kSSOff = kSXOff + kSX * 8192;          // [kSX][64 floats]
-constexpr int kSDummy = kSSOff + kSX * 256;
-constexpr int kLdsStream = kSDummy + 256;
-constexpr int kLds = (kLdsTail > kLdsMain ? kLdsTail : kLdsMain) > kLdsStream ? (kLdsTail > kLdsMain ? kLdsTail : kLdsMain) : kLdsStream;
+constexpr int kLds = kLdsTail > kLdsMain ? kLdsTail : kLdsMain;
 static_assert(kLds <= 160 * 1024, "one workgroup per CU");
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -740,7 +733,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   }
 }
 
-// epilogue of the tail / stream bodies: wave w holds weight rows 32 w ... + 31 (2 row blocks) x 64 token slots (4 blocks)
+// epilogue of the tail body: wave w holds weight rows 32 w ... + 31 (2 row blocks) x 64 token slots (4 blocks)
 template <bool kHasXs, bool kAct>
 __device__ __forceinline__ void tail_finish(const Args& a, uint8_t* s_mem, f32x4 (&tot)[2][4], cint_ptr ws_row, int mt0, int n0,
                                             int m_cnt, int m0) {
@@ -1059,210 +1052,6 @@ __device__ __forceinline__ void p8_tail_body(const Args& a, uint8_t* s_mem, int 
   tail_finish<kHasXs, kAct>(a, s_mem, tot, ws_row, mt0, n0, m_cnt, m0);
 }
 
-// ---- the STREAM body: a group whose ONLY token tile holds <= 64 rows (decode-sized batches: 16 ... 64 rows per expert) ----
-// Its weight rows are read once, by this workgroup alone, from HBM: the op is a weight stream (8.7 GB at BASELINE
-// configs[3]) and what bounds it is the bytes a CU keeps in flight at HBM latency (measured with the tail body: 64 KB of
-// weights in flight per CU = 5.5-5.7 TB/s).  Same decomposition and arithmetic as the tail body, but
-//   * FOUR-stage private weight rings - three k-tiles (96 KB per CU) in flight -, non-temporal;
-//   * the token slabs in a three-stage ring of SINGLE slabs (the 128 KB of weight rings leave 24 KB), one barrier per
-//     k-tile - nothing next to ~2 400 ticks of memory latency per k-tile;
-//   * VMEM order per k-tile T: [X(T+2), scales(T+2)] then [W(T+3) x 4]; the wait in front of k-tile T needs everything up
-//     to scales(T) - it leaves W(T+1) x 4 and all of the previous k-tile's six pieces in flight.
-template <bool kHasXs, bool kAct, bool kKTail>
-__device__ __forceinline__ void p8_stream_body(const Args& a, uint8_t* s_mem, int e, int mt0, int n0, int m_cnt, int m0) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r16 = lane & 15, g4 = lane >> 4;
-  const int K = a.K, KB = a.KB;
-  const int inter = a.N >> 1;  // kAct only
-  const int col0 = n0 >> 1;    // kAct only
-  const int p_row = lane >> 3, p_chunk = (lane & 7) ^ (lane >> 3);
-
-  const int wrow0 = kAct ? (wave >> 2) * inter + col0 + (wave & 3) * 32 : n0 + wave * 32;
-  const uint8_t* wsrc = a.w + static_cast<long>(e) * a.N * K;
-  const unsigned w_bytes = static_cast<unsigned>(a.N) * static_cast<unsigned>(K);
-  unsigned w_voff[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) w_voff[q] = static_cast<unsigned>(wrow0 + q * 8 + p_row) * static_cast<unsigned>(K) + p_chunk * 16;
-  auto dma_w = [&](int T, auto stage, int q) {
-    constexpr int kS = decltype(stage)::value;
-    const int koff = T * kBK;
-    const auto rw = make_rsrc(wsrc, T < KB ? w_bytes : 0u);
-    const bool k_ok = !kKTail || koff + p_chunk * 16 < K;
-    uint8_t* dst = s_mem + (wave * kSW + kS) * 4096 + q * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)dst, 16, k_ok ? w_voff[q] : 0xffffff00u, koff, 0, 2);  // nt
-  };
-  unsigned x_voff;
-  {
-    const int slot = mt0 + wave * 8 + p_row;
-    const int sc = slot < m_cnt ? slot : m_cnt - 1;
-    const int xrow = a.row_index ? a.row_index[m0 + sc] : m0 + sc;
-    x_voff = static_cast<unsigned>(xrow) * static_cast<unsigned>(K) + p_chunk * 16;
-  }
-  auto dma_x = [&](int T, auto stage) {
-    constexpr int kS = decltype(stage)::value;
-    const int koff = T * kBK;
-    const auto rx = make_rsrc(a.x, T < KB ? a.x_bytes : 0u);
-    const bool k_ok = !kKTail || koff + p_chunk * 16 < K;
-    uint8_t* dst = s_mem + kSXOff + kS * 8192 + wave * 1024;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)dst, 16, k_ok ? x_voff : 0xffffff00u, koff, 0, 0);
-  };
-  unsigned xs_voff = 0;
-  if constexpr (kHasXs) {
-    const int slot = mt0 + lane;
-    const int sc = slot < m_cnt ? slot : m_cnt - 1;
-    const long cb = a.col_base ? static_cast<long>(as_const(a.col_base)[e]) * a.tile_m : 0;
-    const long term = a.col_base ? cb + sc : static_cast<long>(a.row_index ? a.row_index[m0 + sc] : m0 + sc);
-    xs_voff = static_cast<unsigned>(term * a.xs_row_stride * 4);
-  }
-  const int xs_kb_bytes = static_cast<int>(a.xs_kb_stride * 4);
-  const unsigned xs_nrec = __builtin_amdgcn_readfirstlane(wave == 0 ? 0xffffffffu : 0u);
-  auto dma_xs = [&](int T, auto stage) {  // every wave issues one piece per k-tile (equal vmcnt counts); wave 0 fetches the scales
-    constexpr int kS = decltype(stage)::value;
-    if constexpr (kHasXs) {
-      const auto rs = make_rsrc(a.xs, T < KB ? xs_nrec : 0u);
-      uint8_t* dst = s_mem + (wave == 0 ? kSSOff + kS * 256 : kSDummy);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 4, xs_voff, T * xs_kb_bytes, 0, 0);
-    }
-  };
-  const cint_ptr ws_row = as_const(reinterpret_cast<const int*>(a.ws)) + static_cast<long>(e) * a.ws_group_stride +
-                          ((kAct ? (wave >> 2) * inter + col0 : n0 + wave * 32) >> 7) * a.ws_ntile_stride;
-
-  f32x4 tot[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  int a_rd[2], b_rd[2], xs_rd;
-#pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    a_rd[c] = wave * kSW * 4096 + r16 * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);  // + stage * 4096 + i * 2048
-    asm volatile("" : "+v"(a_rd[c]));
-  }
-  // the token ring starts at 128 KB and the scales behind it: past the 16-bit offset field together with the stage and
-  // block offsets, so each token stage gets its own (opaque) base
-  int b_rdx[kSX][2];
-#pragma unroll
-  for (int st = 0; st < kSX; ++st)
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      b_rdx[st][c] = kSXOff + st * 8192 + r16 * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);  // + j * 2048
-      asm volatile("" : "+v"(b_rdx[st][c]));
-    }
-  (void)b_rd;
-  xs_rd = kSSOff + r16 * 4;  // + stage * 256 + j * 64
-  asm volatile("" : "+v"(xs_rd));
-
-  // ---- prologue: [W(0)] [X(0) scales(0) W(1)] [X(1) scales(1) W(2)] ---------------------------------------------------
-#pragma unroll
-  for (int q = 0; q < 4; ++q) dma_w(0, IntC<0>{}, q);
-  dma_x(0, IntC<0>{});
-  dma_xs(0, IntC<0>{});
-#pragma unroll
-  for (int q = 0; q < 4; ++q) dma_w(1, IntC<1>{}, q);
-  dma_x(1, IntC<1>{});
-  dma_xs(1, IntC<1>{});
-#pragma unroll
-  for (int q = 0; q < 4; ++q) dma_w(2, IntC<2>{}, q);
-  __builtin_amdgcn_sched_barrier(0);
-
-  constexpr int kNx = 1 + (kHasXs ? 1 : 0);  // token + scale pieces per wave and k-tile
-  constexpr int kFly = 4 + kNx + 4;          // W(T+1) x 4, then the previous k-tile's pieces
-  f32x4 pend[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  float fpend[4] = {0.f, 0.f, 0.f, 0.f};
-  auto k_tile = [&](int T, auto wc, auto xc) {
-    constexpr int kQW = decltype(wc)::value, kQX = decltype(xc)::value;  // weight stage T % 4, token stage T % 3
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (kFly & 15) | ((kFly >> 4) << 14));
-    __builtin_amdgcn_s_barrier();  // every wave's X(T) piece has landed; everyone is done with token stage (T + 2) % 3 = (T - 1) % 3
-    __builtin_amdgcn_sched_barrier(0);
-    dma_x(T + 2, IntC<(kQX + 2) % kSX>{});
-    dma_xs(T + 2, IntC<(kQX + 2) % kSX>{});
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dma_w(T + 3, IntC<(kQW + 3) % kSW>{}, q);
-    __builtin_amdgcn_sched_barrier(0);
-    u32x4 af[2][2], bf[4][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) af[i][c] = *reinterpret_cast<const u32x4*>(s_mem + a_rd[c] + kQW * 4096 + i * 2048);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int c = 0; c < 2; ++c) bf[j][c] = *reinterpret_cast<const u32x4*>(s_mem + b_rdx[kQX][c] + j * 2048);
-    float f[4] = {1.f, 1.f, 1.f, 1.f};
-    if constexpr (kHasXs) {
-      const float wsk = __int_as_float(ws_row[T * a.ws_kb_stride]);
-      float xsv[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) xsv[j] = *reinterpret_cast<const float*>(s_mem + xs_rd + kQX * 256 + j * 64);
-      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) f[j] = wsk * xsv[j];
-    } else {
-      __builtin_amdgcn_s_waitcnt(0xC07F);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 pv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      const int i = n >> 2, j = n & 3;
-      const i32x8 av = {static_cast<int>(af[i][0][0]), static_cast<int>(af[i][0][1]), static_cast<int>(af[i][0][2]),
-                        static_cast<int>(af[i][0][3]), static_cast<int>(af[i][1][0]), static_cast<int>(af[i][1][1]),
-                        static_cast<int>(af[i][1][2]), static_cast<int>(af[i][1][3])};
-      const i32x8 bv = {static_cast<int>(bf[j][0][0]), static_cast<int>(bf[j][0][1]), static_cast<int>(bf[j][0][2]),
-                        static_cast<int>(bf[j][0][3]), static_cast<int>(bf[j][1][0]), static_cast<int>(bf[j][1][1]),
-                        static_cast<int>(bf[j][1][2]), static_cast<int>(bf[j][1][3])};
-      if constexpr (kHasXs) {
-        const f32x4 part = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (n >= 2) {
-          const int pi = (n - 2) >> 2, pj = (n - 2) & 3;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) tot[pi][pj][r] = fmaf(pv[1][r], f[pj], tot[pi][pj][r]);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) tot[1][2 + n][r] = fmaf(pend[n][r], fpend[2 + n], tot[1][2 + n][r]);
-        }
-        pv[1] = pv[0];
-        pv[0] = part;
-      } else {
-        tot[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, tot[i][j], 0, 0, 0, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if constexpr (kHasXs) {
-      pend[0] = pv[1];
-      pend[1] = pv[0];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fpend[j] = f[j];
-    }
-  };
-  for (int kb = 0; kb < KB; kb += 12) {  // (T % 4, T % 3) repeats every 12 k-tiles
-    k_tile(kb, IntC<0>{}, IntC<0>{});
-    if (kb + 1 < KB) k_tile(kb + 1, IntC<1>{}, IntC<1>{});
-    if (kb + 2 < KB) k_tile(kb + 2, IntC<2>{}, IntC<2>{});
-    if (kb + 3 < KB) k_tile(kb + 3, IntC<3>{}, IntC<0>{});
-    if (kb + 4 < KB) k_tile(kb + 4, IntC<0>{}, IntC<1>{});
-    if (kb + 5 < KB) k_tile(kb + 5, IntC<1>{}, IntC<2>{});
-    if (kb + 6 < KB) k_tile(kb + 6, IntC<2>{}, IntC<0>{});
-    if (kb + 7 < KB) k_tile(kb + 7, IntC<3>{}, IntC<1>{});
-    if (kb + 8 < KB) k_tile(kb + 8, IntC<0>{}, IntC<2>{});
-    if (kb + 9 < KB) k_tile(kb + 9, IntC<1>{}, IntC<0>{});
-    if (kb + 10 < KB) k_tile(kb + 10, IntC<2>{}, IntC<1>{});
-    if (kb + 11 < KB) k_tile(kb + 11, IntC<3>{}, IntC<2>{});
-  }
-  if constexpr (kHasXs) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) tot[1][2 + t][r] = fmaf(pend[t][r], fpend[2 + t], tot[1][2 + t][r]);
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // drain the (empty) tail DMAs before the workgroup's LDS is reused / released
-
-  tail_finish<kHasXs, kAct>(a, s_mem, tot, ws_row, mt0, n0, m_cnt, m0);
-}
-
 template <class Cfg, bool kHasXs, bool kNoDma = false, bool kAct = false, bool kKTail = false>
 __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, const int* __restrict__ cu_tiles,
                                                                   int num_group) {
@@ -1278,9 +1067,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   const int n0 = __builtin_amdgcn_readfirstlane(it.wt) * kBN;
   // a group's last token tile: <= 64 rows the tail body, <= 128 rows the half-tile body (development key 21 = 1: neither,
   // 2: no tail body)
-  if (m_cnt <= 64 && a.no_half_tile == 0 && !kNoDma && a.nt_single == 1)
-    p8_stream_body<kHasXs, kAct, kKTail>(a, s_mem, e, mt0, n0, m_cnt, m0);
-  else if (m_cnt <= 64 && a.no_half_tile == 0 && !kNoDma && a.nt_single == 2)
+  if (m_cnt <= 64 && a.no_half_tile == 0 && !kNoDma && a.nt_single)
     p8_tail_body<kHasXs, kAct, kKTail, true>(a, s_mem, e, mt0, n0, m_cnt, m0);
   else if (m_cnt - mt0 <= 64 && a.no_half_tile == 0 && !kNoDma)
     p8_tail_body<kHasXs, kAct, kKTail, false>(a, s_mem, e, mt0, n0, m_cnt, m0);
@@ -1318,9 +1105,11 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int n
   using namespace hpc::ggemm;
   Args a = a_in;
   a.no_half_tile = hpc_dev_tuning_get(21);  // development: 1 = full body only, 2 = no tail body
-  // a group's ONLY (<= 64-row) token tile: the stream body; development key 24: 1 = the tail body, 2 = the tail body with
-  // non-temporal weight loads (the round-5 steps on the way)
-  a.nt_single = hpc_dev_tuning_get(24) == 1 ? 0 : (hpc_dev_tuning_get(24) == 2 ? 2 : 1);
+  // a group's ONLY (<= 64-row) token tile streams its weights non-temporally (development key 24 = 1: default policy).
+  // (A four-stage form of the weight rings with a single-slab token ring - 96 instead of 64 KB of weights in flight per CU -
+  // was built, bit-identical, and measured no faster: T = 256 1 515-1 563 against 1 505-1 512 us, profiles/
+  // round5_moe_kernel_choice.txt; the stream is not bound by the bytes in flight at that point.  Removed.)
+  a.nt_single = hpc_dev_tuning_get(24) != 1;
   if (n % kBN || a.K < kBK) return HPC_ERR_UNSUPPORTED;
   const long max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 256)
   const long items = max_tiles * (n / kBN) + 16;  // + 16: the per-XCD chunks of the full and of the tail tiles round up

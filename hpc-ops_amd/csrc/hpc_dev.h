@@ -31,7 +31,7 @@
 //   key 22 256x256 grouped GEMM, blockwise: variant of the k-loop (group_gemm_p8.hip: 1 section profile, 2 the round-4 loop
 //          (tails behind the barrier), 3 its profile, 4 no s_setprio)
 //   key 25 grouped GEMM kernel choice: 1 = the 256 x 256 kernel only from 192 rows per group on (rounds 2-4)
-//   key 24 256x256 grouped GEMM, single-tile groups (<= 64 rows): 1 = tail body instead of the stream body, 2 = tail body with non-temporal weight loads
+//   key 24 256x256 grouped GEMM, tail body: 1 = default cache policy instead of non-temporal weight loads for single-tile groups
 //   key 23 256x256 grouped GEMM: 1 = all full tiles first, tail tiles last (measured slower than tails in place)
 //   key 33 decode, first generation: 1 = split requests merged by decode_combine_kernel (second launch) instead of the last arriver
 //   key 34 decode scheduler: bin count override (<= 4 per CU)

@@ -382,10 +382,10 @@ def test_group_gemm_blockwise_many_groups(tiled_mode, num_group):
 @pytest.mark.dev
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,k", [(512, 512), (768, 1408), (256, 2048)])  # 4, 11 and 16 k-tiles: shorter than / not a multiple of / longer
-def test_group_gemm_tail_body_is_bit_identical(n, k):                      # than the rings' periods (6 for the tail, 12 for the stream body)
+def test_group_gemm_tail_body_is_bit_identical(n, k):                      # than the rings' period of 6 k-tiles
     """A group's last token tile with <= 64 rows runs the TAIL body of the 256 x 256 kernel (round 5: per-wave weight
-    rings, 64-token chunks of three k-slabs, one barrier per three k-tiles), a group's ONLY tile with <= 64 rows the STREAM
-    body (four-stage non-temporal weight rings, single-slab token ring) - every third group here.  Same operand conventions and the same
+    rings, 64-token chunks of three k-slabs, one barrier per three k-tiles; a group's ONLY tile - every third group here -
+    with non-temporal weight loads).  Same operand conventions and the same
     arithmetic order as the full / half-tile bodies, so the output must be BIT-IDENTICAL to the round-4 dispatch
     (development key 21 = 2: tails on the half-tile body) - groups of every tail size 1 ... 64 next to 65, 128, 129 and
     empty groups, blockwise scales of either sign; and within the reference tolerance of the oracle."""
