@@ -123,25 +123,16 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
   const uint8_t* vbase = static_cast<const uint8_t*>(a.vcache);
 
   // ---- how many tasks does this bin hold, and how long is the longest? ------------------------------
-  // (lane-parallel scan of the bin's records; the list ends at the first h < 0 / b < 0 record.)  The first 64 records
-  // are loaded WHOLE here - lane i keeps the eight ints of record i - so that a task takes its fields from registers
-  // (v_readlane) instead of one more scalar round trip through the task map per task (round 5: the chain record ->
-  // page ids -> K is what a one-tile-per-wave bin spends its time on).
+  // (lane-parallel scan of the bin's records; the list ends at the first h < 0 / b < 0 record)
   int ntasks = 0, max_ntile = 0;
-  i32x4 rec_lo = {-1, -1, 0, 0}, rec_hi = {0, 0, 0, 0};
   for (int base = 0; base < per1; base += 64) {
     const int idx = base + lane;
     int hh = -1, bb = -1, nt = 0;
     if (idx < per1) {
       const int* rec = a.task_map + static_cast<long>(kTaskStride) * (1 + static_cast<long>(bin) * per1 + idx);
-      const i32x4 lo = *reinterpret_cast<const i32x4*>(rec), hi = *reinterpret_cast<const i32x4*>(rec + 4);
-      hh = lo[0];
-      bb = lo[1];
-      nt = hi[2];
-      if (kNB < 3 && base == 0) {  // (the three-block kernel sits at the 512-register limit: it keeps the scalar reads)
-        rec_lo = lo;
-        rec_hi = hi;
-      }
+      hh = rec[0];
+      bb = rec[1];
+      nt = rec[6];
     }
     const uint64_t bad = __ballot(hh < 0 || bb < 0);
     const int first = bad ? __builtin_ctzll(bad) : 64;
@@ -159,30 +150,17 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
   // (long tasks: KV streaming).  SOLO: one wave runs the whole task alone and finishes it without
   // any workgroup barrier, so 4 short tasks of a bin run side by side - a bin packed with short
   // requests (mixed-length batches) would otherwise serialise ~5 us of latency chain per task.
-  auto run_task = [&](int it, auto solo_c) {
+  auto run_task = [&](cint_ptr task_ptr, auto solo_c) {
     constexpr bool kSolo = decltype(solo_c)::value;
     const int t_first = kSolo ? 0 : wave, t_step = kSolo ? 1 : kWaves;
-    int h, b, ichunk, iseq_start, num_seqkv, num_seqkvcache, ntile, ntile_full;
-    if (kNB < 3 && it < 64) {  // (wave-uniform) the record sits in lane `it`
-      h = __builtin_amdgcn_readlane(rec_lo[0], it);
-      b = __builtin_amdgcn_readlane(rec_lo[1], it);
-      ichunk = __builtin_amdgcn_readlane(rec_lo[2], it);
-      iseq_start = __builtin_amdgcn_readlane(rec_lo[3], it);
-      num_seqkv = __builtin_amdgcn_readlane(rec_hi[0], it);
-      num_seqkvcache = __builtin_amdgcn_readlane(rec_hi[1], it);
-      ntile = __builtin_amdgcn_readlane(rec_hi[2], it);
-      ntile_full = __builtin_amdgcn_readlane(rec_hi[3], it);
-    } else {
-      const cint_ptr tp = task_ptr + it * kTaskStride;
-      h = __builtin_amdgcn_readfirstlane(tp[0]);
-      b = __builtin_amdgcn_readfirstlane(tp[1]);
-      ichunk = __builtin_amdgcn_readfirstlane(tp[2]);
-      iseq_start = __builtin_amdgcn_readfirstlane(tp[3]);
-      num_seqkv = __builtin_amdgcn_readfirstlane(tp[4]);
-      num_seqkvcache = __builtin_amdgcn_readfirstlane(tp[5]);
-      ntile = __builtin_amdgcn_readfirstlane(tp[6]);
-      ntile_full = __builtin_amdgcn_readfirstlane(tp[7]);
-    }
+    const int h = __builtin_amdgcn_readfirstlane(task_ptr[0]);
+    const int b = __builtin_amdgcn_readfirstlane(task_ptr[1]);
+    const int ichunk = __builtin_amdgcn_readfirstlane(task_ptr[2]);
+    const int iseq_start = __builtin_amdgcn_readfirstlane(task_ptr[3]);
+    const int num_seqkv = __builtin_amdgcn_readfirstlane(task_ptr[4]);
+    const int num_seqkvcache = __builtin_amdgcn_readfirstlane(task_ptr[5]);
+    const int ntile = __builtin_amdgcn_readfirstlane(task_ptr[6]);
+    const int ntile_full = __builtin_amdgcn_readfirstlane(task_ptr[7]);
 
     // ---- Q fragments (B operand of S^T = K Q^T) and per-row score scales -----------------------
     // bf16: lane (n, g) holds dims (4j+g)*8..+7 for k-step j; fp8: 16-byte chunks g and g+4.
@@ -640,11 +618,11 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
   if constexpr (kNB < 3) {
     const bool solo = ntasks >= 2 && max_ntile <= kSoloMaxTiles && a.solo_ok;
     if (solo) {
-      for (int it = wave; it < ntasks; it += kWaves) run_task(it, std::true_type{});
+      for (int it = wave; it < ntasks; it += kWaves) run_task(task_ptr + it * kTaskStride, std::true_type{});
       return;
     }
   }
-  for (int it = 0; it < ntasks; ++it) run_task(it, std::false_type{});
+  for (int it = 0; it < ntasks; ++it) run_task(task_ptr + it * kTaskStride, std::false_type{});
 }
 
 // ---- split-KV combine: y = sum_c 2^(lse_c - max) O_c / sum_c 2^(lse_c - max) ----------------------------

@@ -32,7 +32,6 @@ struct Args {
   const float* kscale;  // [1] or base of the per-token K-scale rows
   const float* vscale;  // [1] or [Hkv]
   int by_head;  // row mapping, see the kernel
-  int prio;     // development key 36: 1 = s_setprio 1 around a stage's MFMA phases (S^T and P V), 0 around its softmax
   const uint8_t* block_mask;  // null, or [B][Hq][mask_tiles_m][mask_tiles_kv]: 128 x 128 (q pos x kv token) tiles
   int mask_tiles_m, mask_tiles_kv;
   int num_batch, num_head_q, num_head_kv, g_shift, page_shift, max_blocks, qs_pad;
@@ -354,7 +353,6 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
     // ---- S^T = K Q^T: the whole head dim in ONE v_mfma_f32_16x16x128_f8f6f4 per 16 x 16 block; lane (n, g) supplies
     // chunks g and g + 4 of its row on both sides ---------------------------------------------------------------
     f32x4 s[kNB][8];
-    if (kHpcDevBuild && a.prio == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int tb = 0; tb < 8; ++tb) {
       u32x4 ka[2];
@@ -378,7 +376,6 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
 
     // ---- online softmax, base 2.  p is produced as 256 p (the +8 rides in the exponent): it feeds the
     // e4m3 pack directly and the row sum is kept in the same units (undone once in the epilogue). -------
-    if (kHpcDevBuild && a.prio == 1) __builtin_amdgcn_s_setprio(0);
     i32x8 pf[kNB];
     bool all_bits = true;
 #pragma unroll
@@ -452,7 +449,6 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
     // dense: V^T operands shared by the two blocks (848 us against 888 us with one pass per block; the block-sparse
     // form is the other way round, 799 against 839 us at skip 0.5: half its blocks need no pass)
     if constexpr (!kSparse) {
-      if (kHpcDevBuild && a.prio == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
         const i32x8 va = vt_operand(jj);
@@ -460,7 +456,6 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_fp8_kernel(const Args a) 
         for (int nb = 0; nb < kNB; ++nb)
           o[nb][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(va, pf[nb], o[nb][jj], 0, 0, 0, 0, 0, 0);
       }
-      if (kHpcDevBuild && a.prio == 1) __builtin_amdgcn_s_setprio(0);
     }
   };
   // tiles every row of this wave sees in full, scales of a real quantiser (>= 0), no per-row mask bits: the fast body
@@ -559,7 +554,6 @@ static int prefill_fp8_launch(const void* block_mask_ptr, int mask_tiles_m, int 
   // head-major 16-row blocks let a block skip masked-out tiles (block-sparse); dense attention measured ~8 %
   // faster with every wave holding all G heads of a few positions (key 7 overrides: 1 = by head, 2 = by position)
   a.by_head = group <= 8 && (hpc_dev_tuning_get(7) ? hpc_dev_tuning_get(7) == 1 : block_mask_ptr != nullptr);
-  a.prio = hpc_dev_tuning_get(36);
   a.mask_tiles_m = mask_tiles_m;
   a.mask_tiles_kv = mask_tiles_kv;
   if (block_mask_ptr && (mask_tiles_m <= 0 || mask_tiles_kv <= 0)) return HPC_ERR_INVALID;

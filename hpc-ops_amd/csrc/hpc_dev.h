@@ -35,7 +35,6 @@
 //   key 23 256x256 grouped GEMM: 1 = all full tiles first, tail tiles last (measured slower than tails in place)
 //   key 33 decode, first generation: 1 = split requests merged by decode_combine_kernel (second launch) instead of the last arriver
 //   key 34 decode scheduler: bin count override (<= 4 per CU)
-//   key 36 fp8 prefill: 1 = s_setprio 1 around a stage's MFMA phases
 //   others: see the launchers that read them
 #pragma once
 
