@@ -23,7 +23,14 @@
 //     section's barrier) and lands two or more sections before its first read; the waits are the constants
 //     vmcnt(9|8) and vmcnt(6);
 //   * the blockwise rescale is software-pipelined by hand: the four FMAs of block n follow the MFMA of
-//     block n+2, the last two blocks' follow the barrier that ends the section;
+//     block n+2, and the last two blocks' are CARRIED into the wave's next MFMA section (behind its first
+//     MFMAs).  Round 5: a load section holds no VALU work at all - with the partner wave of the SIMD
+//     multiplying at raised priority, every VALU instruction of a load section waits for an issue slot
+//     between the partner's MFMAs (s_memtime stamps: profiles/round5_moe_p8_section_profile.txt);
+//   * three bodies share the launch (round 5): the full tile, a half tile for a group's last <= 128 rows
+//     (half the token strips, the same sections) and a tail body for its last <= 64 rows (p8_tail_body: no
+//     shared weight staging - each wave streams its own 32 weight rows through a private 3-stage ring, the
+//     <= 64 token rows arrive in chunks of 3 k-slabs, one barrier per 3 k-tiles);
 //   * LDS image, source-side XOR swizzle and the K = 128 MFMA operand convention as in
 //     group_gemm_tiled256.hip; 2 x 64 KB + scales = 131 KB of LDS, one workgroup per CU;
 //   * epilogue: neighbouring row blocks are exchanged between lane quarters (v_permlane16_swap) so that a
