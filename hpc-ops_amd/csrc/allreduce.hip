@@ -19,7 +19,8 @@
 //    the broadcast copy, then adds the residual and normalises.  Three slots rotate; the slot
 //    state lives in the caller's `buffer_flags` exactly like the reference (low_latency.h:208-304).
 //    No workgroup ever waits on another workgroup of the same GPU, so the protocol cannot
-//    deadlock on residency; every spin is bounded.
+//    deadlock on residency; every spin is bounded.  Round 5: when the grid is resident at once the two
+//    phases run in ONE launch (ll_fused_kernel) - at decode sizes the second launch was a third of the call.
 #include "hpc_common.h"
 #include "hpc_dev.h"
 #include "../../include/hpc_amd.h"
@@ -266,7 +267,8 @@ __device__ __forceinline__ void ll_scatter_body(const LlArgs& a, int bid, int nb
   // 1. clean the slot the NEXT call will use: nobody reads or writes it any more (everyone has
   //    finished the call before the previous one, or this call could not have started)
   {
-    const uint32_t dirty = a.flags[4 + nxt];
+    const uint32_t d0 = a.flags[4], d1 = a.flags[5], d2 = a.flags[6];  // one round trip with `cur`, not one behind it
+    const uint32_t dirty = nxt == 0u ? d0 : nxt == 1u ? d1 : d2;
     uint8_t* base = a.local_ws + static_cast<long>(nxt) * slot_bytes;
     const u32x4 s = u32x4{kSentinel, kSentinel, kSentinel, kSentinel};
     for (long o = (static_cast<long>(bid) * kThreads + threadIdx.x) * 16; o < dirty;
@@ -327,6 +329,7 @@ __device__ __forceinline__ void ll_reduce_norm_body(const LlArgs& a, int bid, in
   const long bcast_off = static_cast<long>(cur) * slot_bytes + static_cast<long>(n_pad) * row_bytes;
 
   // slot bookkeeping: the last workgroup to arrive (all have read `cur` by then) rotates the slots
+  // (looking at the ticket only after the rows was measured: T 8 9.0 -> 8.8 us, T 128 11.5 -> 12.7 - not kept)
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t old = atomicAdd(&a.flags[8], 1u);
@@ -409,6 +412,17 @@ __global__ __launch_bounds__(kThreads) void ll_reduce_norm_kernel(const LlArgs a
   __shared__ float red[4];
   ll_reduce_norm_body<kVec>(a, blockIdx.x, gridDim.x, red);
 }
+// Both phases in ONE launch (round 5): workgroup b pushes rows b, b + grid, ... and then reduces / polls the same
+// rows, so it only ever waits for workgroup b of the OTHER ranks, and those push before they wait - the property the
+// two-kernel form has ("never waits on a workgroup of the same GPU") is kept.  Both bodies read the slot state before
+// this workgroup arrives at the rotation counter, so the state they see is the same.  Used when the whole grid is
+// resident at once (no assumption about the order in which a GPU starts workgroups); larger grids keep two launches.
+template <int kVec>
+__global__ __launch_bounds__(kThreads) void ll_fused_kernel(const LlArgs a) {
+  __shared__ float red[4];
+  ll_scatter_body(a, blockIdx.x, gridDim.x);
+  ll_reduce_norm_body<kVec>(a, blockIdx.x, gridDim.x, red);
+}
 
 #ifdef HPC_DEV
 // ---------------------------------------------------------------------------------------------
@@ -437,6 +451,15 @@ __global__ __launch_bounds__(kThreads) void ll_reduce_norm_loopback_kernel(const
   __shared__ LlArgs a;
   if (threadIdx.x == 0) a = all[blockIdx.y];
   __syncthreads();
+  ll_reduce_norm_body<kVec>(a, blockIdx.x, gridDim.x, red);
+}
+template <int kVec>
+__global__ __launch_bounds__(kThreads) void ll_fused_loopback_kernel(const LlArgs* all) {
+  __shared__ float red[4];
+  __shared__ LlArgs a;
+  if (threadIdx.x == 0) a = all[blockIdx.y];
+  __syncthreads();
+  ll_scatter_body(a, blockIdx.x, gridDim.x);
   ll_reduce_norm_body<kVec>(a, blockIdx.x, gridDim.x, red);
 }
 #endif  // HPC_DEV
@@ -544,6 +567,26 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_high_throughput_async(
   return HPC_OK;
 }
 
+// workgroups of the fused low-latency kernel the current device holds at once (per instantiation, cached per device)
+static int ll_fused_capacity(bool wide, bool resident) {
+  static int cap[16][2], cu_count[16];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;
+  if (cap[dev][wide] == 0) {
+    int per_cu = 0, cus = 0;
+    hipError_t e = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ll_fused_kernel<8>, kThreads, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ll_fused_kernel<4>, kThreads, 0);
+    if (e != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    cap[dev][wide] = per_cu * cus > 0 ? per_cu * cus : -1;
+    cu_count[dev] = cus;
+  }
+  if (cap[dev][wide] <= 0) return 0;
+  return resident || cap[dev][wide] < cu_count[dev] ? cap[dev][wide] : cu_count[dev];
+}
+
 extern "C" int hpc_fuse_allreduce_rmsnorm_low_latency_async(
     void* output_ptr, void* residual_out_ptr, const void* input_ptr, const void* data_buffer_ptrs_dev,
     void* local_workspace_ptr, void* buffer_flags_dev, const void* residual_in_ptr,
@@ -578,9 +621,21 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_low_latency_async(
   a.rank = rank;
   a.ws = world_size;
   const int grid = num_tokens < 2048 ? num_tokens : 2048;
+  const bool wide = hidden_size > 4 * kThreads * 8;
+  // one launch up to one workgroup per CU (measured at ws = 1, H 8192: T 8 / 128 9.0 / 11.5 us against 10.0 / 12.5 with two
+  // launches, T 512 25.6 against 23.1 - with two workgroups per CU the second's scatter waits behind the first's poll)
+  const int key35 = hpc_dev_tuning_get(35);  // development: 1 = always two launches, 2 = one launch whenever resident
+  if (key35 != 1 && grid <= ll_fused_capacity(wide, key35 == 2)) {
+    if (!wide)
+      ll_fused_kernel<4><<<grid, kThreads, 0, stream>>>(a);
+    else
+      ll_fused_kernel<8><<<grid, kThreads, 0, stream>>>(a);
+    HPC_CHECK_LAUNCH();
+    return HPC_OK;
+  }
   ll_scatter_kernel<<<grid, kThreads, 0, stream>>>(a);
   HPC_CHECK_LAUNCH();
-  if (hidden_size <= 4 * kThreads * 8)
+  if (!wide)
     ll_reduce_norm_kernel<4><<<grid, kThreads, 0, stream>>>(a);
   else
     ll_reduce_norm_kernel<8><<<grid, kThreads, 0, stream>>>(a);
@@ -684,6 +739,14 @@ extern "C" int hpc_dev_allreduce_loopback_ll(void* const* output, void* const* r
   const LlArgs* dev = loopback_args_on_device(host, world_size, stream);
   if (!dev) return HPC_ERR_LAUNCH;
   const dim3 g(num_tokens < 2048 ? num_tokens : 2048, world_size);
+  if (static_cast<int>(g.x * g.y) <= ll_fused_capacity(hidden > 4 * kThreads * 8, true) && hpc_dev_tuning_get(35) != 1) {
+    if (hidden <= 4 * kThreads * 8)
+      ll_fused_loopback_kernel<4><<<g, kThreads, 0, stream>>>(dev);
+    else
+      ll_fused_loopback_kernel<8><<<g, kThreads, 0, stream>>>(dev);
+    HPC_CHECK_LAUNCH();
+    return HPC_OK;
+  }
   ll_scatter_loopback_kernel<<<g, kThreads, 0, stream>>>(dev);
   HPC_CHECK_LAUNCH();
   if (hidden <= 4 * kThreads * 8)

@@ -35,6 +35,8 @@
 //   key 23 256x256 grouped GEMM: 1 = all full tiles first, tail tiles last (measured slower than tails in place)
 //   key 33 decode, first generation: 1 = split requests merged by decode_combine_kernel (second launch) instead of the last arriver
 //   key 34 decode scheduler: bin count override (<= 4 per CU)
+//   key 35 low-latency all-reduce: 1 = always two launches, 2 = one launch whenever the grid is resident at once
+//          (default: one launch up to one workgroup per CU)
 //   others: see the launchers that read them
 #pragma once
 

@@ -186,7 +186,8 @@ def _spawn(world_size, one_gpu_per_rank=False, tuning="", cases=None, timeout=60
 @pytest.mark.exclusive_gpu
 @pytest.mark.gpu
 def test_allreduce_rmsnorm_world1():
-    _spawn(1)
+    # the last case has more rows than the GPU holds workgroups of the fused low-latency kernel: the two-launch form
+    _spawn(1, cases=CASES + [("ll", 2100, 2048, 4, 2)])
 
 
 @pytest.mark.exclusive_gpu
@@ -275,9 +276,14 @@ def test_allreduce_rmsnorm_ws8_loopback(world_size):
         assert lib.hpc_allreduce_reset_timeouts() == 0
         for mode, N, H, nblk, iters in (("ht", 64, 8192, 4, 3), ("ht", 61, 5120, 3, 2), ("ht_uneven", 96, 4096, 4, 2),
                                         ("ht", 16, 16384, 2, 2), ("ll", 16, 8192, 4, 5), ("ll", 13, 7168, 4, 4),
-                                        ("ll", 24, 16384, 4, 3)):
+                                        ("ll", 24, 16384, 4, 3), ("ll_two_launches", 16, 8192, 4, 4),
+                                        ("ll_two_launches", 11, 16384, 4, 2)):
             N_pad = (N + ws - 1) // ws * ws
-            if mode == "ll":
+            # round 5: the low-latency entry runs both phases in one launch when the grid is resident at once (these sizes);
+            # development key 35 = 1 keeps the scatter / reduce launches apart - the form larger grids still take
+            dev_set(35, 1 if mode == "ll_two_launches" else 0)
+            if mode.startswith("ll"):
+                mode = "ll"
                 M_pad = 2 * math.ceil(N / ws) * ws * 3
                 bufs = [torch.full((M_pad, H // 2), -(2 ** 31), dtype=torch.int32, device=dev) for _ in range(ws)]
                 table = torch.tensor([b.data_ptr() for b in bufs], dtype=torch.int64, device=dev)
@@ -349,6 +355,7 @@ def test_allreduce_rmsnorm_ws8_loopback(world_size):
     finally:
         dev_set(10, 0)
         dev_set(11, 0)
+        dev_set(35, 0)
 
 
 @pytest.mark.exclusive_gpu
