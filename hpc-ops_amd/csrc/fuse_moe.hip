@@ -58,73 +58,181 @@ __device__ __forceinline__ int block_sum(int v, int* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// seqlens[e] = #{i : ids[i] == first_expert + e}
-__global__ __launch_bounds__(kThreads) void count_kernel(const int* __restrict__ ids, int n,
-                                                         int first_expert, int* __restrict__ seqlens) {
-  __shared__ int red[4];
+// Four consecutive routed ids starting at i (all inside the array).  kVec = the id array is 16-byte aligned: one
+// 16-byte load; otherwise four 4-byte loads.  No branch on the data path: the loops below keep several of these in flight.
+template <bool kVec>
+__device__ __forceinline__ void load_ids4(const int* __restrict__ ids, int i, int (&id)[4]) {
+  if constexpr (kVec) {
+    const int4 v = *reinterpret_cast<const int4*>(ids + i);
+    id[0] = v.x; id[1] = v.y; id[2] = v.z; id[3] = v.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) id[j] = ids[i + j];
+  }
+}
+
+// A wave's share of the id array: wave w of kW owns [w * share_len(n), ...) - a multiple of 4 ids, so that 16-byte loads
+// stay aligned; the n % 4 ids behind the last full group of four are looked at one by one.
+template <int kW>
+__device__ __forceinline__ int share_len(int n) { return (((n + kW - 1) / kW) + 3) & ~3; }
+
+template <int kW>
+__device__ __forceinline__ int block_sum_w(int v, int* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  int t = 0;
+#pragma unroll
+  for (int w = 0; w < kW; ++w) t += red[w];
+  return t;
+}
+
+// seqlens[e] = #{i : ids[i] == first_expert + e}.  One workgroup of kW waves per expert; a lane compares 4 ids per
+// 16-byte load.  Round 5: one id per load and lane in a 4-wave workgroup took 32 us for the 32768 routed ids of the fused
+// MoE's 4096-token case - a lone wave per SIMD issues an instruction every ~5 cycles, so the loop count per wave is
+// what the kernel costs: 16 waves and 4 ids per lane cut it 16-fold.
+template <bool kVec, int kW>
+__global__ __launch_bounds__(kW * 64) void count_kernel(const int* __restrict__ ids, int n,
+                                                        int first_expert, int* __restrict__ seqlens) {
+  __shared__ int red[kW];
   const int target = first_expert + blockIdx.x;
+  const int n4 = n & ~3;
   int c = 0;
-  for (int i = threadIdx.x; i < n; i += kThreads) c += ids[i] == target;
-  c = block_sum(c, red);
+#pragma unroll 2
+  for (int i = threadIdx.x * 4; i < n4; i += kW * 256) {
+    int id[4];
+    load_ids4<kVec>(ids, i, id);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c += id[j] == target;
+  }
+  if (n4 + static_cast<int>(threadIdx.x) < n) c += ids[n4 + threadIdx.x] == target;
+  c = block_sum_w<kW>(c, red);
   if (threadIdx.x == 0) seqlens[blockIdx.x] = c;
 }
 
-// Stable slotting of expert blockIdx.x: topk_pos[i] = cu_seqlens[e] + (# earlier i' with the same
-// expert); row_index[pos] = token.  Block 0 also writes cu_seqlens / tiles / cu_tiles; entries whose
-// expert is not local get topk_pos = -1.
-__global__ __launch_bounds__(kThreads) void slot_kernel(
+// Stable slotting: entry i (token i / num_topk) routed to local expert e gets position cu_seqlens[e] + #{i' < i routed to e}.
+// One workgroup of kW waves per expert.  Round 5: every wave owns a contiguous share of the id array - it counts its
+// share's matches first (the shares before it give its starting offset: ONE barrier), then walks the share again,
+// 256 ids per step (4 per lane, one ballot per id column), with no further barrier.  The one-id-per-lane form with two
+// barriers per 256 ids took 64 us at 32768 ids; like the count, the walk is paced by instruction issue of a lone wave
+// per SIMD (~0.75 us per 256 ids), so large batches get 16 waves per expert.
+template <bool kVec, int kW>
+__global__ __launch_bounds__(kW * 64) void slot_kernel(
     const int* __restrict__ ids, int n, int num_topk, int first_expert, int num_expert, int tile_m,
     const int* __restrict__ seqlens, int* __restrict__ cu_seqlens, int* __restrict__ tiles,
     int* __restrict__ cu_tiles, int* __restrict__ topk_pos, int* __restrict__ row_index) {
-  __shared__ int red[4];
-  __shared__ int wave_cnt[4];
+  __shared__ int red[kW];
+  __shared__ int wave_cnt[kW];
   const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int part = 0;
-  for (int j = tid; j < e; j += kThreads) part += seqlens[j];
-  const int cu = block_sum(part, red);
-
-  if (e == 0) {
-    if (tid == 0) {
-      int c = 0, ct = 0;
-      for (int j = 0; j < num_expert; ++j) {
-        cu_seqlens[j] = c;
-        const int t = (seqlens[j] + tile_m - 1) / tile_m;
-        tiles[j] = t;
-        cu_tiles[j] = ct;
-        c += seqlens[j];
-        ct += t;
-      }
-      cu_seqlens[num_expert] = c;
-      cu_tiles[num_expert] = ct;
+  // exclusive prefixes of the row and tile counts of the experts before this one: every workgroup writes its own
+  // entries (round 5: thread 0 of workgroup 0 used to walk all experts one dependent load at a time - the longest
+  // chain of the kernel), the last one also the totals
+  int part = 0, part_t = 0;
+  for (int j = tid; j < e; j += kW * 64) {
+    const int c = seqlens[j];
+    part += c;
+    part_t += (c + tile_m - 1) / tile_m;
+  }
+  const int cu = block_sum_w<kW>(part, red);
+  const int cu_t = block_sum_w<kW>(part_t, red);
+  if (tid == 0) {
+    const int c = seqlens[e], t = (c + tile_m - 1) / tile_m;
+    cu_seqlens[e] = cu;
+    tiles[e] = t;
+    cu_tiles[e] = cu_t;
+    if (e == num_expert - 1) {
+      cu_seqlens[num_expert] = cu + c;
+      cu_tiles[num_expert] = cu_t + t;
     }
   }
   const int target = first_expert + e;
-  int running = 0;
-  for (int base = 0; base < n; base += kThreads) {
-    const int i = base + tid;
+  const int n4 = n & ~3;
+  const int slen = share_len<kW>(n);
+  const int q_begin = wave * slen < n4 ? wave * slen : n4;
+  const int q_end = q_begin + slen < n4 ? q_begin + slen : n4;  // groups of four; the n % 4 ids behind n4: last wave, below
+  int mine = 0;
+#pragma unroll 2
+  for (int i = q_begin + lane * 4; i < q_end; i += 256) {
+    int id[4];
+    load_ids4<kVec>(ids, i, id);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mine += id[j] == target;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if (lane == 0) wave_cnt[wave] = mine;
+  __syncthreads();
+  int running = cu;
+#pragma unroll
+  for (int w = 0; w < kW; ++w) running += w < wave ? wave_cnt[w] : 0;
+
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int last_expert = first_expert + num_expert;
+  // token (i / num_topk) and owner (i % num_expert) of a lane's first entry are divided out ONCE and then advanced by
+  // additions
+  const int first_i = q_begin + lane * 4;
+  int tok0 = first_i / num_topk, sub0 = first_i - tok0 * num_topk;
+  int own0 = first_i % num_expert;
+  const int step_tok = 256 / num_topk, step_sub = 256 - step_tok * num_topk;
+  const int step_own = 256 % num_expert;
+  int nxt[4] = {-1, -1, -1, -1};  // the next step's ids are requested before this step's positions are stored
+  if (first_i < q_end) load_ids4<kVec>(ids, first_i, nxt);
+  for (int base = q_begin; base < q_end; base += 256) {
+    const int i0 = base + lane * 4;
+    const bool live = i0 < q_end;
+    int id[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      id[j] = nxt[j];
+      nxt[j] = -1;
+    }
+    if (i0 + 256 < q_end) load_ids4<kVec>(ids, i0 + 256, nxt);
+    int pre = 0, tot = 0;  // matches in lower lanes / in these 256 ids
+    bool match[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      match[j] = id[j] == target;
+      const unsigned long long bal = __ballot(match[j]);
+      pre += __builtin_popcountll(bal & below);
+      tot += __builtin_popcountll(bal);
+    }
+    int pos = running + pre;
+    int tok = tok0, sub = sub0, own = own0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (match[j]) {
+        topk_pos[i0 + j] = pos;
+        row_index[pos] = tok;
+        ++pos;
+      }
+      // non-local experts: exactly one block owns entry i
+      if (live && (id[j] < first_expert || id[j] >= last_expert) && own == e) topk_pos[i0 + j] = -1;
+      if (++sub == num_topk) { sub = 0; ++tok; }
+      if (++own == num_expert) own = 0;
+    }
+    running += tot;
+    tok0 += step_tok;
+    sub0 += step_sub;
+    if (sub0 >= num_topk) { sub0 -= num_topk; ++tok0; }
+    own0 += step_own;
+    if (own0 >= num_expert) own0 -= num_expert;
+  }
+  // the n % 4 ids behind the last group of four: after every group in index order, so the last wave takes them
+  // (its `running` has arrived at the count of everything before them)
+  if (wave == kW - 1 && n4 < n) {
+    const int i = n4 + lane;
     const int id = i < n ? ids[i] : -1;
     const bool match = id == target;
     const unsigned long long bal = __ballot(match);
-    const int pre = __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_cnt[wave] = __builtin_popcountll(bal);
-    __syncthreads();
-    int off = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const int c = wave_cnt[w];
-      off += w < wave ? c : 0;
-      tot += c;
-    }
     if (match) {
-      const int pos = cu + running + off + pre;
+      const int pos = running + __builtin_popcountll(bal & below);
       topk_pos[i] = pos;
       row_index[pos] = i / num_topk;
     }
-    // non-local experts: exactly one block owns entry i
-    if (i < n && (id < first_expert || id >= first_expert + num_expert) && (i % num_expert) == e)
-      topk_pos[i] = -1;
-    running += tot;
-    __syncthreads();
+    if (i < n && (id < first_expert || id >= last_expert) && i % num_expert == e) topk_pos[i] = -1;
   }
 }
 
@@ -369,13 +477,24 @@ extern "C" int hpc_moe_count_and_slot_async(const void* topk_ids, int num_tokens
   if (num_expert <= 0 || num_topk <= 0 || tile_m <= 0 || num_tokens < 0) return HPC_ERR_INVALID;
   const int n = num_tokens * num_topk;
   const int first = rank_ep * num_expert;
-  count_kernel<<<num_expert, kThreads, 0, stream>>>(static_cast<const int*>(topk_ids), n, first,
-                                                    static_cast<int*>(seqlens));
-  HPC_CHECK_LAUNCH();
-  slot_kernel<<<num_expert, kThreads, 0, stream>>>(
-      static_cast<const int*>(topk_ids), n, num_topk, first, num_expert, tile_m,
-      static_cast<const int*>(seqlens), static_cast<int*>(cu_seqlens), static_cast<int*>(tiles),
-      static_cast<int*>(cu_tiles), static_cast<int*>(topk_pos), static_cast<int*>(row_index));
+  // 16-byte id loads when the array allows them (any tensor torch hands over does; a caller's odd offset gets 4-byte loads);
+  // 16 waves per expert from 4096 routed ids on (the walk is paced by instruction issue per wave), 4 below
+  const bool vec = (reinterpret_cast<uintptr_t>(topk_ids) & 15) == 0;
+  const bool wide = n >= 4096;
+  const int* ids = static_cast<const int*>(topk_ids);
+#define HPC_ROUTING_PREP(VEC, W)                                                                                       \
+  do {                                                                                                                 \
+    count_kernel<VEC, W><<<num_expert, W * 64, 0, stream>>>(ids, n, first, static_cast<int*>(seqlens));                \
+    HPC_CHECK_LAUNCH();                                                                                                \
+    slot_kernel<VEC, W><<<num_expert, W * 64, 0, stream>>>(                                                            \
+        ids, n, num_topk, first, num_expert, tile_m, static_cast<const int*>(seqlens), static_cast<int*>(cu_seqlens),  \
+        static_cast<int*>(tiles), static_cast<int*>(cu_tiles), static_cast<int*>(topk_pos), static_cast<int*>(row_index)); \
+  } while (0)
+  if (vec && wide) HPC_ROUTING_PREP(true, 16);
+  else if (vec) HPC_ROUTING_PREP(true, 4);
+  else if (wide) HPC_ROUTING_PREP(false, 16);
+  else HPC_ROUTING_PREP(false, 4);
+#undef HPC_ROUTING_PREP
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }

@@ -200,20 +200,28 @@ def test_fused_activation_epilogue(num_tokens, num_expert, num_topk, hidden, int
 
 
 @pytest.mark.gpu
-def test_moe_routing_is_bit_exact():
+@pytest.mark.parametrize("T,k,E,rank,size_ep,misalign", [(333, 8, 128, 1, 4, 0), (4096, 8, 64, 0, 1, 0), (7, 3, 8, 0, 1, 0),
+                                                         (1, 1, 4, 1, 2, 0), (1021, 5, 32, 1, 2, 0), (333, 8, 128, 3, 4, 1),
+                                                         (259, 7, 16, 0, 1, 3), (1023, 5, 32, 0, 1, 2), (819, 5, 32, 1, 2, 0)])
+def test_moe_routing_is_bit_exact(T, k, E, rank, size_ep, misalign):
     """routing indices must be bit-exact (BASELINE north_star): compare the device prep with the
-    oracle's stable slotting through the C-ABI."""
+    oracle's stable slotting through the C-ABI.  Round 5 (16-byte id loads, one quarter of the id array per wave):
+    entry counts that are no multiple of 4 / 16 / 1024, a single entry, configs[3]'s 32768 entries, and an id array that
+    starts 4 / 8 / 12 bytes past a 16-byte boundary (the kernels fall back to 4-byte loads); from 4096 entries on the kernels
+    run 16 waves per expert instead of 4 (4095 = 819 x 5 is the last count below)."""
     import hpc  # noqa: F401
     from hpc import _C
     from oracle import fuse_moe as omoe
 
     torch.manual_seed(3)
-    T, k, E, rank, size_ep = 333, 8, 128, 1, 4
     el = E // size_ep
     ids = torch.sort(torch.multinomial(torch.ones((T, E)), k, replacement=False).to(torch.int32), dim=1)[0]
     x = torch.zeros((T, 128)).to(F8)
     _, _, pos_ref, cnt_ref, cu_ref = omoe.gather_expert_inputs(x, torch.zeros(T, 1), ids, el, rank)
-    d = ids.cuda()
+    buf = torch.empty(T * k + 4, dtype=torch.int32, device="cuda")
+    d = buf[misalign:misalign + T * k].view(T, k)
+    d.copy_(ids)
+    assert d.data_ptr() % 16 == 4 * misalign
     i32 = dict(dtype=torch.int32, device="cuda")
     seqlens, cu = torch.empty(el, **i32), torch.empty(el + 1, **i32)
     tiles, cut = torch.empty(el, **i32), torch.empty(el + 1, **i32)
