@@ -32,6 +32,7 @@ struct Args {
   int use_bf16_mul = 0;
   int no_half_tile = 0;  // development (key 21): 1 = the 256 x 256 kernel runs its full body only, 2 = no tail body (<= 64 rows)
   int nt_single = 1;     // 256 x 256 kernel, tail body: non-temporal weight loads for a group's ONLY (<= 64-row) token tile
+  int tail_regs = 0;     // development (key 26): 1 = the register-streamed tail body instead of the LDS-ring one
   int item_order = 0;    // 256 x 256 kernel: 0 = tail tiles in place, 1 = full tiles first, tail tiles last (group_gemm_p8.hip::locate_item)
   void* prof = nullptr;  // development: s_memtime log of the 256 x 256 kernel's section boundaries (hpc_dev_p8_prof_buffer)
 };

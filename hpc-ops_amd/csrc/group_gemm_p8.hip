@@ -57,6 +57,12 @@ constexpr int kTXOff = kTWOff + 8 * kTW * 4096;      // [2 chunk buffers][kTW sl
 constexpr int kTSOff = kTXOff + 2 * kTW * 8192;      // [2][kTW][64 floats]
 constexpr int kTDummy = kTSOff + 2 * kTW * 256;      // 256 B nobody reads (idle waves' scale DMA)
 constexpr int kLdsTail = kTDummy + 256;
+// the register-streamed tail body (p8_tail_body_r): no weights in LDS at all - two chunk buffers of token slabs and their scales
+constexpr int kTR = 6;                               // k-slabs of a token chunk = register stages of the weight stream
+constexpr int kRXOff = 0;                            // [2 chunk buffers][kTR slabs][64 token rows x 128 B]
+constexpr int kRSOff = kRXOff + 2 * kTR * 8192;      // [2][kTR][64 floats]
+constexpr int kRDummy = kRSOff + 2 * kTR * 256;
+static_assert(kRDummy + 256 <= kLdsTail, "the register-streamed tail body fits the tail body's LDS");
 constexpr int kLds = kLdsTail > kLdsMain ? kLdsTail : kLdsMain;
 static_assert(kLds <= 160 * 1024, "one workgroup per CU");
 
@@ -1059,6 +1065,245 @@ __device__ __forceinline__ void p8_tail_body(const Args& a, uint8_t* s_mem, int 
   tail_finish<kHasXs, kAct>(a, s_mem, tot, ws_row, mt0, n0, m_cnt, m0);
 }
 
+// DEVELOPMENT VARIANT (key 26 = 1; not in the shipped library): the tail body with the weights streamed THROUGH REGISTERS.
+// Question it answers: is a tail tile - ~32 us for the 32 k-tiles of the MoE's gate-up GEMM, 3 times what its 8 MFMAs per
+// wave and k-tile need - slow because the LDS-ring body above keeps too little in flight (two k-tiles of weights, the next
+// three k-tiles of tokens)?  Nothing in a tail tile shares weights between waves, so here a lane loads exactly its MFMA A
+// operand - chunks g and g + 4 of row r of a 16-row block, two 16-byte loads - into one of SIX register stages, five
+// k-tiles ahead (20 KB per wave, 160 KB per CU in flight instead of 64), and the LDS the rings leave free holds token
+// chunks of SIX k-slabs, fetched a whole chunk ahead, one barrier per six k-tiles.  Bit-identical results.
+// Answer (profiles/round5_moe_tail_body_ab.txt): no.  Routed sizes of the MoE 2 955 / 1 463 us against 2 922-2 946 /
+// 1 455-1 461 with the rings; 320 rows per expert 2 245 / 1 068 against 2 268 / 1 140; 64 rows per expert (every tile a
+// tail, the whole chip streaming) 1 350-1 400 / 673-690 against 1 105 / 574: the rings' LDS-DMA moves full 128-byte lines,
+// the operand-shaped loads 64-byte halves.  Either way a CU pulls ~45 GB/s here: what is in flight per CU is capped below
+// what either body asks for (~64 KB at ~1.4 us), so a tail tile costs its bytes - 1 MB of weights nobody shares with
+// it + 256 KB of tokens = ~28 us - whatever the depth of the software pipeline.  Tails are a bandwidth-per-CU cost.
+//   * loads are inline asm and counted by hand; VMEM order per k-tile T (s = T % 6): [s = 0, behind the wait and the
+//     barrier: token chunk T / 6 + 1 (6 slabs + scales)] then [W(T + 5) x 4].  The wait in front of k-tile T leaves in
+//     flight: W(T + 1 ... T + 4) = 16, plus the chunk issued in k-tile T - s when s = 1 ... 4 (the chunk a k-tile opens
+//     is older than its own W: no extra wait at s = 0).
+template <bool kNt>
+__device__ __forceinline__ void ld_w2(u32x4& c0, u32x4& c1, unsigned voff, unsigned voff1, i32x4 rs, int soff) {
+  // chunk g at voff, chunk g + 4 at voff1 (= voff + 64, or out of range for the half k-tile of K % 128 == 64)
+  if constexpr (kNt)
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %4, %5 offen nt\n\tbuffer_load_dwordx4 %1, %3, %4, %5 offen nt"
+                 : "=&v"(c0), "=&v"(c1) : "v"(voff), "v"(voff1), "s"(rs), "s"(soff));
+  else
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %4, %5 offen\n\tbuffer_load_dwordx4 %1, %3, %4, %5 offen"
+                 : "=&v"(c0), "=&v"(c1) : "v"(voff), "v"(voff1), "s"(rs), "s"(soff));
+}
+template <int N>
+__device__ __forceinline__ void wait_w(u32x4 (&w)[2][2]) {  // at most N VMEM operations outstanding; makes this stage valid
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]) : "n"(N));
+}
+
+template <bool kHasXs, bool kAct, bool kKTail, bool kNt>
+__device__ __forceinline__ void p8_tail_body_r(const Args& a, uint8_t* s_mem, int e, int mt0, int n0, int m_cnt, int m0) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int K = a.K, KB = a.KB;
+  const int inter = a.N >> 1;  // kAct only
+  const int col0 = n0 >> 1;    // kAct only: first activation column of the tile
+  const int p_row = lane >> 3, p_chunk = (lane & 7) ^ (lane >> 3);
+
+  // ---- weights: this lane's operand bytes of row block i: row wrow0 + 16 i + r16, chunks g4 and g4 + 4 -----------------
+  const int wrow0 = kAct ? (wave >> 2) * inter + col0 + (wave & 3) * 32 : n0 + wave * 32;  // first weight row (in the group)
+  const uint8_t* wsrc = a.w + static_cast<long>(e) * a.N * K;
+  const unsigned w_bytes = static_cast<unsigned>(a.N) * static_cast<unsigned>(K);
+  const uint64_t wbase = reinterpret_cast<uint64_t>(wsrc);
+  const int w_lo = __builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(wbase)));
+  const int w_hi = __builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(wbase >> 32)));
+  unsigned w_voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) w_voff[i] = static_cast<unsigned>(wrow0 + i * 16 + r16) * static_cast<unsigned>(K) + g4 * 16;
+  u32x4 wr[6][2][2];  // [stage][row block][chunk g4 / g4 + 4]
+  auto ld_w = [&](int T, auto stage) {
+    constexpr int kS = decltype(stage)::value;
+    const int koff = T * kBK;
+    const i32x4 rs = i32x4{w_lo, w_hi, __builtin_amdgcn_readfirstlane(T < KB ? static_cast<int>(w_bytes) : 0), 0x00020000};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned v1 = w_voff[i] + 64;
+      if constexpr (kKTail) v1 = koff + 64 + g4 * 16 < K ? v1 : 0xffffff00u;
+      ld_w2<kNt>(wr[kS][i][0], wr[kS][i][1], w_voff[i], v1, rs, koff);
+    }
+  };
+
+  // ---- tokens (LDS-DMA, as in the LDS-ring tail body) ---------------------------------------------------------------------
+  unsigned x_voff;
+  {
+    const int slot = mt0 + wave * 8 + p_row;
+    const int sc = slot < m_cnt ? slot : m_cnt - 1;
+    const int xrow = a.row_index ? a.row_index[m0 + sc] : m0 + sc;
+    x_voff = static_cast<unsigned>(xrow) * static_cast<unsigned>(K) + p_chunk * 16;
+  }
+  auto dma_x = [&](int T, auto buf, auto slab) {  // this wave's 8 token rows of k-tile T -> chunk buffer, slab
+    constexpr int kP = decltype(buf)::value, kT = decltype(slab)::value;
+    const int koff = T * kBK;
+    const auto rx = make_rsrc(a.x, T < KB ? a.x_bytes : 0u);
+    const bool k_ok = !kKTail || koff + p_chunk * 16 < K;
+    uint8_t* dst = s_mem + kRXOff + (kP * kTR + kT) * 8192 + wave * 1024;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)dst, 16, k_ok ? x_voff : 0xffffff00u, koff, 0, 0);
+  };
+  unsigned xs_voff = 0;
+  if constexpr (kHasXs) {
+    const int slot = mt0 + lane;
+    const int sc = slot < m_cnt ? slot : m_cnt - 1;
+    const long cb = a.col_base ? static_cast<long>(as_const(a.col_base)[e]) * a.tile_m : 0;
+    const long term = a.col_base ? cb + sc : static_cast<long>(a.row_index ? a.row_index[m0 + sc] : m0 + sc);
+    xs_voff = static_cast<unsigned>(term * a.xs_row_stride * 4);
+  }
+  const int xs_kb_bytes = static_cast<int>(a.xs_kb_stride * 4);
+  const unsigned xs_nrec = __builtin_amdgcn_readfirstlane(wave < kTR ? 0xffffffffu : 0u);
+  auto dma_xs = [&](int chunk, auto buf) {  // every wave issues one piece per chunk (equal vmcnt counts); wave t < kTR fetches slab t's scales
+    constexpr int kP = decltype(buf)::value;
+    if constexpr (kHasXs) {
+      const int T = chunk * kTR + wave;
+      const auto rs = make_rsrc(a.xs, T < KB ? xs_nrec : 0u);
+      uint8_t* dst = s_mem + (wave < kTR ? kRSOff + (kP * kTR + wave) * 256 : kRDummy);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 4, xs_voff, T * xs_kb_bytes, 0, 0);
+    }
+  };
+  const cint_ptr ws_row = as_const(reinterpret_cast<const int*>(a.ws)) + static_cast<long>(e) * a.ws_group_stride +
+                          ((kAct ? (wave >> 2) * inter + col0 : n0 + wave * 32) >> 7) * a.ws_ntile_stride;
+
+  f32x4 tot[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  int b_rd[2], xs_rd;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    b_rd[c] = kRXOff + r16 * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);  // + (buffer * kTR + slab) * 8192 + j * 2048
+    asm volatile("" : "+v"(b_rd[c]));
+  }
+  xs_rd = kRSOff + r16 * 4;  // + (buffer * kTR + slab) * 256 + j * 64
+  asm volatile("" : "+v"(xs_rd));
+
+  // ---- prologue, in the order the loop would have issued it: chunk 0 | W(0) ... W(4) -------------------------------------
+  constexpr int kNx = kTR + (kHasXs ? 1 : 0);  // pieces of a token chunk per wave
+  dma_x(0, IntC<0>{}, IntC<0>{});
+  dma_x(1, IntC<0>{}, IntC<1>{});
+  dma_x(2, IntC<0>{}, IntC<2>{});
+  dma_x(3, IntC<0>{}, IntC<3>{});
+  dma_x(4, IntC<0>{}, IntC<4>{});
+  dma_x(5, IntC<0>{}, IntC<5>{});
+  dma_xs(0, IntC<0>{});
+  ld_w(0, IntC<0>{});
+  ld_w(1, IntC<1>{});
+  ld_w(2, IntC<2>{});
+  ld_w(3, IntC<3>{});
+  ld_w(4, IntC<4>{});
+  __builtin_amdgcn_sched_barrier(0);
+
+  f32x4 pend[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+  float fpend[4] = {0.f, 0.f, 0.f, 0.f};
+  auto k_tile = [&](int T, auto sc_, auto pc) {
+    constexpr int kS = decltype(sc_)::value, kP = decltype(pc)::value;  // register stage = slab of the chunk; chunk buffer
+    constexpr int kQ = kS;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (kS == 0) {
+      wait_w<16>(wr[kS]);                 // W(T) landed - and this chunk's slabs (mine), issued six k-tiles ago
+      __builtin_amdgcn_s_barrier();       // everybody's slabs landed; everybody is done with the other buffer
+      __builtin_amdgcn_sched_barrier(0);
+      dma_x(T + 6, IntC<1 - kP>{}, IntC<0>{});
+      dma_x(T + 7, IntC<1 - kP>{}, IntC<1>{});
+      dma_x(T + 8, IntC<1 - kP>{}, IntC<2>{});
+      dma_x(T + 9, IntC<1 - kP>{}, IntC<3>{});
+      dma_x(T + 10, IntC<1 - kP>{}, IntC<4>{});
+      dma_x(T + 11, IntC<1 - kP>{}, IntC<5>{});
+      dma_xs(T / kTR + 1, IntC<1 - kP>{});
+    } else if constexpr (kS <= 4) {
+      wait_w<16 + kNx>(wr[kS]);           // the chunk issued in k-tile T - s is younger than W(T)
+    } else {
+      wait_w<16>(wr[kS]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    ld_w(T + 5, IntC<(kS + 5) % 6>{});
+    __builtin_amdgcn_sched_barrier(0);
+    u32x4 bf[4][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) bf[j][c] = *reinterpret_cast<const u32x4*>(s_mem + b_rd[c] + (kP * kTR + kQ) * 8192 + j * 2048);
+    float f[4] = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (kHasXs) {
+      const float wsk = __int_as_float(ws_row[T * a.ws_kb_stride]);
+      float xsv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xsv[j] = *reinterpret_cast<const float*>(s_mem + xs_rd + (kP * kTR + kQ) * 256 + j * 64);
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) f[j] = wsk * xsv[j];
+    } else {
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 pv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const int i = n >> 2, j = n & 3;
+      const i32x8 av = {static_cast<int>(wr[kS][i][0][0]), static_cast<int>(wr[kS][i][0][1]), static_cast<int>(wr[kS][i][0][2]),
+                        static_cast<int>(wr[kS][i][0][3]), static_cast<int>(wr[kS][i][1][0]), static_cast<int>(wr[kS][i][1][1]),
+                        static_cast<int>(wr[kS][i][1][2]), static_cast<int>(wr[kS][i][1][3])};
+      const i32x8 bv = {static_cast<int>(bf[j][0][0]), static_cast<int>(bf[j][0][1]), static_cast<int>(bf[j][0][2]),
+                        static_cast<int>(bf[j][0][3]), static_cast<int>(bf[j][1][0]), static_cast<int>(bf[j][1][1]),
+                        static_cast<int>(bf[j][1][2]), static_cast<int>(bf[j][1][3])};
+      if constexpr (kHasXs) {
+        const f32x4 part = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (n >= 2) {
+          const int pi = (n - 2) >> 2, pj = (n - 2) & 3;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tot[pi][pj][r] = fmaf(pv[1][r], f[pj], tot[pi][pj][r]);
+        } else {  // blocks 6, 7 of the previous k-tile, under its scales
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tot[1][2 + n][r] = fmaf(pend[n][r], fpend[2 + n], tot[1][2 + n][r]);
+        }
+        pv[1] = pv[0];
+        pv[0] = part;
+      } else {
+        tot[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, tot[i][j], 0, 0, 0, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (kHasXs) {
+      pend[0] = pv[1];
+      pend[1] = pv[0];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fpend[j] = f[j];
+    }
+  };
+  for (int kb = 0; kb < KB; kb += 2 * kTR) {
+    k_tile(kb, IntC<0>{}, IntC<0>{});
+    if (kb + 1 < KB) k_tile(kb + 1, IntC<1>{}, IntC<0>{});
+    if (kb + 2 < KB) k_tile(kb + 2, IntC<2>{}, IntC<0>{});
+    if (kb + 3 < KB) k_tile(kb + 3, IntC<3>{}, IntC<0>{});
+    if (kb + 4 < KB) k_tile(kb + 4, IntC<4>{}, IntC<0>{});
+    if (kb + 5 < KB) k_tile(kb + 5, IntC<5>{}, IntC<0>{});
+    if (kb + 6 < KB) k_tile(kb + 6, IntC<0>{}, IntC<1>{});
+    if (kb + 7 < KB) k_tile(kb + 7, IntC<1>{}, IntC<1>{});
+    if (kb + 8 < KB) k_tile(kb + 8, IntC<2>{}, IntC<1>{});
+    if (kb + 9 < KB) k_tile(kb + 9, IntC<3>{}, IntC<1>{});
+    if (kb + 10 < KB) k_tile(kb + 10, IntC<4>{}, IntC<1>{});
+    if (kb + 11 < KB) k_tile(kb + 11, IntC<5>{}, IntC<1>{});
+  }
+  if constexpr (kHasXs) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tot[1][2 + t][r] = fmaf(pend[t][r], fpend[2 + t], tot[1][2 + t][r]);
+  }
+  // drain: the (empty) loads past the last k-tile still write their stage registers and the chunk buffers
+#pragma unroll
+  for (int st = 0; st < 6; ++st) wait_w<0>(wr[st]);
+
+  tail_finish<kHasXs, kAct>(a, s_mem, tot, ws_row, mt0, n0, m_cnt, m0);
+}
+
 template <class Cfg, bool kHasXs, bool kNoDma = false, bool kAct = false, bool kKTail = false>
 __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, const int* __restrict__ cu_tiles,
                                                                   int num_group) {
@@ -1074,9 +1319,16 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   const int n0 = __builtin_amdgcn_readfirstlane(it.wt) * kBN;
   // a group's last token tile: <= 64 rows the tail body, <= 128 rows the half-tile body (development key 21 = 1: neither,
   // 2: no tail body)
-  if (m_cnt <= 64 && a.no_half_tile == 0 && !kNoDma && a.nt_single)
+  // (development key 26 = 1: the register-streamed tail body instead of the LDS-ring one - development build only)
+  const bool tail = m_cnt - mt0 <= 64 && a.no_half_tile == 0 && !kNoDma;
+  const bool single = m_cnt <= 64 && a.nt_single;
+  if (kHpcDevBuild && tail && a.tail_regs && single)
+    p8_tail_body_r<kHasXs, kAct, kKTail, true>(a, s_mem, e, mt0, n0, m_cnt, m0);
+  else if (kHpcDevBuild && tail && a.tail_regs)
+    p8_tail_body_r<kHasXs, kAct, kKTail, false>(a, s_mem, e, mt0, n0, m_cnt, m0);
+  else if (tail && single)
     p8_tail_body<kHasXs, kAct, kKTail, true>(a, s_mem, e, mt0, n0, m_cnt, m0);
-  else if (m_cnt - mt0 <= 64 && a.no_half_tile == 0 && !kNoDma)
+  else if (tail)
     p8_tail_body<kHasXs, kAct, kKTail, false>(a, s_mem, e, mt0, n0, m_cnt, m0);
   else if (m_cnt - mt0 <= 128 && a.no_half_tile != 1)
     p8_body<Cfg, kHasXs, kNoDma, kAct, true, kKTail>(a, s_mem, e, mt0, n0, m_cnt, m0);
@@ -1117,6 +1369,7 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int n
   // was built, bit-identical, and measured no faster: T = 256 1 515-1 563 against 1 505-1 512 us, profiles/
   // round5_moe_kernel_choice.txt; the stream is not bound by the bytes in flight at that point.  Removed.)
   a.nt_single = hpc_dev_tuning_get(24) != 1;
+  a.tail_regs = hpc_dev_tuning_get(26) == 1;
   if (n % kBN || a.K < kBK) return HPC_ERR_UNSUPPORTED;
   const long max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 256)
   const long items = max_tiles * (n / kBN) + 16;  // + 16: the per-XCD chunks of the full and of the tail tiles round up

@@ -30,6 +30,8 @@
 //   key 21 256x256 grouped GEMM: 1 = never the half-tile / tail body for a group's last token tile, 2 = no tail body (<= 64 rows)
 //   key 22 256x256 grouped GEMM, blockwise: variant of the k-loop (group_gemm_p8.hip: 1 section profile, 2 the round-4 loop
 //          (tails behind the barrier), 3 its profile, 4 no s_setprio)
+//   key 26 256x256 grouped GEMM: 1 = the register-streamed tail body (weights global -> MFMA operand registers, six stages)
+//          instead of the LDS-ring one (measured: no faster - a tail tile costs its bytes at the per-CU bandwidth)
 //   key 25 grouped GEMM kernel choice: 1 = the 256 x 256 kernel only from 192 rows per group on (rounds 2-4)
 //   key 24 256x256 grouped GEMM, tail body: 1 = default cache policy instead of non-temporal weight loads for single-tile groups
 //   key 23 256x256 grouped GEMM: 1 = all full tiles first, tail tiles last (measured slower than tails in place)

@@ -393,7 +393,8 @@ def test_group_gemm_blockwise_many_groups(tiled_mode, num_group):
 def test_group_gemm_tail_body_is_bit_identical(n, k):                      # than the rings' period of 6 k-tiles
     """A group's last token tile with <= 64 rows runs the TAIL body of the 256 x 256 kernel (round 5: per-wave weight
     rings, 64-token chunks of three k-slabs, one barrier per three k-tiles; a group's ONLY tile - every third group here -
-    with non-temporal weight loads).  Same operand conventions and the same
+    with non-temporal weight loads; development key 26 = 1: the variant that streams the weights through six register
+    stages, five k-tiles ahead, with token chunks of six k-slabs).  Same operand conventions and the same
     arithmetic order as the full / half-tile bodies, so the output must be BIT-IDENTICAL to the round-4 dispatch
     (development key 21 = 2: tails on the half-tile body) - groups of every tail size 1 ... 64 next to 65, 128, 129 and
     empty groups, blockwise scales of either sign; and within the reference tolerance of the oracle."""
@@ -422,14 +423,18 @@ def test_group_gemm_tail_body_is_bit_identical(n, k):                      # tha
     outs = {}
     dev_set(3, 4)  # the 256 x 256 kernel
     try:
-        for key in (2, 0, 1):  # half-tile body for the tails / tail body (the product) / full body only
-            dev_set(21, key)
+        # half-tile body for the tails / tail body (the product: weights through per-wave LDS rings) / full body only /
+        # the register-streamed tail body (development key 26 = 1)
+        for key in (2, 0, 1, "regs"):
+            dev_set(21, 0 if key == "regs" else key)
+            dev_set(26, 1 if key == "regs" else 0)
             outs[key] = hpc.group_gemm_blockwise_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), xs_t.cuda(), wscale.cuda(),
                                                      num_seq_per_group_avg=avg).cpu()
     finally:
         dev_set(21, 0)
+        dev_set(26, 0)
         dev_set(3, 0)
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs["regs"])
     assert allclose(gt.float(), outs[0].float(), rtol=0.01, atol=0.02)
 
 
@@ -453,13 +458,15 @@ def test_fuse_moe_blockwise_tail_body_is_bit_identical(num_tokens, hidden, inter
     outs = {}
     dev_set(3, 4)
     try:
-        for key in (2, 0):
-            dev_set(21, key)
+        for key in (2, 0, "regs"):
+            dev_set(21, 0 if key == "regs" else key)
+            dev_set(26, 1 if key == "regs" else 0)
             outs[key] = hpc.fuse_moe_blockwise_fp8(*dev, 0, num_expert).cpu()
     finally:
         dev_set(21, 0)
+        dev_set(26, 0)
         dev_set(3, 0)
-    assert torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs["regs"])
     assert allclose(gt.float(), outs[0].float(), rtol=0.01, atol=0.01)
 
 

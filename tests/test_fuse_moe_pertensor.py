@@ -103,13 +103,15 @@ def test_fuse_moe_pertensor_tail_body_is_bit_identical(use_bf16_mul, num_seq, hi
     outs = {}
     dev_set(3, 4)
     try:
-        for key in (2, 0):
-            dev_set(21, key)
+        for key in (2, 0, "regs"):  # half-tile body / tail body (the product) / register-streamed tail body (development variant)
+            dev_set(21, 0 if key == "regs" else key)
+            dev_set(26, 1 if key == "regs" else 0)
             outs[key] = run()
     finally:
         dev_set(21, 0)
+        dev_set(26, 0)
         dev_set(3, 0)
-    assert torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs["regs"])
     assert allclose(gt.float(), outs[0].float(), rtol=0.08, atol=0.1)
 
 

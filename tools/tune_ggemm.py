@@ -11,6 +11,7 @@ sys.path.insert(0, str(ROOT / "hpc-ops_amd")); sys.path.insert(0, str(ROOT))
 import torch, bench, hpc
 from hpc import _C
 dev = torch.device("cuda", 0)
+NO_GRAPH = bool(os.environ.get("HPC_NO_GRAPH"))  # plain launches: rocprofv3 --pmc attributes counters per dispatch
 PT = "--pertensor" in sys.argv
 if PT: sys.argv.remove("--pertensor")
 ROWS = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--rows=")]  # extra cases: N rows in every group
@@ -50,7 +51,7 @@ for cfg in (sys.argv[1:] or ["3=2", "3=4"]):
     for k, v in pairs: _C.lib.hpc_dev_tuning_set(k, v)
     for nm, fn, fl, out in cases:
         out.zero_()
-        us = bench.timed(fn, iters=10, warm=3, graph=True)
+        us = bench.timed(fn, iters=3 if NO_GRAPH else 10, warm=1 if NO_GRAPH else 3, graph=not NO_GRAPH)
         torch.cuda.synchronize()
         if nm not in first:  # every configuration must reproduce the first one's output (same arithmetic, other schedule)
             first[nm] = out.clone()
