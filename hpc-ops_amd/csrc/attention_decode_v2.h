@@ -28,6 +28,9 @@ struct Args {
   int pair_wgs[4];  // fp8, 4 head pairs: workgroups (= ranges) per pair, [0] = 0: equal shares
   int big_pct;      // > 100: ranges of the first half of the grid are this many percent of the others' length
   int dev_nomem;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing; results are wrong)
+  int pair_xor;   // workgroups from mate_from on (the SECOND workgroup of every CU) serve head pair p ^ pair_xor: a CU's two
+  int mate_from;  // workgroups stream slices of the token rows that differ in byte-address bit 9 (see the kernel); 0 = off
+  int dev_slice;  // development key 37 = s + 1: every workgroup streams slice s of the token rows (timing only; results are wrong)
   long k_block_stride, k_token_stride;  // bytes
   long v_block_stride, v_token_stride;
   long ks_block_stride, ks_row_stride, ks_head_stride;  // bytes

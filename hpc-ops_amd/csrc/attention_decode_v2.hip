@@ -45,6 +45,9 @@
 //    call's scratch: a fixed 64 KB region that must be zero on first use and is left zero by every call (one
 //    atomic add per arrival; round 2 tagged them with a launch epoch instead of requiring zeros, which cost a
 //    second round trip per split task and could misread stale words).  Two workgroups per CU.
+//  * a CU's two workgroups stream DIFFERENT slices of the token rows: workgroups from #CUs on serve head pair p ^ mask, the
+//    slice across byte-address bit 9 from their CU mate's (round 5: +4-6 % on every fp8 shape with >= 4 pairs, +1-2.5 % bf16;
+//    profiles/round5_decode_pair_map_ab.txt).
 //  * fp8 numerics as in the first generation / the reference kernels.
 #include <atomic>
 #include <type_traits>
@@ -259,6 +262,13 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   int nrange = nwg / npair;
   int rng = wg / npair;
   int pr = wg % npair;  // this workgroup's head pair
+  // A CU's two workgroups on DIFFERENT slices.  Measured (profiles/round5_decode_pair_map_ab.txt): when the second workgroup of
+  // every CU (the dispatcher hands out workgroups in index order, one per CU, then the second ones) streams the slice whose
+  // byte offset differs in address bit 9 from the first one's, the whole launch runs 4-6 % faster (C3 mix 141 -> 133-137 us,
+  // uniform 8k 180 -> 175 us, every box); mates on the same slice (today's kernel until round 5), slices that differ in bit 8, or
+  // an XCD that serves all four slices are all slower.  Every workgroup that streams alone on a slice runs as fast as any
+  // other (development key 37), so this is not a property of the memory channels behind a slice.
+  if (a.mate_from > 0 && wg >= a.mate_from) pr ^= a.pair_xor;
   int lwg = wg;         // logical workgroup index: partial slots are addressed by (slice offset + range)
   int lwg0 = pr * nrange;  // first logical index of this slice
   if (a.pair_wgs[0] > 0 && npair == 4) {
@@ -412,8 +422,9 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   const int v_voff0 = static_cast<int>((in0 + lane / kCpr) * v_rs) + lane_off, v_voff1 = static_cast<int>((in1 + lane / kCpr) * v_rs) + lane_off;
   const int ks1 = sgpr(kRpi * k_rs), ks2 = sgpr(2 * kRpi * k_rs), ks3 = sgpr(3 * kRpi * k_rs);
   const int vs1 = sgpr(kRpi * v_rs), vs2 = sgpr(2 * kRpi * v_rs), vs3 = sgpr(3 * kRpi * v_rs);
-  const uint64_t kbase_h = reinterpret_cast<uint64_t>(a.kcache) + static_cast<uint64_t>(pr) * kRowB;
-  const uint64_t vbase_h = reinterpret_cast<uint64_t>(a.vcache) + static_cast<uint64_t>(pr) * kRowB;
+  const int mem_slice = a.dev_slice > 0 ? a.dev_slice - 1 : pr;
+  const uint64_t kbase_h = reinterpret_cast<uint64_t>(a.kcache) + static_cast<uint64_t>(mem_slice) * kRowB;
+  const uint64_t vbase_h = reinterpret_cast<uint64_t>(a.vcache) + static_cast<uint64_t>(mem_slice) * kRowB;
   const uint32_t kbs = static_cast<uint32_t>(a.k_block_stride), vbs = static_cast<uint32_t>(a.v_block_stride);  // < 4 GB (eligible())
   const bool mem = a.dev_nomem == 0;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing)
   i32x4 dk0, dk1, dv0, dv1;  // descriptors of the WI being issued
@@ -1159,6 +1170,24 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
   a.part_lse = reinterpret_cast<float*>(ws);
   a.arrive = static_cast<int*>(counters);
   const bool temporal = hpc_dev_tuning_get(0) == 1;
+  a.dev_slice = hpc_dev_tuning_get(37);
+  // the second workgroup of every CU on the slice across address bit 9 (see the kernel): slices of 256 B (fp8 pairs) -> pair
+  // index bit 1, of 512 B (bf16 pairs, fp8 quads) -> bit 0.  Measured per shape (profiles/round5_decode_pair_map_ab.txt):
+  // fp8 8 / 64 heads +4-6 %, 16 / 128 heads +4 % (bit 8: +2 %, bit 10: 0), bf16 8 / 64 +1-2.5 % (bit 10: 0); with two pairs
+  // (4 kv heads, fp8) only bit 8 exists: +2 % on the length mix, +-1 % on uniform lengths - taken.  Needs a power-of-two pair
+  // count that holds the bit, more than one workgroup per CU, whole rows of pairs in front of the second workgroups, equal
+  // shares.  Development key 36 = mask + 1 overrides the mask (1 = off: both workgroups of a CU on the same slice).
+  {
+    int dev = 0;
+    const int npair = a.num_head_kv / (mode == 2 ? 4 : 2);
+    const int cus = hipGetDevice(&dev) == hipSuccess ? hpc_get_cu_count(dev) : 0;
+    const int k36 = hpc_dev_tuning_get(36);
+    int mask = (a.bf16 || mode == 2 || npair == 2) ? 1 : 2;
+    if (k36 > 0) mask = k36 - 1;
+    const bool ok = cus > 0 && num_wg > cus && (npair & (npair - 1)) == 0 && mask > 0 && mask < npair && cus % npair == 0;
+    a.pair_xor = ok ? mask : 0;
+    a.mate_from = ok ? cus : 0;
+  }
   // Unequal shares for the four 256-byte slices of an 8-kv-head fp8 row (see the kernel): slice 1 gets d1 more
   // workgroups than the even share, slice 3 d3, slices 0 and 2 give them up.  Off by default: measured +3 % on the C3 mix
   // at d1 = 12 of 128 and nothing on uniform 8k (where the even split puts exactly one request half on every
@@ -1173,6 +1202,7 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
       a.pair_wgs[0] = even - g0, a.pair_wgs[1] = even + d1, a.pair_wgs[2] = even - g2, a.pair_wgs[3] = even + d3;
     }
   }
+  if (a.pair_wgs[0] > 0) a.pair_xor = a.mate_from = 0;  // unequal shares (development) re-map the tail of the grid themselves
   // longer ranges for the first workgroup of every CU (see the kernel): only when the grid is exactly two workgroups
   // per CU, so that "first half of the grid" means "first on its CU".  Development key 32: percentage (0 = off).
   // Measured: no gain at 108 / 115 / 122 % (C3 mix 139.7 / 139.0 / 138.4 us vs 139.3 us) - when a CU's first workgroup

@@ -39,6 +39,9 @@
 //   key 34 decode scheduler: bin count override (<= 4 per CU)
 //   key 35 low-latency all-reduce: 1 = always two launches, 2 = one launch whenever the grid is resident at once
 //          (default: one launch up to one workgroup per CU)
+//   key 36 decode v2: head pair of the SECOND workgroup of every CU = pair ^ (value - 1) (0 = the product's rule: the slice across
+//          byte-address bit 9; 1 = off, both workgroups of a CU on the same slice)
+//   key 37 decode v2: value = s + 1: every workgroup streams slice s of the token rows (timing only - wrong results)
 //   others: see the launchers that read them
 #pragma once
 

@@ -40,6 +40,8 @@ def run(name, lens_c, nomem):
     if DUMP:
         torch.save(buf.cpu().view(NWG * 4, 12).clone(), str(ROOT / "gpurun_out" / f"prof_{name}_nomem{int(nomem)}_map{MAP}.pt"))
     t = buf.cpu().view(NWG * 4, 12).double()
+    wg_of = (torch.arange(NWG * 4) // 4)[t[:, 9] > 0]
+    raw11 = buf.cpu().view(NWG * 4, 12)[:, 11][t[:, 9] > 0]
     t = t[t[:, 9] > 0]
     tot = t[:, 2]
     names = ["wait_k", "wait_v", "lds_write", "issue+step", "compute", "finish"]
@@ -59,6 +61,14 @@ def run(name, lens_c, nomem):
     q = torch.tensor([0.0, 0.1, 0.5, 0.9, 0.99, 1.0], dtype=torch.double)
     print("   wave start us (quantiles 0/10/50/90/99/100):", [round(float(x), 1) for x in torch.quantile(start, q)])
     print("   wave end   us (quantiles 0/10/50/90/99/100):", [round(float(x), 1) for x in torch.quantile(end, q)])
+    pair_of = raw11 & 0xff
+    for half in (0, 1):  # mean end time / us per wave-iteration by grid half (rows) and head pair (columns)
+        cells = []
+        for p_ in range(4):
+            m = ((wg_of >= NWG // 2) == bool(half)) & (pair_of == p_)
+            if m.any():
+                cells.append(f"{float(end[m].mean()):6.1f}/{float(((end - start)[m] / t[:, 9][m]).mean()):.2f}")
+        print(f"   {'second' if half else 'first '} half, pairs 0..3: end us / us per WI:", "  ".join(cells))
     clk = tot / ((r1 - r0) / 100.0).clamp_min(1e-3)  # shader cycles per us
     print(f"   shader clock seen by the waves: {clk.median():.0f} MHz")
 

@@ -33,11 +33,18 @@ for name, lens_c in cases:
     kvb = int(lens_c.sum()) * Hkv * 512
     outs = {}
     # order matters on these boxes (the first measurement after a pause runs 4-7 % faster): A B A B, read the later pair
-    for gen, key in (("first", 1), ("head_pair", 0), ("first", 1), ("head_pair", 0)):
+    plan = (("first", 1, 0), ("head_pair", 0, 0), ("first", 1, 0), ("head_pair", 0, 0))
+    if len(sys.argv) > 1:  # "36=34": head-pair kernel with and without that register, A B A B
+        rk = int(sys.argv[1].split("=")[0])
+        plan = (("head_pair", 0, 0),) + tuple((f"{rk}={v}", 0, int(v)) for v in sys.argv[1].split("=")[1].split("|")) + (("head_pair", 0, 0),)
+    for gen, key, reg in plan:
         _C.lib.hpc_dev_tuning_set(28, key)
+        if len(sys.argv) > 1: _C.lib.hpc_dev_tuning_set(rk, reg)
         us = bench.timed(lambda: hpc.attention_decode_bf16(q, k, v, bid, lens, 0, True, True, tm, None, o), graph=True, iters=30, reps=10)
         outs[gen] = o.clone()
         print(f"[{gen:>9}] bf16 {name:<15} 8/64: {us:8.1f} us {kvb / us / 1e3:8.1f} GB/s {kvb / us / 1e3 / 8000:.3f}", flush=True)
     _C.lib.hpc_dev_tuning_set(28, 0)
-    print(f"    max |head_pair - first| = {(outs['head_pair'].float() - outs['first'].float()).abs().max().item():.5f}", flush=True)
+    if len(sys.argv) > 1: _C.lib.hpc_dev_tuning_set(rk, 0)
+    ks = list(outs)
+    print(f"    max |{ks[0]} - {ks[-1]}| = {(outs[ks[0]].float() - outs[ks[-1]].float()).abs().max().item():.5f}", flush=True)
     del k, v
