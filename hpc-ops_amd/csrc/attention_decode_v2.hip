@@ -268,6 +268,11 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   // uniform 8k 180 -> 175 us, every box); mates on the same slice (today's kernel until round 5), slices that differ in bit 8, or
   // an XCD that serves all four slices are all slower.  Every workgroup that streams alone on a slice runs as fast as any
   // other (development key 37), so this is not a property of the memory channels behind a slice.
+  if (a.xcd_map != 0 && npair == 4 && (nwg & 7) == 0) {  // development: which XCD (= wg % 8) streams which slice
+    const int e = (a.xcd_map >> (3 * (wg & 7))) & 7;
+    pr = e & 3;
+    rng = (wg >> 3) * 2 + (e >> 2);
+  }
   if (a.mate_from > 0 && wg >= a.mate_from) pr ^= a.pair_xor;
   int lwg = wg;         // logical workgroup index: partial slots are addressed by (slice offset + range)
   int lwg0 = pr * nrange;  // first logical index of this slice
@@ -854,6 +859,10 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     // (round 5: s_setprio 2 around this load issue, around the whole memory phase of a wave-iteration, or s_setprio 1
     //  around its compute phase change nothing - C3 mix 140.1-141.0 us against 140.3-141.9 us, uniform 8k 185.3-185.6
     //  against 180.2-185.5 us, profiles/round5_decode_ab.txt: the waves wait for the memory pipeline, not for issue slots)
+    if constexpr (kHpcDevBuild) {  // development key 39: (in front of the load issue) throttle the workgroups of the even head pairs (the fast slices)
+      if (a.dev_sleep > 0 && !(pr & 1))
+        for (int i = 0; i < a.dev_sleep; ++i) __builtin_amdgcn_s_sleep(1);
+    }
     issue_k0();
     issue_k1();
     issue_v0();
@@ -1171,6 +1180,8 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
   a.arrive = static_cast<int*>(counters);
   const bool temporal = hpc_dev_tuning_get(0) == 1;
   a.dev_slice = hpc_dev_tuning_get(37);
+  a.xcd_map = hpc_dev_tuning_get(38);
+  a.dev_sleep = hpc_dev_tuning_get(39);
   // the second workgroup of every CU on the slice across address bit 9 (see the kernel): slices of 256 B (fp8 pairs) -> pair
   // index bit 1, of 512 B (bf16 pairs, fp8 quads) -> bit 0.  Measured per shape (profiles/round5_decode_pair_map_ab.txt):
   // fp8 8 / 64 heads +4-6 %, 16 / 128 heads +4 % (bit 8: +2 %, bit 10: 0), bf16 8 / 64 +1-2.5 % (bit 10: 0); with two pairs

@@ -15,6 +15,7 @@
 // splits in fixed order - deterministic - writes y and leaves the counter at zero for the next call
 // (same contract as the reference's split_flag).
 #include "hpc_common.h"
+#include "hpc_dev.h"
 #include "../../include/hpc_amd.h"
 
 namespace hpc {
@@ -28,6 +29,7 @@ struct Args {
   float* split_y;  // [S, m, n] fp32 (S > 1)
   int* flag;       // per-tile arrival counters, row stride flag_ld (S > 1)
   int m, n, k, splits, flag_ld, fp32_out;
+  int dev_skip;  // development key 41: bit 0 = no weight loads, bit 1 = no activation loads in the tile kernel (timing only)
   float scale;
 };
 
@@ -171,6 +173,191 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16xfp32_kernel(const Args a) 
   }
 }
 
+// ---- large m (> 256): 64 weight rows x 128 tokens per workgroup, activations staged through LDS ------------------
+// The 64 x 64 kernel above fetches every activation row four times (each of its waves loads the whole token tile into
+// MFMA operand registers) as 64-byte pieces: at m = 4096 it is bound by what the CU's load path accepts (93 us for
+// 17 GFLOP, round 1-4).  Here the activations - the big operand: m x k against 2 x n x k of weights that live in L2 - are
+// read ONCE per workgroup, 128 contiguous bytes per token row and 64-k step, into registers one step ahead, written to a
+// double-buffered LDS tile ([128 tokens][128 B], 16-byte chunks XOR-swizzled with the token index) and read from there as
+// MFMA B operands; the weight planes go straight into A-operand registers two steps ahead (a wave owns 32 weight rows x
+// 64 tokens: 8 weight + 8 activation operand reads for 32 MFMAs per step).  One barrier per step.  Split-K and its
+// last-arriver reduction as above (counters on the same [m tiles, n / 64] grid, m tiles of 128).
+__global__ __launch_bounds__(kThreads, 2) void gemm_bf16xfp32_tile_kernel(const Args a) {
+  constexpr int kTT = 128;  // tokens per workgroup
+  __shared__ u32x4 s_x[2][kTT * 8];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int wr = wave & 1, wt = wave >> 1;  // weight-row half, token half
+  const int n0 = blockIdx.x * 64, m0 = blockIdx.y * kTT, split = blockIdx.z;
+  const int K = a.k;
+  const int chunks = K >> 6;
+  const int c_begin = static_cast<int>(static_cast<long>(chunks) * split / a.splits);
+  const int c_end = static_cast<int>(static_cast<long>(chunks) * (split + 1) / a.splits);
+
+  const unsigned w_bytes = static_cast<unsigned>(a.n) * static_cast<unsigned>(K) * 2u;
+  const unsigned x_bytes = static_cast<unsigned>(a.m) * static_cast<unsigned>(K) * 2u;
+  unsigned w_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) w_off[i] = static_cast<unsigned>(n0 + wr * 32 + i * 16 + r16) * static_cast<unsigned>(K) * 2u + g4 * 16;
+  // staging: thread t carries chunk t % 8 of tokens t / 8 + 32 q
+  unsigned xg_off[4];
+  int xs_idx[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int tl = (tid >> 3) + 32 * q, t = m0 + tl;
+    xg_off[q] = static_cast<unsigned>(t < a.m ? t : a.m - 1) * static_cast<unsigned>(K) * 2u + (tid & 7) * 16;
+    xs_idx[q] = tl * 8 + ((tid & 7) ^ (tl & 7));
+  }
+  // operand reads: token wt * 64 + j * 16 + r16, chunk h * 4 + g4
+  int xr_idx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tl = wt * 64 + j * 16 + r16;
+    xr_idx[j] = tl * 8 + (g4 ^ (tl & 7));  // h = 1: ^ 4
+  }
+
+  f32x4 acc_h[2][4], acc_l[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc_h[i][j] = acc_l[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 bh[2][2][2], bl[2][2][2];  // [buffer][row block][32-k half]
+  u32x4 xr[2][4];  // staging registers: two steps of activations in flight
+  // (Measured and dropped: every workgroup starting its k walk at its own step - rows of x and of the weight planes are a
+  //  power of two apart, so workgroups in step queue at the same lines - changes nothing: 49.4 against 50.2 us.)
+  auto issue_w = [&](int buf, int c) {
+    const bool on = c < c_end;
+    const int koff = on ? c * 128 : 0;
+    const bool mem_w = on && !(a.dev_skip & 1);  // development key 41 bit 0: no weight loads (timing only)
+    const auto rh_ = make_rsrc(a.wh, mem_w ? w_bytes : 0u), rl_ = make_rsrc(a.wl, mem_w ? w_bytes : 0u);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bh[buf][i][h] = buf_ld16<0>(rh_, w_off[i], koff + h * 64);
+        bl[buf][i][h] = buf_ld16<0>(rl_, w_off[i], koff + h * 64);
+      }
+  };
+  auto load_x = [&](int rb, int c) {
+    const bool on = c < c_end;
+    const auto rx_ = make_rsrc(a.x, on && !(a.dev_skip & 2) ? x_bytes : 0u);  // development key 41 bit 1: no activation loads
+    const int koff = on ? c * 128 : 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xr[rb][q] = buf_ld16<0>(rx_, xg_off[q], koff);
+  };
+  auto stage_x = [&](int sb, int rb) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s_x[sb][xs_idx[q]] = xr[rb][q];
+  };
+  auto compute = [&](int buf, int sb) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u32x4 bx[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bx[j] = s_x[sb][xr_idx[j] ^ (h << 2)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          acc_h[i][j] = mfma_bf16(bh[buf][i][h], bx[j], acc_h[i][j]);
+          acc_l[i][j] = mfma_bf16(bl[buf][i][h], bx[j], acc_l[i][j]);
+        }
+    }
+  };
+  // Step s is loaded into staging registers xr[s & 1] three steps before it is multiplied, written to LDS buffer s & 1 one
+  // step before (that buffer was last read two steps earlier, behind a barrier); its weights go in flight two steps before.
+  load_x(0, c_begin);
+  issue_w(0, c_begin);
+  load_x(1, c_begin + 1);
+  issue_w(1, c_begin + 1);
+  stage_x(0, 0);
+  load_x(0, c_begin + 2);
+  __syncthreads();
+  for (int c = c_begin; c < c_end; c += 2) {
+    stage_x(1, 1);  // step c + 1
+    load_x(1, c + 3);
+    compute(0, 0);
+    issue_w(0, c + 2);
+    __syncthreads();
+    stage_x(0, 0);  // step c + 2
+    load_x(0, c + 4);
+    compute(1, 1);
+    issue_w(1, c + 3);
+    __syncthreads();
+  }
+
+  // lane holds weight rows nn_i + 0..3 of token column t_j
+  auto emit = [&](int t, int nn, const f32x4 v) {
+    if (a.fp32_out) {
+      *reinterpret_cast<f32x4*>(static_cast<float*>(a.y) + static_cast<long>(t) * a.n + nn) = v;
+    } else {
+      u32x2 pk;
+      pk[0] = pack_bf16x2(v[0], v[1]);
+      pk[1] = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(static_cast<uint16_t*>(a.y) + static_cast<long>(t) * a.n + nn) = pk;
+    }
+  };
+  if (a.splits == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = m0 + wt * 64 + j * 16 + r16;
+        if (t < a.m) emit(t, n0 + wr * 32 + i * 16 + g4 * 4, acc_l[i][j] * a.scale + acc_h[i][j]);
+      }
+    return;
+  }
+  const unsigned plane = static_cast<unsigned>(a.m) * static_cast<unsigned>(a.n) * 4u;
+  const auto rp = make_rsrc(a.split_y, plane * static_cast<unsigned>(a.splits));
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int t = m0 + wt * 64 + j * 16 + r16;
+      const f32x4 v = acc_l[i][j] * a.scale + acc_h[i][j];
+      if (t < a.m)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rp,
+                                               (static_cast<unsigned>(t) * a.n + n0 + wr * 32 + i * 16 + g4 * 4) * 4u, split * plane, 17);
+    }
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the write-through stores are acknowledged
+  __syncthreads();
+  int* flag = a.flag + static_cast<long>(blockIdx.y) * a.flag_ld + blockIdx.x;
+  if (tid == 0) {
+    const int old = atomicAdd(flag, 1);
+    s_last = (old == a.splits - 1);
+    if (s_last) atomicExch(flag, 0);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  constexpr int kMaxSplits = 16;
+  const auto rnull = make_rsrc(a.split_y, 0u);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j0 = 0; j0 < 4; j0 += 2) {
+      u32x4 part[2][kMaxSplits];
+      const int nn = n0 + wr * 32 + i * 16 + g4 * 4;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int t = m0 + wt * 64 + (j0 + jj) * 16 + r16;
+        const unsigned off = (static_cast<unsigned>(t < a.m ? t : 0) * a.n + nn) * 4u;
+#pragma unroll
+        for (int sp = 0; sp < kMaxSplits; ++sp) part[jj][sp] = buf_ld16<17>(sp < a.splits ? rp : rnull, off, sp * plane);
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        const int t = m0 + wt * 64 + (j0 + jj) * 16 + r16;
+        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sp = 0; sp < kMaxSplits; ++sp) sum += __builtin_bit_cast(f32x4, part[jj][sp]);
+        if (t < a.m) emit(t, nn, sum);
+      }
+    }
+}
+
 // ---- decode-size m (<= 256): skinny tiles, K split across waves AND workgroups --------------------------
 // The problem is a stream of the two weight planes (4 - 33 MB) against a few tokens: it needs every
 // CU pulling bytes (one CU sustains only ~50 GB/s), so the tile is the MFMA minimum of 16 weight rows
@@ -288,6 +475,7 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16xfp32_skinny_kernel(const A
 }
 
 constexpr int kSkinnyMaxM = 256;
+constexpr int kTileMinM = 512;  // the LDS-staged tile kernel above this many tokens (m = 512: 27.3 against 24.8 us, m = 1024: 32.4 against 36.9)
 inline int skinny_tm(int m) { return m <= 16 ? 16 : (m <= 32 ? 32 : 64); }
 
 }  // namespace rgemm
@@ -307,7 +495,8 @@ extern "C" int hpc_gemm_bf16xfp32_splits(int m, int n, int k, int use_splitk) {
     while (s < 16 && tiles * s < 256 && (k >> 6) / (s * 2) >= 4) s *= 2;
     return s;
   }
-  const long tiles = static_cast<long>((m + 63) / 64) * (n / 64);
+  // 256 < m <= 512: 64 x 64 tiles; above: the tile kernel, 64 weight rows x 128 tokens
+  const long tiles = m <= kTileMinM ? static_cast<long>((m + 63) / 64) * (n / 64) : static_cast<long>((m + 127) / 128) * (n / 64);
   while (s < 16 && tiles * s < 512 && k / (s * 2) >= 256) s *= 2;
   return s;
 }
@@ -341,6 +530,7 @@ extern "C" int hpc_gemm_bf16xfp32_async(void* y_ptr, void* splitk_y_ptr, void* s
   a.flag_ld = flag_ld;
   a.fp32_out = use_fp32_output;
   a.scale = scale;
+  a.dev_skip = hpc_dev_tuning_get(41);
   if (m <= kSkinnyMaxM) {
     const int tm = skinny_tm(m);
     dim3 grid(n / 16, (m + tm - 1) / tm, splits);
@@ -354,10 +544,21 @@ extern "C" int hpc_gemm_bf16xfp32_async(void* y_ptr, void* splitk_y_ptr, void* s
     HPC_CHECK_LAUNCH();
     return HPC_OK;
   }
-  dim3 grid(n / 64, (m + 63) / 64, splits);
-  if (grid.y > 65535) return HPC_ERR_UNSUPPORTED;
   if (splits > 1 && flag_ld < n / 64) return HPC_ERR_INVALID;
-  gemm_bf16xfp32_kernel<4><<<grid, kThreads, 0, stream>>>(a);
+  // Measured (profiles/round5_router_tile_ab.txt; n = 256, k = 4096 unless said): m = 4096 94.9 -> 48.6 us, m = 8192 x k = 7168
+  // 303 -> 127 us (0.47 PFLOP/s), m = 16384 x n = 128 180 -> 80 us.  What is left (timing-only variants, development key 41): the
+  // loop with no loads at all runs at 1.0 PFLOP/s (60 of 127 us), the weight planes - 16 rows x 64 B per load instruction out
+  // of L2 - cost 50 us, the activations 5; split-K adds ~11 us at m = 4096.  Next: weights through LDS as full lines.
+  if (m <= kTileMinM || hpc_dev_tuning_get(40) == 1) {  // (development key 40 = 1: always the 64 x 64 kernel)
+    dim3 grid(n / 64, (m + 63) / 64, splits);
+    if (grid.y > 65535) return HPC_ERR_UNSUPPORTED;
+    gemm_bf16xfp32_kernel<4><<<grid, kThreads, 0, stream>>>(a);
+    HPC_CHECK_LAUNCH();
+    return HPC_OK;
+  }
+  dim3 grid(n / 64, (m + 127) / 128, splits);
+  if (grid.y > 65535) return HPC_ERR_UNSUPPORTED;
+  gemm_bf16xfp32_tile_kernel<<<grid, kThreads, 0, stream>>>(a);
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }

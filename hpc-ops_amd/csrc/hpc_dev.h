@@ -42,6 +42,8 @@
 //   key 36 decode v2: head pair of the SECOND workgroup of every CU = pair ^ (value - 1) (0 = the product's rule: the slice across
 //          byte-address bit 9; 1 = off, both workgroups of a CU on the same slice)
 //   key 37 decode v2: value = s + 1: every workgroup streams slice s of the token rows (timing only - wrong results)
+//   key 40 router GEMM: 1 = the 64 x 64 kernel at every m > 256 (rounds 1-4) instead of the LDS-staged tile kernel above m = 512
+//   key 41 router GEMM tile kernel: bit 0 = no weight loads, bit 1 = no activation loads (timing only - wrong results)
 //   others: see the launchers that read them
 #pragma once
 
