@@ -1213,7 +1213,7 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
       a.pair_wgs[0] = even - g0, a.pair_wgs[1] = even + d1, a.pair_wgs[2] = even - g2, a.pair_wgs[3] = even + d3;
     }
   }
-  if (a.pair_wgs[0] > 0) a.pair_xor = a.mate_from = 0;  // unequal shares (development) re-map the tail of the grid themselves
+  if (a.pair_wgs[0] > 0) a.pair_xor = a.mate_from = 0;  // unequal shares (development) re-map the tail of the grid themselves (both together: measured worse)
   // longer ranges for the first workgroup of every CU (see the kernel): only when the grid is exactly two workgroups
   // per CU, so that "first half of the grid" means "first on its CU".  Development key 32: percentage (0 = off).
   // Measured: no gain at 108 / 115 / 122 % (C3 mix 139.7 / 139.0 / 138.4 us vs 139.3 us) - when a CU's first workgroup
