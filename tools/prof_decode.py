@@ -69,6 +69,14 @@ def run(name, lens_c, nomem):
             if m.any():
                 cells.append(f"{float(end[m].mean()):6.1f}/{float(((end - start)[m] / t[:, 9][m]).mean()):.2f}")
         print(f"   {'second' if half else 'first '} half, pairs 0..3: end us / us per WI:", "  ".join(cells))
+    xcc_of = (raw11 >> 32) & 0xf
+    cells = []
+    for x_ in range(8):  # by XCD: mean end / us per wave-iteration, first- and second-half workgroups
+        m1 = (xcc_of == x_) & (wg_of < NWG // 2); m2 = (xcc_of == x_) & (wg_of >= NWG // 2)
+        if m1.any() and m2.any():
+            prs = sorted(set(int(v) for v in pair_of[xcc_of == x_].tolist()))
+            cells.append(f"x{x_}(pairs {prs}) {float(end[m1].mean()):.0f}/{float(((end - start)[m1] / t[:, 9][m1]).mean()):.2f} {float(end[m2].mean()):.0f}/{float(((end - start)[m2] / t[:, 9][m2]).mean()):.2f}")
+    print("   by XCD (first half end/us per WI, second half):", "  ".join(cells))
     clk = tot / ((r1 - r0) / 100.0).clamp_min(1e-3)  # shader cycles per us
     print(f"   shader clock seen by the waves: {clk.median():.0f} MHz")
 
@@ -76,6 +84,8 @@ DUMP = "dump" in sys.argv
 MAP = 2 if "four_heads" in sys.argv else 0   # "four_heads": the four-head form (key 29 = 2) instead of head pairs
 lib.hpc_dev_tuning_set(29, MAP)
 mixed = bench.c3_lens()
+ONLY = [a_[5:] for a_ in sys.argv if a_.startswith("only=")]
 for nm, lens in (("mixed", mixed), ("uniform8k", torch.full((B,), 8192, dtype=torch.int32))):
+    if ONLY and nm not in ONLY: continue
     for nomem in ((False,) if DUMP else (False, True)):
         run(nm, lens, nomem)
