@@ -173,18 +173,21 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16xfp32_kernel(const Args a) 
   }
 }
 
-// ---- large m (> 256): 64 weight rows x 128 tokens per workgroup, activations staged through LDS ------------------
+// ---- large m (> 512): 64 weight rows x 128 tokens per workgroup, every operand staged through LDS ------------------
 // The 64 x 64 kernel above fetches every activation row four times (each of its waves loads the whole token tile into
 // MFMA operand registers) as 64-byte pieces: at m = 4096 it is bound by what the CU's load path accepts (93 us for
-// 17 GFLOP, round 1-4).  Here the activations - the big operand: m x k against 2 x n x k of weights that live in L2 - are
-// read ONCE per workgroup, 128 contiguous bytes per token row and 64-k step, into registers one step ahead, written to a
-// double-buffered LDS tile ([128 tokens][128 B], 16-byte chunks XOR-swizzled with the token index) and read from there as
-// MFMA B operands; the weight planes go straight into A-operand registers two steps ahead (a wave owns 32 weight rows x
-// 64 tokens: 8 weight + 8 activation operand reads for 32 MFMAs per step).  One barrier per step.  Split-K and its
-// last-arriver reduction as above (counters on the same [m tiles, n / 64] grid, m tiles of 128).
+// 17 GFLOP, round 1-4).  Here every operand is read ONCE per workgroup as full 128-byte lines - a thread fetches one 16-byte
+// chunk of four token rows and of two weight rows of both planes per 64-k step, three steps ahead, parks it in registers and
+// writes it one step ahead into a double-buffered LDS stage ([128 tokens | 2 planes x 64 weight rows][128 B], 16-byte chunks
+// XOR-swizzled with the row index: conflict-free b128 writes and operand reads) - and leaves LDS as MFMA operands: a wave owns
+// 32 weight rows x 64 tokens (8 operand reads for 16 MFMAs per 32-k half).  One barrier per step, 64 KB of LDS, two
+// workgroups per CU.  (First form of this kernel: weight planes straight into A-operand registers, 16 rows x 64 B per load
+// instruction - those loads alone cost 50 of 128 us at m = 8192 x k = 7168.)  Split-K and its last-arriver reduction as above
+// (counters on the same [m tiles, n / 64] grid, m tiles of 128).
 __global__ __launch_bounds__(kThreads, 2) void gemm_bf16xfp32_tile_kernel(const Args a) {
   constexpr int kTT = 128;  // tokens per workgroup
   __shared__ u32x4 s_x[2][kTT * 8];
+  __shared__ u32x4 s_w[2][2][64 * 8];  // [buffer][plane][64 weight rows x 8 chunks]
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -198,24 +201,33 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16xfp32_tile_kernel(const 
 
   const unsigned w_bytes = static_cast<unsigned>(a.n) * static_cast<unsigned>(K) * 2u;
   const unsigned x_bytes = static_cast<unsigned>(a.m) * static_cast<unsigned>(K) * 2u;
-  unsigned w_off[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) w_off[i] = static_cast<unsigned>(n0 + wr * 32 + i * 16 + r16) * static_cast<unsigned>(K) * 2u + g4 * 16;
-  // staging: thread t carries chunk t % 8 of tokens t / 8 + 32 q
-  unsigned xg_off[4];
-  int xs_idx[4];
+  // staging roles: thread t carries 16-byte chunk t % 8 of tokens t / 8 + 32 q (q = 0 .. 3) and of weight rows t / 8 + 32 q2
+  // (q2 = 0, 1) of both planes: every load instruction fetches whole 128-byte lines
+  unsigned xg_off[4], wg_off[2];
+  int xs_idx[4], ws_idx[2];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int tl = (tid >> 3) + 32 * q, t = m0 + tl;
     xg_off[q] = static_cast<unsigned>(t < a.m ? t : a.m - 1) * static_cast<unsigned>(K) * 2u + (tid & 7) * 16;
     xs_idx[q] = tl * 8 + ((tid & 7) ^ (tl & 7));
   }
-  // operand reads: token wt * 64 + j * 16 + r16, chunk h * 4 + g4
-  int xr_idx[4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int rl = (tid >> 3) + 32 * q;
+    wg_off[q] = static_cast<unsigned>(n0 + rl) * static_cast<unsigned>(K) * 2u + (tid & 7) * 16;
+    ws_idx[q] = rl * 8 + ((tid & 7) ^ (rl & 7));
+  }
+  // operand reads: token wt * 64 + j * 16 + r16 / weight row wr * 32 + i * 16 + r16, chunk h * 4 + g4 (h = 1: index ^ 4)
+  int xr_idx[4], wr_idx[2];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int tl = wt * 64 + j * 16 + r16;
-    xr_idx[j] = tl * 8 + (g4 ^ (tl & 7));  // h = 1: ^ 4
+    xr_idx[j] = tl * 8 + (g4 ^ (tl & 7));
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rl = wr * 32 + i * 16 + r16;
+    wr_idx[i] = rl * 8 + (g4 ^ (rl & 7));
   }
 
   f32x4 acc_h[2][4], acc_l[2][4];
@@ -224,68 +236,67 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16xfp32_tile_kernel(const 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc_h[i][j] = acc_l[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 bh[2][2][2], bl[2][2][2];  // [buffer][row block][32-k half]
-  u32x4 xr[2][4];  // staging registers: two steps of activations in flight
+  u32x4 xr[2][4], wreg[2][2][2];  // staging registers: two steps in flight ([stage][q] / [stage][plane][q2])
   // (Measured and dropped: every workgroup starting its k walk at its own step - rows of x and of the weight planes are a
   //  power of two apart, so workgroups in step queue at the same lines - changes nothing: 49.4 against 50.2 us.)
-  auto issue_w = [&](int buf, int c) {
+  auto load = [&](int rb, int c) {
     const bool on = c < c_end;
     const int koff = on ? c * 128 : 0;
     const bool mem_w = on && !(a.dev_skip & 1);  // development key 41 bit 0: no weight loads (timing only)
     const auto rh_ = make_rsrc(a.wh, mem_w ? w_bytes : 0u), rl_ = make_rsrc(a.wl, mem_w ? w_bytes : 0u);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        bh[buf][i][h] = buf_ld16<0>(rh_, w_off[i], koff + h * 64);
-        bl[buf][i][h] = buf_ld16<0>(rl_, w_off[i], koff + h * 64);
-      }
-  };
-  auto load_x = [&](int rb, int c) {
-    const bool on = c < c_end;
     const auto rx_ = make_rsrc(a.x, on && !(a.dev_skip & 2) ? x_bytes : 0u);  // development key 41 bit 1: no activation loads
-    const int koff = on ? c * 128 : 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) xr[rb][q] = buf_ld16<0>(rx_, xg_off[q], koff);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      wreg[rb][0][q] = buf_ld16<0>(rh_, wg_off[q], koff);
+      wreg[rb][1][q] = buf_ld16<0>(rl_, wg_off[q], koff);
+    }
   };
-  auto stage_x = [&](int sb, int rb) {
+  auto stage = [&](int sb, int rb) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) s_x[sb][xs_idx[q]] = xr[rb][q];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      s_w[sb][0][ws_idx[q]] = wreg[rb][0][q];
+      s_w[sb][1][ws_idx[q]] = wreg[rb][1][q];
+    }
   };
-  auto compute = [&](int buf, int sb) {
+  auto compute = [&](int sb) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      u32x4 bx[4];
+      u32x4 bx[4], ah[2], al[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        ah[i] = s_w[sb][0][wr_idx[i] ^ (h << 2)];
+        al[i] = s_w[sb][1][wr_idx[i] ^ (h << 2)];
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) bx[j] = s_x[sb][xr_idx[j] ^ (h << 2)];
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          acc_h[i][j] = mfma_bf16(bh[buf][i][h], bx[j], acc_h[i][j]);
-          acc_l[i][j] = mfma_bf16(bl[buf][i][h], bx[j], acc_l[i][j]);
+          acc_h[i][j] = mfma_bf16(ah[i], bx[j], acc_h[i][j]);
+          acc_l[i][j] = mfma_bf16(al[i], bx[j], acc_l[i][j]);
         }
     }
   };
-  // Step s is loaded into staging registers xr[s & 1] three steps before it is multiplied, written to LDS buffer s & 1 one
-  // step before (that buffer was last read two steps earlier, behind a barrier); its weights go in flight two steps before.
-  load_x(0, c_begin);
-  issue_w(0, c_begin);
-  load_x(1, c_begin + 1);
-  issue_w(1, c_begin + 1);
-  stage_x(0, 0);
-  load_x(0, c_begin + 2);
+  // Step s is loaded into staging registers [s & 1] three steps before it is multiplied and written to LDS buffer s & 1 one
+  // step before (that buffer was last read two steps earlier, behind a barrier).
+  load(0, c_begin);
+  load(1, c_begin + 1);
+  stage(0, 0);
+  load(0, c_begin + 2);
   __syncthreads();
   for (int c = c_begin; c < c_end; c += 2) {
-    stage_x(1, 1);  // step c + 1
-    load_x(1, c + 3);
-    compute(0, 0);
-    issue_w(0, c + 2);
+    stage(1, 1);  // step c + 1
+    load(1, c + 3);
+    compute(0);
     __syncthreads();
-    stage_x(0, 0);  // step c + 2
-    load_x(0, c + 4);
-    compute(1, 1);
-    issue_w(1, c + 3);
+    stage(0, 0);  // step c + 2
+    load(0, c + 4);
+    compute(1);
     __syncthreads();
   }
 
@@ -545,10 +556,10 @@ extern "C" int hpc_gemm_bf16xfp32_async(void* y_ptr, void* splitk_y_ptr, void* s
     return HPC_OK;
   }
   if (splits > 1 && flag_ld < n / 64) return HPC_ERR_INVALID;
-  // Measured (profiles/round5_router_tile_ab.txt; n = 256, k = 4096 unless said): m = 4096 94.9 -> 48.6 us, m = 8192 x k = 7168
-  // 303 -> 127 us (0.47 PFLOP/s), m = 16384 x n = 128 180 -> 80 us.  What is left (timing-only variants, development key 41): the
-  // loop with no loads at all runs at 1.0 PFLOP/s (60 of 127 us), the weight planes - 16 rows x 64 B per load instruction out
-  // of L2 - cost 50 us, the activations 5; split-K adds ~11 us at m = 4096.  Next: weights through LDS as full lines.
+  // Measured (profiles/round5_router_tile_ab.txt; n = 256, k = 4096 unless said): m = 4096 94.9 -> 38.5 us, m = 8192 x k = 7168
+  // 304 -> 81 us (0.74 PFLOP/s), m = 16384 x n = 128 180 -> 54 us.  What is left (timing-only variants, development key 41): the
+  // loop with no loads at all takes 64 of the 81 us (0.93 PFLOP/s: eight 16-byte LDS stores + sixteen operand reads per wave for
+  // 32 MFMAs, one barrier per step), the activations from memory 16 us, the weight planes 5; split-K adds ~11 us at m = 4096.
   if (m <= kTileMinM || hpc_dev_tuning_get(40) == 1) {  // (development key 40 = 1: always the 64 x 64 kernel)
     dim3 grid(n / 64, (m + 63) / 64, splits);
     if (grid.y > 65535) return HPC_ERR_UNSUPPORTED;
