@@ -14,6 +14,8 @@
 // go to an fp32 workspace; the last workgroup to arrive at a tile (device-scope counter) sums the
 // splits in fixed order - deterministic - writes y and leaves the counter at zero for the next call
 // (same contract as the reference's split_flag).
+#include <type_traits>
+
 #include "hpc_common.h"
 #include "hpc_dev.h"
 #include "../../include/hpc_amd.h"
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16xfp32_kernel(const Args a) 
   }
 }
 
-// ---- large m (> 512): 64 weight rows x 128 tokens per workgroup, every operand staged through LDS ------------------
+// ---- m > 256: 64 weight rows x 128 tokens per workgroup, every operand staged through LDS ------------------
 // The 64 x 64 kernel above fetches every activation row four times (each of its waves loads the whole token tile into
 // MFMA operand registers) as 64-byte pieces: at m = 4096 it is bound by what the CU's load path accepts (93 us for
 // 17 GFLOP, round 1-4).  Here every operand is read ONCE per workgroup as full 128-byte lines - a thread fetches one 16-byte
@@ -343,30 +345,41 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16xfp32_tile_kernel(const 
   }
   __syncthreads();
   if (!s_last) return;
-  constexpr int kMaxSplits = 16;
+  // The last arriver sums the splits in split order.  All partial loads of a trip are in flight at once (a serial load -> add
+  // chain costs one ~2.5 us system-scope round trip per trip): 32 loads per trip = all eight (row block, token block) units of
+  // the wave with up to 4 splits, four units with up to 8, two with up to 16 (round 5: two units per trip whatever the split
+  // count - four trips = ~10 of the 49 us at m = 4096).  Splits past a.splits use an empty descriptor (read 0, add nothing).
   const auto rnull = make_rsrc(a.split_y, 0u);
+  auto reduce = [&](auto ks) {
+    constexpr int kS = decltype(ks)::value, kG = 32 / kS;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int u0 = 0; u0 < 8; u0 += kG) {
+      u32x4 part[kG][kS];
 #pragma unroll
-    for (int j0 = 0; j0 < 4; j0 += 2) {
-      u32x4 part[2][kMaxSplits];
-      const int nn = n0 + wr * 32 + i * 16 + g4 * 4;
+      for (int g = 0; g < kG; ++g) {
+        const int i = (u0 + g) >> 2, j = (u0 + g) & 3;
+        const int t = m0 + wt * 64 + j * 16 + r16;
+        const unsigned off = (static_cast<unsigned>(t < a.m ? t : 0) * a.n + n0 + wr * 32 + i * 16 + g4 * 4) * 4u;
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int t = m0 + wt * 64 + (j0 + jj) * 16 + r16;
-        const unsigned off = (static_cast<unsigned>(t < a.m ? t : 0) * a.n + nn) * 4u;
-#pragma unroll
-        for (int sp = 0; sp < kMaxSplits; ++sp) part[jj][sp] = buf_ld16<17>(sp < a.splits ? rp : rnull, off, sp * plane);
+        for (int sp = 0; sp < kS; ++sp) part[g][sp] = buf_ld16<17>(sp < a.splits ? rp : rnull, off, sp * plane);
       }
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const int t = m0 + wt * 64 + (j0 + jj) * 16 + r16;
+      for (int g = 0; g < kG; ++g) {
+        const int i = (u0 + g) >> 2, j = (u0 + g) & 3;
+        const int t = m0 + wt * 64 + j * 16 + r16;
         f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int sp = 0; sp < kMaxSplits; ++sp) sum += __builtin_bit_cast(f32x4, part[jj][sp]);
-        if (t < a.m) emit(t, nn, sum);
+        for (int sp = 0; sp < kS; ++sp) sum += __builtin_bit_cast(f32x4, part[g][sp]);
+        if (t < a.m) emit(t, n0 + wr * 32 + i * 16 + g4 * 4, sum);
       }
     }
+  };
+  if (a.splits <= 4)
+    reduce(std::integral_constant<int, 4>{});
+  else if (a.splits <= 8)
+    reduce(std::integral_constant<int, 8>{});
+  else
+    reduce(std::integral_constant<int, 16>{});
 }
 
 // ---- decode-size m (<= 256): skinny tiles, K split across waves AND workgroups --------------------------
@@ -486,14 +499,14 @@ __global__ __launch_bounds__(kThreads) void gemm_bf16xfp32_skinny_kernel(const A
 }
 
 constexpr int kSkinnyMaxM = 256;
-constexpr int kTileMinM = 512;  // the LDS-staged tile kernel above this many tokens (m = 512: 27.3 against 24.8 us, m = 1024: 32.4 against 36.9)
 inline int skinny_tm(int m) { return m <= 16 ? 16 : (m <= 32 ? 32 : 64); }
 
 }  // namespace rgemm
 }  // namespace hpc
 
 // Split count the launcher will use for (m, n, k): callers size split_y = splits * m * n floats and
-// (m <= 256) provide ceil(m / tm) * n / 16 zeroed counters, (m > 256) a [ceil(m/64)+, n/64+] counter grid.
+// (m <= 256) provide ceil(m / tm) * n / 16 zeroed counters, (m > 256) a [ceil(m/64)+, n/64+] counter grid (the tile kernel
+// counts on its first ceil(m / 128) rows).
 extern "C" int hpc_gemm_bf16xfp32_splits(int m, int n, int k, int use_splitk) {
   using namespace hpc::rgemm;
   if (m <= 0 || n <= 0 || k <= 0) return 1;
@@ -506,9 +519,14 @@ extern "C" int hpc_gemm_bf16xfp32_splits(int m, int n, int k, int use_splitk) {
     while (s < 16 && tiles * s < 256 && (k >> 6) / (s * 2) >= 4) s *= 2;
     return s;
   }
-  // 256 < m <= 512: 64 x 64 tiles; above: the tile kernel, 64 weight rows x 128 tokens
-  const long tiles = m <= kTileMinM ? static_cast<long>((m + 63) / 64) * (n / 64) : static_cast<long>((m + 127) / 128) * (n / 64);
-  while (s < 16 && tiles * s < 512 && k / (s * 2) >= 256) s *= 2;
+  // m > 256: the tile kernel, 64 weight rows x 128 tokens.  Splits until there is ONE workgroup per CU, at most 8 (every split
+  // costs the hand-off of its fp32 partials: m = 4096 x n = 256 35.7 us with 4 splits = two workgroups per CU, 28.7 us with 2;
+  // m = 1024 29.2 us with 16 splits, 19.9 with 8 - profiles/round5_router_tile_ab.txt); a launch that has between one and two
+  // workgroups per CU without splitting is split once more (two resident workgroups per CU overlap each other's load phases).
+  const long tiles = static_cast<long>((m + 127) / 128) * (n / 64);
+  const int cap = hpc_dev_tuning_get(45) > 0 ? hpc_dev_tuning_get(45) : 8;  // development key 45: cap on the split count above m = 256
+  while (s < cap && tiles * s < 256 && k / (s * 2) >= 256) s *= 2;
+  if (tiles >= 256 && tiles < 512 && s == 1 && k >= 512) s = 2;
   return s;
 }
 
@@ -556,11 +574,12 @@ extern "C" int hpc_gemm_bf16xfp32_async(void* y_ptr, void* splitk_y_ptr, void* s
     return HPC_OK;
   }
   if (splits > 1 && flag_ld < n / 64) return HPC_ERR_INVALID;
-  // Measured (profiles/round5_router_tile_ab.txt; n = 256, k = 4096 unless said): m = 4096 94.9 -> 38.5 us, m = 8192 x k = 7168
-  // 304 -> 81 us (0.74 PFLOP/s), m = 16384 x n = 128 180 -> 54 us.  What is left (timing-only variants, development key 41): the
-  // loop with no loads at all takes 64 of the 81 us (0.93 PFLOP/s: eight 16-byte LDS stores + sixteen operand reads per wave for
-  // 32 MFMAs, one barrier per step), the activations from memory 16 us, the weight planes 5; split-K adds ~11 us at m = 4096.
-  if (m <= kTileMinM || hpc_dev_tuning_get(40) == 1) {  // (development key 40 = 1: always the 64 x 64 kernel)
+  // Measured (profiles/round5_router_tile_ab.txt; n = 256, k = 4096 unless said, old -> new): m = 4096 94.7 -> 29.0 us, m = 1024
+  // 32.5 -> 20.1, m = 304 23.6 -> 18.2, m = 8192 x k = 7168 304 -> 77.5 us (0.78 PFLOP/s), m = 16384 x n = 128 180 -> 51.5 us.  What is
+  // left (timing-only variants, development key 41): the loop with no loads at all takes 62 of the 77.5 us (eight 16-byte LDS
+  // stores + sixteen operand reads per wave for 32 MFMAs, one barrier per step), and below m ~ 1024 the call is its fixed
+  // cost (launch, eight steps, split hand-off: 18-19 us).
+  if (hpc_dev_tuning_get(40) == 1) {  // development key 40 = 1: the 64 x 64 kernel of rounds 1-4 (operands straight from memory)
     dim3 grid(n / 64, (m + 63) / 64, splits);
     if (grid.y > 65535) return HPC_ERR_UNSUPPORTED;
     gemm_bf16xfp32_kernel<4><<<grid, kThreads, 0, stream>>>(a);

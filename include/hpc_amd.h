@@ -289,7 +289,8 @@ int hpc_rope_norm_store_kv_fp8_async(void* out_q, void* kcache, void* vcache, vo
  * n % 64 == 0, k % 64 == 0.  splits = hpc_gemm_bf16xfp32_splits(m, n, k, use_splitk); when > 1 the
  * caller provides splitk_y (splits*m*n fp32) and zeroed int32 arrival counters split_flag: for
  * m <= 256 a flat [ceil(m/tm), flag_ld = n/16] array (tm = 16 / 32 / 64 for m <= 16 / 32 / 256), for
- * larger m a [ceil(m/64), flag_ld >= n/64] grid; the counters are zero again when the call retires. */
+ * larger m a [ceil(m/64), flag_ld >= n/64] grid (the tile kernel counts on its first ceil(m/128) rows); the counters are zero
+ * again when the call retires. */
 int hpc_gemm_bf16xfp32_splits(int m, int n, int k, int use_splitk);
 int hpc_gemm_bf16xfp32_async(void* y, void* splitk_y, void* split_flag, const void* x, const void* w_high,
                              const void* w_low, int m, int n, int k, float scale, int use_fp32_output,
