@@ -7,10 +7,11 @@
 //
 // MI355X design: weights sit on the MFMA M axis, tokens on N.  Two kernels: the decode-step shape
 // (m <= 256 tokens against n = #experts rows of k = 4096: 3 - 33 MB of weights, a streaming / latency
-// problem) runs on skinny 16-row tiles with K split over waves and workgroups (below); larger m runs
-// on 64 x 64 tiles (16 rows per wave) with K optionally split across blockIdx.z.  Both weight planes and the
-// activations are fetched straight into MFMA operand layout (v_mfma_f32_16x16x32_bf16: lane
-// (r, g) holds 8 consecutive k of row r), 64 k per step, register double-buffered.  Split-K partials
+// problem) runs on skinny 16-row tiles with K split over waves and workgroups (below), both weight planes and
+// the activations fetched straight into MFMA operand layout (v_mfma_f32_16x16x32_bf16: lane (r, g) holds 8
+// consecutive k of row r), 64 k per step, register double-buffered; larger m runs on the LDS-staged tile kernel
+// (64 weight rows x 128 tokens, every operand read once per workgroup as full lines; round 5 - the 64 x 64
+// direct-load kernel of rounds 1-4 stays behind development key 40 as the A/B partner).  Split-K partials
 // go to an fp32 workspace; the last workgroup to arrive at a tile (device-scope counter) sums the
 // splits in fixed order - deterministic - writes y and leaves the counter at zero for the next call
 // (same contract as the reference's split_flag).
