@@ -267,7 +267,10 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   // byte offset differs in address bit 9 from the first one's, the whole launch runs 4-6 % faster (C3 mix 141 -> 133-137 us,
   // uniform 8k 180 -> 175 us, every box); mates on the same slice (today's kernel until round 5), slices that differ in bit 8, or
   // an XCD that serves all four slices are all slower.  Every workgroup that streams alone on a slice runs as fast as any
-  // other (development key 37), so this is not a property of the memory channels behind a slice.
+  // other (development key 37), so this is not a property of the memory channels behind a slice.  Two more facts of the same
+  // sweep that this mapping relies on: pair index bit 0 (= slice address bit 8 for fp8 pairs) is the PARITY of the XCD a
+  // workgroup runs on (workgroups go round the 8 XCDs in index order) - every other assignment of slice bits to XCD index bits
+  // is 3 % slower (development key 38) -, and the even XCDs stream bit-8 = 0 addresses faster than anything else streams (call 28).
   if (a.xcd_map != 0 && npair == 4 && (nwg & 7) == 0) {  // development: which XCD (= wg % 8) streams which slice
     const int e = (a.xcd_map >> (3 * (wg & 7))) & 7;
     pr = e & 3;
