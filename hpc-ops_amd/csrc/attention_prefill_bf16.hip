@@ -9,11 +9,13 @@
 // and finishes alone, a workgroup = 4 waves = 128 consecutive rows that walk the KV tiles together; every
 // 64-token K/V tile (256-byte rows) is fetched once per workgroup - wave w loads token block w, full rows,
 // one tile ahead - into a double-buffered LDS stage, one barrier per tile.  P is rounded to bf16 before
-// P V like the decode kernel; V^T operands are built from 16-byte row pieces with v_perm_b32.  The
+// P V like the decode kernel; V^T operands come out of LDS through the transposing read ds_read_b64_tr_b16
+// (round 5; rounds 3-4 built them from 16-byte row pieces with v_perm_b32).  The
 // epilogue reuses the staging LDS (aliased), so two workgroups fit a CU.
 // Contiguous form: K/V rows of request b are rows cu_seqlens_q[b] .. of [total_seq, Hkv, 128] tensors
 // (block_ids == null), every q token attends the keys up to itself.
 #include "hpc_common.h"
+#include "hpc_dev.h"
 #include "../../include/hpc_amd.h"
 
 namespace hpc {
@@ -41,7 +43,8 @@ constexpr int kRowsPerWave = 16 * kNB;
 constexpr float kNegInf = -__builtin_inff();
 constexpr int kKRow = 256 + 16;             // padded LDS row (bytes)
 constexpr int kTileBytes = 64 * kKRow;      // one K or V tile
-constexpr int kStageBytes = 4 * kTileBytes; // K, V x 2 buffers
+constexpr int kVTileBytes = 64 * 256;       // one V tile: unpadded 256-byte rows, 16-byte chunks XOR-swizzled (transposing reads)
+constexpr int kStageBytes = 4 * kTileBytes;  // K, V x 2 buffers (the padded V form of rounds 3-4 is the larger one)
 constexpr int kEpiBytes = kWaves * 16 * (128 + 4) * 4 + kWaves * 16 * 4;
 
 // max / sum over the 4 lanes that share a q row (lane, lane ^ 16, lane ^ 32, lane ^ 48) with the gfx950 row swaps
@@ -63,15 +66,22 @@ struct IntC {
   static constexpr int value = kN;
 };
 
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+
 union Frag16 {
   u32x4 u;
   bf16x8 b;
 };
 
+// kTr: V^T operands through the transposing LDS read (round 5); false: the v_perm_b32 form of rounds 3-4 (development key 46 = 1)
+template <bool kTr>
 __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a) {
+  constexpr int kVStride = kTr ? 256 : kKRow, kVBuf = kTr ? kVTileBytes : kTileBytes;
   __shared__ __attribute__((aligned(16))) uint8_t s_raw[kStageBytes > kEpiBytes ? kStageBytes : kEpiBytes];
   uint8_t* s_k = s_raw;                   // [2][64 * kKRow]
-  uint8_t* s_v = s_raw + 2 * kTileBytes;  // [2][64 * kKRow]
+  uint8_t* s_v = s_raw + 2 * kTileBytes;  // [2][64 * 256], chunk c of token row t in slot c ^ (2 * (t & 7))
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -172,12 +182,21 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a)
     for (int c = 0; c < 4; ++c)
       *reinterpret_cast<u32x4*>(s_k + buf * kTileBytes + (wave * 16 + c * 4 + st_rsub) * kKRow + st_chunk * 16) = kst[c];
   };
+  // V stage: row t = 256 bytes, its 16-byte chunk c in slot c ^ (2 * (t & 7)): the 32 lanes of a transposing read (8 token rows
+  // x 2 chunks x 2 halves) fall on 32 different 8-byte bank pairs, the 8 lanes of a 16-byte store group on 8 different slots
+  const int vkey_e = (2 * st_rsub) * 16, vkey_o = (8 + 2 * st_rsub) * 16;  // rows c * 4 + st_rsub: (t & 7) = 4 (c & 1) + st_rsub
   auto stash_v = [&](int buf) {
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      *reinterpret_cast<u32x4*>(s_v + buf * kTileBytes + (wave * 16 + c * 4 + st_rsub) * kKRow + st_chunk * 16) = vst[c];
+      *reinterpret_cast<u32x4*>(s_v + buf * kVBuf + (wave * 16 + c * 4 + st_rsub) * kVStride +
+                                (kTr ? ((st_chunk * 16) ^ ((c & 1) ? vkey_o : vkey_e)) : st_chunk * 16)) = vst[c];
   };
 
+  // transposing reads: lane -> token row 4g + j (j = (lane % 16) / 4) of a 16-token block, bytes 8 (lane % 4) .. + 7 of the 32 bytes
+  // of a 16-dim block: chunk 2 u + (lane % 4) / 2 (swizzled: ^ 2 * (row & 7)), half lane % 2
+  const int vtr_j = (lane & 15) >> 2, vtr_c = lane & 3;
+  const int vtr_row = (4 * g + vtr_j) * 256 + (vtr_c >> 1) * 16 + (vtr_c & 1) * 8;
+  const int vtr_key = (2 * ((4 * g + vtr_j) & 7)) * 16;
   f32x4 o[kNB][8];
   float m_run[kNB], l_run[kNB];
 #pragma unroll
@@ -201,7 +220,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a)
     const bool more = t + 1 < ntile;
     if (more) fetch_k(t + 1);
     const uint8_t* kt = s_k + buf * kTileBytes;
-    const uint8_t* vt = s_v + buf * kTileBytes;
+    const uint8_t* vt = s_v + buf * kVBuf;
 
     // ---- S^T = K Q^T --------------------------------------------------------------------------------
     f32x4 s[kNB][4];
@@ -271,28 +290,56 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a)
 
     if (more) stash_k(buf ^ 1);
 
-    // ---- O^T += V^T P^T: lane (n, g) reads dims 8n .. 8n+7 of tokens 16 tb + 4g + r -----------------------
+    // ---- O^T += V^T P^T: V^T operands straight out of LDS through ds_read_b64_tr_b16 (the gfx950 transposing read: lanes
+    // 4j .. 4j+3 of a 16-lane group give the address of 8 bytes of row j of a 4 x 16 tile, lane i gets column i of the four rows).
+    // Lane (i, g) of the A operand = dim 16 u + i of tokens 16 tb + 4g + 0..3 for tb = 2 ks, 2 ks + 1: the eight k-slots the B
+    // operand (this lane group's probabilities, pf) holds.  Round 5: 32 transposing reads per tile instead of 16 row reads + 64
+    // v_perm_b32.
+    if constexpr (kTr) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      u32x4 vf[8];
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int hb = 0; hb < 2; ++hb)
+        for (int u = 0; u < 8; ++u) {
+          Frag16 va;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          vf[hb * 4 + r] = *reinterpret_cast<const u32x4*>(vt + ((2 * ks + hb) * 16 + g * 4 + r) * kKRow + n * 16);
+          for (int hb = 0; hb < 2; ++hb) {
+            const v4i16 tr = __builtin_amdgcn_ds_read_tr16_b64_v4i16(reinterpret_cast<lds_v4i16*>(
+                static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_u8*)(vt + (2 * ks + hb) * 16 * 256 + vtr_row + ((u * 32) ^ vtr_key))))));
+            const u32x2 t2 = __builtin_bit_cast(u32x2, tr);
+            va.u[2 * hb] = t2[0];
+            va.u[2 * hb + 1] = t2[1];
+          }
 #pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        Frag16 va;
-#pragma unroll
-        for (int p2 = 0; p2 < 4; ++p2) {
-          const uint32_t lo = vf[2 * p2][jj >> 1], hi = vf[2 * p2 + 1][jj >> 1];
-          va.u[p2] = __builtin_amdgcn_perm(hi, lo, (jj & 1) ? 0x07060302u : 0x05040100u);
+          for (int nb = 0; nb < kNB; ++nb) {
+            Frag16 pa;
+            pa.u = u32x4{pf[nb][ks][0], pf[nb][ks][1], pf[nb][ks][2], pf[nb][ks][3]};
+            o[nb][u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.b, pa.b, o[nb][u], 0, 0, 0);
+          }
         }
+      }
+    } else {  // rounds 3-4: lane (n, g) reads dims 8n .. 8n+7 of tokens 16 tb + 4g + r; output block jj holds dims 8 i + jj
 #pragma unroll
-        for (int nb = 0; nb < kNB; ++nb) {
-          Frag16 pa;
-          pa.u = u32x4{pf[nb][ks][0], pf[nb][ks][1], pf[nb][ks][2], pf[nb][ks][3]};
-          o[nb][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.b, pa.b, o[nb][jj], 0, 0, 0);
+      for (int ks = 0; ks < 2; ++ks) {
+        u32x4 vf[8];
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            vf[hb * 4 + r] = *reinterpret_cast<const u32x4*>(vt + ((2 * ks + hb) * 16 + g * 4 + r) * kKRow + n * 16);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          Frag16 va;
+#pragma unroll
+          for (int p2 = 0; p2 < 4; ++p2) {
+            const uint32_t lo = vf[2 * p2][jj >> 1], hi = vf[2 * p2 + 1][jj >> 1];
+            va.u[p2] = __builtin_amdgcn_perm(hi, lo, (jj & 1) ? 0x07060302u : 0x05040100u);
+          }
+#pragma unroll
+          for (int nb = 0; nb < kNB; ++nb) {
+            Frag16 pa;
+            pa.u = u32x4{pf[nb][ks][0], pf[nb][ks][1], pf[nb][ks][2], pf[nb][ks][3]};
+            o[nb][jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va.b, pa.b, o[nb][jj], 0, 0, 0);
+          }
         }
       }
     }
@@ -313,7 +360,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a)
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s_o[wave][n][8 * (g * 4 + r) + jj] = o[nb][jj][r];
+      for (int r = 0; r < 4; ++r) s_o[wave][n][kTr ? 16 * jj + g * 4 + r : 8 * (g * 4 + r) + jj] = o[nb][jj][r];
 #pragma unroll 1
     for (int it = 0; it < 4; ++it) {
       const int row16 = it * 4 + (lane >> 4), c8 = lane & 15;
@@ -356,7 +403,10 @@ int launch_prefill_bf16(hpc::prefill16::Args& a, int max_seqlens_q, int num_head
   const long rows = static_cast<long>(max_seqlens_q) * group;
   dim3 grid(static_cast<unsigned>((rows + kWaves * kRowsPerWave - 1) / (kWaves * kRowsPerWave)), num_head_kv, num_batch);
   if (grid.z > 65535 || grid.y > 65535) return HPC_ERR_UNSUPPORTED;
-  prefill_bf16_kernel<<<grid, kThreads, 0, stream>>>(a);
+  if (kHpcDevBuild && hpc_dev_tuning_get(46) == 1)  // development key 46 = 1: V^T operands built with v_perm_b32 (rounds 3-4)
+    prefill_bf16_kernel<false><<<grid, kThreads, 0, stream>>>(a);
+  else
+    prefill_bf16_kernel<true><<<grid, kThreads, 0, stream>>>(a);
   HPC_CHECK_LAUNCH();
   return HPC_OK;
 }

@@ -44,6 +44,8 @@
 //   key 37 decode v2: value = s + 1: every workgroup streams slice s of the token rows (timing only - wrong results)
 //   key 40 router GEMM: 1 = the 64 x 64 kernel at every m > 256 (rounds 1-4) instead of the LDS-staged tile kernel above m = 512
 //   key 41 router GEMM tile kernel: bit 0 = no weight loads, bit 1 = no activation loads (timing only - wrong results)
+//   key 45 router GEMM: cap on the split count above m = 256 (default 8)
+//   key 46 bf16 prefill: 1 = V^T operands built with v_perm_b32 (rounds 3-4) instead of the transposing LDS read
 //   others: see the launchers that read them
 #pragma once
 
