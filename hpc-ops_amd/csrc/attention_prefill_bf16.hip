@@ -161,19 +161,20 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a)
       v_lim = rows * static_cast<unsigned>(a.v_token_stride) * 2u;
     }
   };
+  // (the page lookup and the two row offsets of a tile are computed once, by fetch_k; fetch_v of the same tile - issued a
+  //  section later - takes the V half from there: round 5, ~35 scalar instructions per tile less)
+  long nx_vb = 0;
+  unsigned nx_vl = 0;
   auto fetch_k = [&](int t) {
-    long kb, vb;
-    unsigned kl, vl;
-    tile_base(t, kb, vb, kl, vl);
+    long kb;
+    unsigned kl;
+    tile_base(t, kb, nx_vb, kl, nx_vl);
     const auto rk = make_rsrc(kbase + (kb + h * a.k_head_stride) * 2, kl);
 #pragma unroll
     for (int c = 0; c < 4; ++c) kst[c] = buf_ld16<0>(rk, k_voff, c * k_ld_bytes);
   };
-  auto fetch_v = [&](int t) {
-    long kb, vb;
-    unsigned kl, vl;
-    tile_base(t, kb, vb, kl, vl);
-    const auto rv = make_rsrc(vbase + (vb + h * a.v_head_stride) * 2, vl);
+  auto fetch_v = [&]() {  // the tile fetch_k was last called for
+    const auto rv = make_rsrc(vbase + (nx_vb + h * a.v_head_stride) * 2, nx_vl);
 #pragma unroll
     for (int c = 0; c < 4; ++c) vst[c] = buf_ld16<0>(rv, v_voff, c * v_ld_bytes);
   };
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a)
   }
 
   fetch_k(0);
-  fetch_v(0);
+  fetch_v();
   stash_k(0);
   stash_v(0);
   __syncthreads();
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(kThreads, 2) void prefill_bf16_kernel(const Args a)
       }
     }
 
-    if (more) fetch_v(t + 1);
+    if (more) fetch_v();
 
     // ---- online softmax, base 2 ---------------------------------------------------------------------
     uint32_t pf[kNB][2][4];
