@@ -340,6 +340,47 @@ def test_attn_fp8_uneven_ranges(keys, num_batch, hi):
             dev_set(k, 0)
 
 
+@pytest.mark.dev
+@pytest.mark.gpu
+@pytest.mark.parametrize("heads", [(8, 64), (4, 32), (16, 64)])
+def test_attn_fp8_workgroup_to_slice_mapping_is_only_a_mapping(heads):
+    """Round 5: the second workgroup of every CU serves head pair p ^ mask (the slice of the token rows across byte-address
+    bit 9 from its CU mate's; csrc/attention_decode_v2.hip).  Which workgroup computes which (range, pair) must not change a
+    bit of the result: the product's mask against none (development key 36 = 1) and against the other masks of the sweep,
+    and an XCD -> slice table (key 38) - same plan, same arithmetic, `torch.equal`."""
+    import hpc
+
+    num_head_kv, num_head_q = heads
+    num_batch, block_size = 48, 64
+    lens = _mixed_lens(num_batch, 11, 9000)
+    lens[3] = 30000  # split over many ranges: the merge finds its chunks under every mapping
+    q8, q_scale, kv, block_ids, nblocks = _case(num_batch, 1, lens, block_size, heads, False)
+    kv_dev = kv.to(torch.float8_e4m3fn).cuda()
+    ks, vs = (torch.rand(1) + 0.5).cuda(), (torch.rand(1) + 0.5).cuda()
+    lens_in = (lens + 1).cuda()
+    tm = hpc.get_attention_decode_task_workspace(num_batch, int(lens.max()) + 1, num_head_kv, 64)
+    hpc.assign_attention_decode_task(lens_in, tm, num_head_kv, 1, True, 64)
+    qd, qs, bd = q8.cuda(), q_scale.cuda(), block_ids.cuda()
+
+    def call():
+        y = hpc.attention_decode_fp8(qd, kv_dev[:, 0, :block_size], kv_dev[:, 1, :block_size], bd, lens_in, qs, ks, vs, mtp=0,
+                                     new_kv_included=True, quant_type=hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR,
+                                     splitk=True, task_map=tm)
+        torch.cuda.synchronize()
+        return y
+
+    ref = call()
+    variants = [{36: 1}, {36: 2}, {36: 3}] + ([{38: 16205392}, {36: 4}] if num_head_kv == 8 else [])
+    for keys in variants:
+        for k, v in keys.items():
+            dev_set(k, v)
+        try:
+            assert torch.equal(call(), ref), keys
+        finally:
+            for k in keys:
+                dev_set(k, 0)
+
+
 @pytest.mark.gpu
 def test_attn_fp8_two_graphs_captured_before_any_replay():
     """The usual serving pattern: one hipGraph per batch size, all captured first, replayed later in any order.  The

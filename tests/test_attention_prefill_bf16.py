@@ -92,3 +92,30 @@ def test_attention_prefill_bf16_contiguous(seq, hq, hkv, use_output):
     my = hpc.attention_prefill_bf16(q.cuda(), k.cuda(), v.cuda(), torch.tensor(seq, dtype=torch.int32).cuda(), cu.cuda(),
                                     max(seq), output=out)
     assert allclose(gt, my.cpu(), atol=0.016, rtol=0.016)
+
+
+@pytest.mark.dev
+@pytest.mark.gpu
+@pytest.mark.parametrize("hq,hkv,block_size", [(8, 1, 64), (16, 4, 32), (32, 4, 16)])
+def test_prefill_bf16_transposing_reads_equal_the_perm_form(hq, hkv, block_size):
+    """Round 5: V^T operands come out of LDS through ds_read_b64_tr_b16 (swizzled unpadded V stage, output block u = dims
+    16 u .. 16 u + 15) instead of 16-byte row reads + v_perm_b32 (output block jj = dims 8 i + jj; development key 46 = 1).
+    Both forms feed every MFMA the same eight tokens per k-group in the same order, so every output element is the same
+    sum in the same order: `torch.equal`, ragged lengths and page sizes included."""
+    import hpc
+    from utils import dev_set
+
+    seq_q, seq_kv = [37, 200, 1, 129], [100, 200, 700, 129]
+    q, kv, cu, bid, lens = paged_case(seq_q, seq_kv, hq, hkv, block_size)
+    kvd = kv.cuda()
+    args = (q.cuda(), kvd[:, 0], kvd[:, 1], cu.cuda(), bid.cuda(), lens.cuda(), max(seq_q))
+    new = hpc.attention_with_kvcache_prefill_bf16(*args)
+    dev_set(46, 1)
+    try:
+        old = hpc.attention_with_kvcache_prefill_bf16(*args)
+    finally:
+        dev_set(46, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(new, old)
+    gt = oattn.ref_prefill_bf16(q, kv[:, 0], kv[:, 1], cu, bid, lens)
+    assert allclose(gt, new.cpu(), atol=0.016, rtol=0.016)

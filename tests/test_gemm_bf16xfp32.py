@@ -80,3 +80,50 @@ def test_gemm_bf16xfp32_checks():
     w = torch.zeros(64, 128, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(RuntimeError):
         hpc.gemm_bf16xfp32(x.float(), w, w, 1 / 256)
+
+
+@pytest.mark.dev
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(304, 192, 4096), (1000, 256, 2048), (4096, 256, 4096), (2100, 128, 7168)])
+def test_gemm_bf16xfp32_tile_kernel_equals_the_direct_load_kernel(m, n, k):
+    """Round 5: above 256 tokens the LDS-staged tile kernel (64 weight rows x 128 tokens, every operand through LDS) replaced
+    the 64 x 64 kernel that loaded operands straight into MFMA layout (development key 40 = 1).  Same k order, same split
+    points, same fixed-order reduction: bit-identical at equal split counts (the count is a function of (m, n, k) only)."""
+    import hpc
+    from utils import dev_set
+
+    x, w = make(m, n, k, seed=7)
+    wh, wl = orc.split_weight(w)
+    d = [t.cuda() for t in (x, wh, wl)]
+    new = hpc.gemm_bf16xfp32(*d, 1 / 256, True, True, None)
+    dev_set(40, 1)
+    try:
+        old = hpc.gemm_bf16xfp32(*d, 1 / 256, True, True, None)
+    finally:
+        dev_set(40, 0)
+    assert torch.equal(new, old)
+    assert allclose(orc.two_plane(x, wh, wl, 1 / 256), new.cpu(), rtol=1e-4, atol=2e-3)
+
+
+def test_gemm_bf16xfp32_split_rule():
+    """CPU: `hpc_gemm_bf16xfp32_splits` (callers size the split workspace from it).  Above 256 tokens: tiles of 64 weight rows
+    x 128 tokens, splits until there is one workgroup per CU (256), at most 8, every split keeps >= 256 of k; a launch with
+    one to two workgroups per CU unsplit is split once; no split-K -> 1."""
+    import ctypes
+    from pathlib import Path
+
+    lib = ctypes.CDLL(str(Path(__file__).resolve().parent.parent / "hpc-ops_amd" / "hpc" / "libhpc_amd.so"))
+    f = lib.hpc_gemm_bf16xfp32_splits
+    f.argtypes = [ctypes.c_int] * 4
+    f.restype = ctypes.c_int
+    assert f(4096, 256, 4096, 0) == 1
+    assert f(4096, 256, 4096, 1) == 2      # 128 tiles
+    assert f(2048, 256, 4096, 1) == 4      # 64 tiles
+    assert f(1024, 256, 4096, 1) == 8      # 32 tiles: the cap
+    assert f(304, 256, 4096, 1) == 8       # 12 tiles: the cap, not 16
+    assert f(8192, 256, 7168, 1) == 2      # 256 tiles: one more split for two workgroups per CU
+    assert f(16384, 256, 4096, 1) == 1     # 512 tiles
+    assert f(4096, 256, 512, 1) == 2       # every split keeps 256 of k ...
+    assert f(4096, 256, 256, 1) == 1       # ... or there is none
+    for m in (1, 16, 64, 256):             # the skinny kernels keep their own rule
+        assert 1 <= f(m, 256, 4096, 1) <= 16
