@@ -41,6 +41,9 @@ namespace hpc {
 namespace decode {
 
 using sched::kTaskStride;
+#ifdef HPC_DEV
+__device__ int g_ticket_overruns;  // arrivals whose ticket exceeded the request's chunk count (a counter not zero on entry)
+#endif
 
 struct Args {
   const void* q;
@@ -536,6 +539,9 @@ __global__ __launch_bounds__(kThreads, kNB == 1 ? 2 : 1) void decode_kernel(cons
         __syncthreads();
         ticket = s_ticket;
       }
+#ifdef HPC_DEV
+      if ((kSolo ? lane == 0 : tid == 0) && ticket > nchunks) atomicAdd(&g_ticket_overruns, 1);  // the counter was not zero on entry
+#endif
       if (ticket == nchunks) {
         const int fb = bin - ichunk;
         auto merge_row = [&](int nb, int row16, int c8) {
@@ -828,6 +834,18 @@ extern "C" int64_t hpc_attention_decode_workspace_zero_bytes(void) { return hpc:
 // development (tools/prof_decode.py): device buffer [workgroups][4 waves][12] uint64 that the profiling build of the
 // second-generation kernel fills with per-wave s_memtime sums; null = the shipped kernel
 #ifdef HPC_DEV
+// development build: number of arrivals (either kernel generation) that drew a ticket above their request's chunk count
+// since the last reset - a stale arrival counter (a caller-owned workspace that was never zeroed makes the
+// split requests' rows of y silently stay unwritten).  Synchronises the device; < 0 on error.
+extern "C" int hpc_dev_decode_ticket_overruns(int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(hpc::decode::g_ticket_overruns), sizeof(int)) != hipSuccess) return -1;
+  const int zero = 0;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(hpc::decode::g_ticket_overruns), &zero, sizeof(int)) != hipSuccess) return -1;
+  const int v2 = hpc::decode2::ticket_overruns(reset != 0);
+  return v2 < 0 ? -1 : v + v2;
+}
 static void* g_decode_prof = nullptr;
 extern "C" int hpc_dev_decode_prof_buffer(void* p) {
   g_decode_prof = p;

@@ -48,6 +48,12 @@ int64_t workspace_bytes(int num_wg);  // partial slots (2 per workgroup x 2 head
 // even number of kv heads, <= 16 q rows per kv head, <= 1024 requests).
 int mode_of(const Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride);
 int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStream_t stream);
+#ifdef HPC_DEV
+// development build: arrivals that drew a ticket ABOVE their request's chunk count since the last reset - the signature of
+// an arrival counter that was not zero on entry (the zero-bytes contract of the workspace was broken: the last arriver is
+// never recognised and the request's rows of y stay unwritten).  Synchronises the device.
+int ticket_overruns(bool reset);
+#endif
 
 }  // namespace decode2
 }  // namespace hpc

@@ -61,6 +61,9 @@
 namespace hpc {
 namespace decode2 {
 
+#ifdef HPC_DEV
+__device__ int g_ticket_overruns;  // see ticket_overruns() in attention_decode_v2.h
+#endif
 constexpr int kThreads = 256;
 constexpr int kWaves = 4;
 constexpr float kNegInf = -__builtin_inff();
@@ -695,6 +698,9 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     }
     __syncthreads();
     const int t0 = s_ticket[0], t1 = s_ticket[1];
+#ifdef HPC_DEV
+    if (tid == 0 && (t0 > p0_n || (np > 1 && t1 > p1_n))) atomicAdd(&g_ticket_overruns, 1);  // a counter was not zero on entry
+#endif
     if (t0 == p0_n) merge_request(p0_b, p0_first, p0_n);
     if (np > 1 && t1 == p1_n) merge_request(p1_b, p1_first, p1_n);
     np = 0;
@@ -1174,6 +1180,16 @@ int mode_of(const Args& a, int num_head_q, int block_size, int64_t k_head_stride
   const bool quad = !a.bf16 && (a.num_head_kv % 4) == 0 && a.num_seq_q * group <= 8 && hpc_dev_tuning_get(29) == 2;
   return quad ? 2 : 1;
 }
+
+#ifdef HPC_DEV
+int ticket_overruns(bool reset) {
+  int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ticket_overruns), sizeof(int)) != hipSuccess) return -1;
+  const int zero = 0;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_ticket_overruns), &zero, sizeof(int)) != hipSuccess) return -1;
+  return v;
+}
+#endif
 
 int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStream_t stream) {
   char* ws = static_cast<char*>(partials);

@@ -513,11 +513,13 @@ extern "C" int hpc_gemm_bf16xfp32_splits(int m, int n, int k, int use_splitk) {
   if (m <= 0 || n <= 0 || k <= 0) return 1;
   if (!use_splitk) return 1;
   int s = 1;
+  int dev = 0;
+  const int cus = hipGetDevice(&dev) == hipSuccess && hpc_get_cu_count(dev) > 0 ? hpc_get_cu_count(dev) : 256;
   if (m <= kSkinnyMaxM) {
     const int tm = skinny_tm(m);
     const long tiles = static_cast<long>((m + tm - 1) / tm) * (n / 16);
     // ~one workgroup per CU; every wave keeps at least one 64-k step
-    while (s < 16 && tiles * s < 256 && (k >> 6) / (s * 2) >= 4) s *= 2;
+    while (s < 16 && tiles * s < cus && (k >> 6) / (s * 2) >= 4) s *= 2;
     return s;
   }
   // m > 256: the tile kernel, 64 weight rows x 128 tokens.  Splits until there is ONE workgroup per CU, at most 8 (every split
@@ -525,9 +527,10 @@ extern "C" int hpc_gemm_bf16xfp32_splits(int m, int n, int k, int use_splitk) {
   // m = 1024 29.2 us with 16 splits, 19.9 with 8 - profiles/round5_router_tile_ab.txt); a launch that has between one and two
   // workgroups per CU without splitting is split once more (two resident workgroups per CU overlap each other's load phases).
   const long tiles = static_cast<long>((m + 127) / 128) * (n / 64);
-  const int cap = hpc_dev_tuning_get(45) > 0 ? hpc_dev_tuning_get(45) : 8;  // development key 45: cap on the split count above m = 256
-  while (s < cap && tiles * s < 256 && k / (s * 2) >= 256) s *= 2;
-  if (tiles >= 256 && tiles < 512 && s == 1 && k >= 512) s = 2;
+  // development key 45: cap on the split count above m = 256 (never above the 16 planes the reduce sums)
+  const int cap = hpc_dev_tuning_get(45) > 0 ? (hpc_dev_tuning_get(45) < 16 ? hpc_dev_tuning_get(45) : 16) : 8;
+  while (s < cap && tiles * s < cus && k / (s * 2) >= 256) s *= 2;
+  if (tiles >= cus && tiles < 2 * cus && s == 1 && k >= 512) s = 2;
   return s;
 }
 
@@ -545,6 +548,7 @@ extern "C" int hpc_gemm_bf16xfp32_async(void* y_ptr, void* splitk_y_ptr, void* s
     return HPC_ERR_UNSUPPORTED;  // 32-bit buffer offsets
   if (splits > 1 && (!splitk_y_ptr || !split_flag_ptr)) return HPC_ERR_INVALID;
   if (splits > (k >> 6)) return HPC_ERR_INVALID;
+  if (splits > 16) return HPC_ERR_INVALID;  // the last arriver of every kernel form sums at most 16 partial planes
   if (splits > 1 && static_cast<int64_t>(splits) * m * n * 4 > 0xfffffff0ll) return HPC_ERR_UNSUPPORTED;
   Args a;
   a.x = static_cast<const uint16_t*>(x_ptr);

@@ -42,9 +42,9 @@
 //   key 36 decode v2: head pair of the SECOND workgroup of every CU = pair ^ (value - 1) (0 = the product's rule: the slice across
 //          byte-address bit 9; 1 = off, both workgroups of a CU on the same slice)
 //   key 37 decode v2: value = s + 1: every workgroup streams slice s of the token rows (timing only - wrong results)
-//   key 40 router GEMM: 1 = the 64 x 64 kernel at every m > 256 (rounds 1-4) instead of the LDS-staged tile kernel above m = 512
+//   key 40 router GEMM: 1 = the 64 x 64 kernel at every m > 256 (rounds 1-4) instead of the LDS-staged tile kernel (which serves every m > 256)
 //   key 41 router GEMM tile kernel: bit 0 = no weight loads, bit 1 = no activation loads (timing only - wrong results)
-//   key 45 router GEMM: cap on the split count above m = 256 (default 8)
+//   key 45 router GEMM: cap on the split count above m = 256 (default 8, clamped to the 16 planes the reduce sums)
 //   key 46 bf16 prefill: 1 = V^T operands built with v_perm_b32 (rounds 3-4) instead of the transposing LDS read
 //   others: see the launchers that read them
 #pragma once

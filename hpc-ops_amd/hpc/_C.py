@@ -46,6 +46,7 @@ _sig("hpc_get_cu_count", I, I)
 if DEV_BUILD:  # the product does not export them
     _sig("hpc_dev_tuning_set", I, I, I)
     _sig("hpc_dev_tuning_get", I, I)
+    _sig("hpc_dev_decode_ticket_overruns", I, I)
 _sig("hpc_fused_rmsnorm_with_scale_async", I, P, P, P, P, P, P, F, I, I, I, P)
 IP = ctypes.POINTER(c_int)
 _sig("hpc_attention_decode_num_bins", I, I, I)

@@ -45,6 +45,7 @@ setup(
     exclude_package_data={"hpc": ["*_dev.so"]},
     python_requires=">=3.10",
     install_requires=["torch"],
+    extras_require={"test": ["pytest>=7", "pytest-xdist>=3", "pytest-timeout", "numpy"]},  # pytest.ini: addopts = -n 6
     cmdclass={"build_py": BuildNative},
     zip_safe=False,
 )

@@ -86,22 +86,31 @@ int hpc_assign_attention_decode_task_async(int* task_map, const int* num_seq_kvc
  * q [B*Sq, Hq, 128] (row stride ldQ elements), kcache/vcache logical [blocks, block_size, Hkv, 128]
  * with element strides (block, token, head), block_ids int32 [B, num_seq_max_blocks],
  * y bf16 [B*Sq, Hq, 128] (row stride ldY).  `task_map_ptr` is a task map produced by the
- * scheduler above for the same num_seq_kvcache / num_seq_q / new_kv_included; `num_bins` must be
- * its header[1].  `workspace` holds the arrival counters of split requests and the fp32 split-KV partials:
+ * scheduler above for the same num_seq_kvcache / num_seq_q / new_kv_included.  `num_bins` is the UPPER bound the
+ * launch and the workspace are sized with - hpc_attention_decode_num_bins(num_seq_q, device), the value the torch
+ * binding passes - NOT the map's header[1]: the scheduler plans a batch with little work on fewer bins
+ * (hpc_attention_decode_effective_bins) and records the count it used in header[1] <= num_bins; the kernels read it
+ * from there.  A caller that passed header[1] as num_bins would cap the head-pair kernel's grid at that count instead of
+ * two workgroups per CU.
+ * `workspace` holds the arrival counters of split requests and the fp32 split-KV partials:
  * hpc_attention_decode_workspace_bytes bytes.  Its first hpc_attention_decode_workspace_zero_bytes() bytes (the
  * counters: a fixed place and size whatever the shapes of the call) must be ZERO the first time the buffer is
  * used - like the reference's split_flag, which its entry allocates zeroed (src/attention/entry.cc:690-694) - and
  * every call leaves them zero again, so one buffer per stream can be reused call after call, with any sequence
  * of shapes, and inside a captured hipGraph; the rest needs no initialisation (the reference allocates
  * lse/split_out per call, src/attention/entry.cc:492-499; here it is 2 slots per workgroup instead of splitk
- * slots per request).  One buffer must not be used by two calls that may run concurrently (two streams: two
- * buffers).  The split-KV combine runs inside the call: a second kernel on the same stream for the
- * first-generation kernels, the last-arriving chunk of a request for the second-generation FP8 kernel
- * (reference: static_splitk_kernels.cuh:362-377).
+ * slots per request).  The zero-bytes contract applies to EVERY decode path (since round 5 the first-generation
+ * kernels take their tickets there too): a counter that is not zero on entry - a caller-owned buffer that was never
+ * cleared, or one left behind by a launch that faulted - means the last arriver of a split request is never
+ * recognised and that request's rows of y are not written.  One buffer must not be used by two calls that may run
+ * concurrently (two streams: two buffers).  The split-KV combine runs inside the launch on both kernel generations:
+ * the chunk of a request that arrives LAST merges all of them (reference: static_splitk_kernels.cuh:362-377); there
+ * is no second kernel.
  * num_seq_kvcache_ptr (device int32 [num_batch]) / new_kv_included as in the reference launchers (decode.h:17-35): with
  * them, NHD pages (adjacent kv heads contiguous) with an even head count and <= 16 q rows per kv head take the
- * second-generation kernel (attention_decode_v2.hip), which plans from the lengths and does not read the task map;
- * NULL lengths = the task map drives the first-generation kernel. */
+ * second-generation kernel (attention_decode_v2.hip), which plans its ranges in closed form from the lengths and takes
+ * from the task map only header int 6 (the scheduler call's min_process_len: the lower bound of its split granularity);
+ * NULL lengths = the task map's bins drive the first-generation kernel. */
 int64_t hpc_attention_decode_workspace_bytes(int num_bins, int num_batch, int num_head_kv,
                                              int num_seq_q, int heads_per_group);
 int64_t hpc_attention_decode_workspace_zero_bytes(void);

