@@ -74,17 +74,21 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // r = bf16(sum + residual) -> residual_out; y = bf16(float(r) * rsqrt(mean(r^2) + eps) * w)
 // acc[i][0..7] hold the all-reduced row (fp32, already rounded to bf16 precision by the caller if
 // the mode requires it); returns the normalised row packed in `out`.
+// `rpre` / `wpre` (round 6): the residual / weight vectors of the row when the caller has them in registers already - the
+// high-throughput body issues the residual loads TOGETHER with the peers' rows (one memory round trip per row instead of two
+// dependent ones) and loads the weight vectors once per workgroup; null = load here (the low-latency bodies: their rows
+// arrive by polling, the residual load overlaps the poll rounds).
 template <int kVec>
 __device__ __forceinline__ void residual_rmsnorm(float (&acc)[kVec][8], int nvec, int hidden,
                                                  const uint16_t* res_row, uint16_t* res_out_row,
                                                  const uint16_t* w, float eps, u32x4 (&out)[kVec],
-                                                 float* red) {
+                                                 float* red, const u32x4* rpre = nullptr, const u32x4* wpre = nullptr) {
   float ss = 0.f;
 #pragma unroll
   for (int i = 0; i < kVec; ++i) {
     const int v = threadIdx.x + i * kThreads;
     if (v < nvec) {
-      const u32x4 rv = ld16(res_row + v * 8);
+      const u32x4 rv = rpre ? rpre[i] : ld16(res_row + v * 8);
       u32x4 ro;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -105,7 +109,7 @@ __device__ __forceinline__ void residual_rmsnorm(float (&acc)[kVec][8], int nvec
   for (int i = 0; i < kVec; ++i) {
     const int v = threadIdx.x + i * kThreads;
     if (v < nvec) {
-      const u32x4 wv = ld16(w + v * 8);
+      const u32x4 wv = wpre ? wpre[i] : ld16(w + v * 8);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         out[i][j] = pack_bf16x2(acc[i][2 * j] * rms * bf16lo_to_f32(wv[j]),
@@ -177,9 +181,27 @@ template <int kWs, int kVec>
 __device__ __forceinline__ void ht_body(const HtArgs& a, int bid, int nblk, float* red) {
   const int nvec = a.hidden >> 3;
   const unsigned row_bytes = static_cast<unsigned>(a.hidden) * 2u;
+  // the weight row does not depend on the peers: its vectors are loaded once per workgroup, in flight across the opening
+  // barrier (bounded loads: lanes past the row end read 0 and are never used).  Not with 8 vectors per thread beside the
+  // rows of many peers (x[4][8] + acc[8][8] + residual: the registers of two workgroups per CU are spent).
+  constexpr bool kHoistW = (kVec == 4 && kWs <= 4) || (kWs > 0 && kWs <= 2);
+  u32x4 wv[kVec];
+  if constexpr (kHoistW) {
+    const auto rw = make_rsrc(uniform_ptr(a.w), row_bytes);
+#pragma unroll
+    for (int i = 0; i < kVec; ++i) wv[i] = buf_ld16<0>(rw, (threadIdx.x + i * kThreads) * 16, 0);
+  }
   signal_barrier(a, bid);  // every rank's input is in place
   for (int row = bid; row < a.rows; row += nblk) {
     const long roff = static_cast<long>(row) * a.hidden;
+    // the residual row rides with the peers' rows: ONE memory round trip per row (round 5 loaded it inside the
+    // normalisation, behind the sum: two dependent round trips per row - ws = 1, T = 4096: 93.6 us for 268 MB)
+    u32x4 rv[kVec];
+    {
+      const auto rr = make_rsrc(uniform_ptr(a.residual + roff), row_bytes);
+#pragma unroll
+      for (int i = 0; i < kVec; ++i) rv[i] = buf_ld16<0>(rr, (threadIdx.x + i * kThreads) * 16, 0);
+    }
     float acc[kVec][8];
 #pragma unroll
     for (int i = 0; i < kVec; ++i)
@@ -224,7 +246,8 @@ __device__ __forceinline__ void ht_body(const HtArgs& a, int bid, int nblk, floa
       }
     }
     u32x4 y[kVec];
-    residual_rmsnorm(acc, nvec, a.hidden, a.residual + roff, a.out_residual + roff, a.w, a.eps, y, red);
+    residual_rmsnorm(acc, nvec, a.hidden, a.residual + roff, a.out_residual + roff, a.w, a.eps, y, red, rv,
+                     kHoistW ? wv : nullptr);
     const int nws = kWs > 0 ? kWs : a.ws;
 #pragma unroll
     for (int i = 0; i < kVec; ++i) {
@@ -509,11 +532,15 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_high_throughput_grid(int world_size, i
   // only (num_max_blocks, world size, pad capacity) - never of this rank's row count (the reference
   // launches num_max_blocks blocks for the same reason, high_throughput.cu:135-150).  One row is
   // only 2 * hidden bytes per peer, so the reference's SM-count-sized default leaves most of an
-  // MI355X idle: at least one workgroup per CU (development key 11 = n replaces the floor of 256 -
+  // MI355X idle: at least TWO workgroups per CU (development key 11 = n replaces the floor of 512 -
   // the tests that run two ranks on ONE GPU need both ranks' grids co-resident).  Block b posts into
   // words [b * ws, (b + 1) * ws) of a pad.
+  // Round 6: TWO workgroups per CU (512) - the kernels hold <= 256 registers and a few bytes of LDS, so two 4-wave workgroups
+  // of a rank are resident per CU, and a row is one memory round trip + two barriers: the second workgroup's round trip
+  // runs under the first one's reduction (ws = 1, H 8192, T 4096: see profiles/round6_allreduce_ab.txt).  A constant,
+  // not the device's CU count: the value must be the same on every rank.
   const int floor_dev = hpc_dev_tuning_get(11);
-  const int floor_blocks = floor_dev > 0 ? floor_dev : 256;
+  const int floor_blocks = floor_dev > 0 ? floor_dev : 512;
   int grid = num_max_blocks > floor_blocks ? num_max_blocks : floor_blocks;
   if (grid > signal_pad_words / world_size) grid = signal_pad_words / world_size;
   return grid > 0 ? grid : HPC_ERR_INVALID;

@@ -16,7 +16,7 @@
 //   key 7  block-sparse prefill row mapping (1 head-major, 2 position-major)
 //   key 9  fused all-reduce (high throughput): 1 = runtime-world-size kernel at any world size
 //   key 10 fused all-reduce: bounded spins give up after 2^value rounds (default 2^22)
-//   key 11 fused all-reduce (high throughput): minimum grid (default 256 = one workgroup per CU)
+//   key 11 fused all-reduce (high throughput): minimum grid (default 512 = two workgroups per CU)
 //   key 12 decode fp8: 1 = never the head-pair kernel (attention_decode_v2.hip)
 //   key 14 decode fp8 v2: workgroup count override
 //   key 15 decode fp8 v2: 1 = no KV loads (compute-only timing)

@@ -195,7 +195,7 @@ def test_allreduce_rmsnorm_world1():
 def test_allreduce_rmsnorm_world2_shared_gpu():
     """two ranks on the single GPU of the test box: exercises IPC handles, pointer tables, signal
     barriers and the Lamport protocol across processes (the 8-GPU run is the driver's).  Both ranks' grids
-    must be co-resident on the one GPU, so the high-throughput grid floor (one workgroup per CU) is lifted:
+    must be co-resident on the one GPU, so the high-throughput grid floor (two workgroups per CU) is lifted:
     development key 11 = 1 -> grid = num_max_blocks like the reference."""
     _spawn(2, tuning="11=1")
 
@@ -271,7 +271,7 @@ def test_allreduce_rmsnorm_ws8_loopback(world_size):
     dev = torch.device("cuda", 0)
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     dev_set(10, 24)  # bounded spins give up after 2^24 rounds: a lost rendezvous is a reported timeout within seconds
-    dev_set(11, 1)   # high-throughput grid = num_max_blocks (the product floor is one workgroup per CU and rank)
+    dev_set(11, 1)   # high-throughput grid = num_max_blocks (the product floor is two workgroups per CU and rank)
     try:
         assert lib.hpc_allreduce_reset_timeouts() == 0
         for mode, N, H, nblk, iters in (("ht", 64, 8192, 4, 3), ("ht", 61, 5120, 3, 2), ("ht_uneven", 96, 4096, 4, 2),
@@ -446,7 +446,7 @@ def test_high_throughput_grid_is_rank_invariant():
     and is clamped to the pad (72 * CUs words from MulticastHandle; fewer CUs on a partitioned device)."""
     lib = ctypes.CDLL(str(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so"))
     f = lib.hpc_fuse_allreduce_rmsnorm_high_throughput_grid
-    assert f(8, 64, 72 * 256) == 256 and f(8, 2048, 72 * 256) == 2048
+    assert f(8, 64, 72 * 256) == 512 and f(8, 2048, 72 * 256) == 2048  # floor: two workgroups per CU
     assert f(8, 64, 72 * 16) == 72 * 16 // 8  # small pad (partitioned device): clamped, not overrun
     assert f(2, 64, 1) < 0 and f(9, 64, 1024) < 0 and f(2, 0, 1024) < 0
 

@@ -7,6 +7,10 @@ the two GEMMs:
      clock, which is calibrated against HIP events in the same run;
   2. sysfs (pp_dpm_sclk / hwmon freq1_input, power1_average | power1_input) sampled by a host thread every ~20 ms;
   3. `amd-smi metric` / `rocm-smi` once during the load, when the tools answer for an ordinary user.
+And the ceiling those clocks imply, measured instead of computed: tools/probes/probe_mfma.hip runs NOTHING BUT back-to-back
+v_mfma_f32_16x16x128_f8f6f4 (the instruction of the grouped GEMMs; register operands, no memory, no LDS, no VALU, 2 waves per
+SIMD on every CU) with pseudo-random fp8 operands and with all-zero operands: the TFLOP/s the chip sustains on this instruction
+under its power limit - the denominator a software schedule can actually be held against.
 usage: python tools/moe_clock.py [out.json]      (writes profiles/round6_moe_clock.json by default)"""
 import ctypes, glob, json, os, subprocess, sys, threading, time
 from pathlib import Path
@@ -22,6 +26,13 @@ so = bindir / "libprobe_clock.so"
 src = ROOT / "tools" / "probes" / "probe_clock.hip"
 if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", str(src), "-o", str(so)])
+so2 = bindir / "libprobe_mfma.so"
+src2 = ROOT / "tools" / "probes" / "probe_mfma.hip"
+if not so2.exists() or so2.stat().st_mtime < src2.stat().st_mtime:
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", str(src2), "-o", str(so2)])
+mfma = ctypes.CDLL(str(so2))
+mfma.mfma_probe_launch.restype = ctypes.c_int
+mfma.mfma_probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 probe = ctypes.CDLL(str(so))
 probe.clock_probe_launch.restype = ctypes.c_int
 probe.clock_probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
@@ -188,6 +199,33 @@ r["us_per_fused_op_alone"] = round(usz, 1)
 results["cases"].append(r)
 del mz, gz
 
+# ---- the matrix pipe on its own: what the power limit leaves of the 5 PF -------------------------------------------------
+cus = torch.cuda.get_device_properties(0).multi_processor_count
+sink = torch.zeros(16, dtype=torch.float32, device=dev)
+for label, mode in (("pure MFMA loop (16x16x128 f8f6f4), pseudo-random fp8 operands", 0), ("pure MFMA loop (16x16x128 f8f6f4), all-zero operands", 1)):
+    def run(iters):
+        assert mfma.mfma_probe_launch(sink.data_ptr(), cus, iters, mode, torch.cuda.current_stream().cuda_stream) == 0
+    run(200); torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record(); run(4000); t1.record(); torch.cuda.synchronize()
+    per_iter_ms = t0.elapsed_time(t1) / 4000
+    iters = int(300.0 / per_iter_ms)
+    holder = {}
+
+    def mfma_work():
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); run(iters); b.record()
+        holder["ev"] = (a, b)
+
+    r = measure(label, mfma_work, iters * per_iter_ms, srcs, with_smi=(mode == 0))
+    ms = holder["ev"][0].elapsed_time(holder["ev"][1])
+    flops = cus * 8.0 * iters * 32 * 2 * 16 * 16 * 128
+    r["tflops"] = round(flops / ms / 1e9, 1)
+    r["frac_of_5PF"] = round(flops / ms / 1e9 / 5000.0, 4)
+    r["tflops_at_2.4GHz_by_cycle_count"] = round(cus * 4 * 2048 * 2.4e9 / 1e12, 1)
+    print(json.dumps({"case": label, "tflops": r["tflops"], "clock_ghz": r["core_clock_ghz"]}), flush=True)
+    results["cases"].append(r)
+
 # a memory-bound kernel for contrast: the FP8 decode headline
 inp = bench.c3_inputs(dev)
 tm = hpc.get_attention_decode_task_workspace(bench.C3["batch"], int(inp["kv_lens"].max()), bench.C3["num_head_kv"], bench.C3["min_process_len"])
@@ -212,8 +250,12 @@ r["us_per_call_alone"] = round(usd, 1)
 results["cases"].append(r)
 
 moe = results["cases"][1]
+pure = next((c for c in results["cases"] if c["case"].startswith("pure MFMA loop") and "random" in c["case"]), {})
+pure0 = next((c for c in results["cases"] if c["case"].startswith("pure MFMA loop") and "zero" in c["case"]), {})
 results["summary"] = {"clock_ghz_under_moe": moe["core_clock_ghz"], "clock_ghz_idle_probe": results["cases"][0]["core_clock_ghz"],
                       "fp8_dense_peak_at_that_clock_tflops": round(5000.0 * moe["core_clock_ghz"] / 2.4, 1),
+                      "pure_mfma_random_operands_tflops": pure.get("tflops"), "pure_mfma_random_operands_clock_ghz": pure.get("core_clock_ghz"),
+                      "pure_mfma_zero_operands_tflops": pure0.get("tflops"), "pure_mfma_zero_operands_clock_ghz": pure0.get("core_clock_ghz"),
                       "note": "5 PF = 256 CUs x 4 SIMDs x 2048 flop/clk (16x16x128 f8f6f4: 65536 flop / 32 clk) x 2.4 GHz; the matrix pipe's rate scales with the core clock"}
 out_path.write_text(json.dumps(results, indent=1) + "\n")
 print("wrote", out_path)
