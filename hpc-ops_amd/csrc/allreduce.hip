@@ -132,37 +132,73 @@ struct HtArgs {
   long spin_limit;
   float eps;
   int rows, hidden, rank, ws;
+  int cas_barrier;  // development key 47 = 1: signal barriers with compare-and-swap (rounds 1-5)
+  int sig_stride;   // words between the flag groups of consecutive blocks (hpc_..._signal_stride: spread over the whole pad)
 };
 
-__device__ __forceinline__ void signal_barrier(const HtArgs& a, int bid) {
-  // block b of rank r <-> block b of every peer (reference high_throughput.cu:37-43, utils.cuh:571-590)
-  __syncthreads();
+__device__ __forceinline__ void signal_barrier(const HtArgs& a, int bid, bool closing = false) {
+  // block b of rank r <-> block b of every peer (reference high_throughput.cu:37-43, utils.cuh:571-590: CAS 0 -> 1 to post,
+  // CAS 1 -> 0 to consume, release / acquire at system scope).  Same protocol, same words, same values, but (round 6):
+  //  * no read-modify-write: a word has exactly ONE writer per direction (only the poster ever turns it 0 -> 1, only its
+  //    owner 1 -> 0), so "post" = wait until the word reads 0, then store 1, "consume" = wait until it reads 1, then store 0;
+  //  * no system-scope release / acquire FENCES.  On gfx950 a system-scope release is `buffer_wbl2 sc0 sc1` - write back
+  //    every dirty line of this XCD's L2 - and an acquire `buffer_inv sc0 sc1` - invalidate it: five to six L2-wide
+  //    operations per workgroup and call, serialised per L2 (measured at world size 1, profiles/round6_allreduce_ab.txt:
+  //    a call's fixed cost was 85 ns x the number of workgroups - 22 us at 256, 43 us at 512 - whatever the flag
+  //    instruction and wherever the flags sit; without them T = 512 29.4 -> 9.9 us, T = 4096 79.4 -> 49.9 us per call).  None of it is needed: everything a PEER reads was stored with sc0 sc1
+  //    (written through to its home memory, uncached there) and is read with sc0 sc1 loads (never served from a cache) -
+  //    the idiom of the Lamport path and of the decode kernels' split-KV partials.  So: every thread retires its own stores
+  //    (vmcnt(0): a write-through store is acknowledged by its home), the workgroup meets, and the flags are relaxed
+  //    system-scope accesses.  The rows this rank keeps to itself (out_residual: ordinary write-back stores) are nobody
+  //    else's business and reach memory at the end of the kernel like any other output.
   const int t = threadIdx.x;
-  if (t < a.ws) {
-    uint32_t* post = a.sig[t] + bid * a.ws + a.rank;  // my flag in peer t's pad
-    long spins = 0;
-    uint32_t expect = 0u;
-    while (!__hip_atomic_compare_exchange_strong(post, &expect, 1u, __ATOMIC_RELEASE, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_SYSTEM)) {
-      expect = 0u;
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > a.spin_limit) {
-        note_timeout(a.timeouts);
-        break;
+  if (kHpcDevBuild && a.cas_barrier) {  // development key 47 = 1: the form of rounds 1-5 (CAS loops, release / acquire fences) - A/B
+    if (closing) __threadfence_system();
+    __syncthreads();
+    if (t < a.ws) {
+      uint32_t* post = a.sig[t] + bid * a.sig_stride + a.rank;
+      long spins = 0;
+      uint32_t expect = 0u;
+      while (!__hip_atomic_compare_exchange_strong(post, &expect, 1u, __ATOMIC_RELEASE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+        expect = 0u;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > a.spin_limit) { note_timeout(a.timeouts); break; }
       }
-    }
-    uint32_t* wait = a.sig[a.rank] + bid * a.ws + t;  // peer t's flag in my pad
-    spins = 0;
-    expect = 1u;
-    while (!__hip_atomic_compare_exchange_strong(wait, &expect, 0u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_SYSTEM)) {
+      uint32_t* wait = a.sig[a.rank] + bid * a.sig_stride + t;
+      spins = 0;
       expect = 1u;
+      while (!__hip_atomic_compare_exchange_strong(wait, &expect, 0u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+        expect = 1u;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > a.spin_limit) { note_timeout(a.timeouts); break; }
+      }
+    }
+    __syncthreads();
+    return;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my write-through stores have been acknowledged by their home memory
+  __syncthreads();
+  if (t < a.ws) {
+    uint32_t* post = a.sig[t] + bid * a.sig_stride + a.rank;  // my flag in peer t's pad
+    long spins = 0;
+    while (__hip_atomic_load(post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {  // the peer has not consumed my last post yet
       __builtin_amdgcn_s_sleep(1);
       if (++spins > a.spin_limit) {
         note_timeout(a.timeouts);
         break;
       }
     }
+    __hip_atomic_store(post, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    uint32_t* wait = a.sig[a.rank] + bid * a.sig_stride + t;  // peer t's flag in my pad
+    spins = 0;
+    while (__hip_atomic_load(wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 1u) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > a.spin_limit) {
+        note_timeout(a.timeouts);
+        break;
+      }
+    }
+    __hip_atomic_store(wait, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
 }
@@ -256,8 +292,7 @@ __device__ __forceinline__ void ht_body(const HtArgs& a, int bid, int nblk, floa
         for (int p = 0; p < nws; ++p) st16_sys(a.out[p] + roff + v * 8, y[i]);
     }
   }
-  __threadfence_system();  // my rows are visible in every peer before I signal
-  signal_barrier(a, bid);  // every rank's rows have landed here
+  signal_barrier(a, bid, true);  // my rows are in every peer (write-through stores, retired inside); every rank's rows have landed here
 }
 template <int kWs, int kVec>
 __global__ __launch_bounds__(kThreads) void ht_kernel(const HtArgs a) {
@@ -532,18 +567,34 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_high_throughput_grid(int world_size, i
   // only (num_max_blocks, world size, pad capacity) - never of this rank's row count (the reference
   // launches num_max_blocks blocks for the same reason, high_throughput.cu:135-150).  One row is
   // only 2 * hidden bytes per peer, so the reference's SM-count-sized default leaves most of an
-  // MI355X idle: at least TWO workgroups per CU (development key 11 = n replaces the floor of 512 -
+  // MI355X idle: at least two workgroups per CU (development key 11 = n replaces the floor of 512 -
   // the tests that run two ranks on ONE GPU need both ranks' grids co-resident).  Block b posts into
   // words [b * ws, (b + 1) * ws) of a pad.
-  // Round 6: TWO workgroups per CU (512) - the kernels hold <= 256 registers and a few bytes of LDS, so two 4-wave workgroups
-  // of a rank are resident per CU, and a row is one memory round trip + two barriers: the second workgroup's round trip
-  // runs under the first one's reduction (ws = 1, H 8192, T 4096: see profiles/round6_allreduce_ab.txt).  A constant,
-  // not the device's CU count: the value must be the same on every rank.
+  // Round 6: TWO workgroups per CU (512).  The kernels hold <= 256 registers and a few bytes of LDS, so two 4-wave workgroups
+  // of a rank are resident per CU and one's memory round trip runs under the other's reduction.  Measured at ws = 1, H 8192
+  // (profiles/round6_allreduce_ab.txt, us per call inside a replay, floor 128 / 256 / 512): T = 512 13.0 / 9.9 / 8.9, T = 4096
+  // 72.9 / 49.9 / 45.3, T = 16384 376 / 218 / 196.  (With the system-scope fences of rounds 1-5 in the barriers every
+  // workgroup cost 85 ns of serialised L2 write-back / invalidate and 256 beat 512: 79 against 103 us at T = 4096.)
+  // A constant, not the device's CU count: the value must be the same on every rank.
   const int floor_dev = hpc_dev_tuning_get(11);
   const int floor_blocks = floor_dev > 0 ? floor_dev : 512;
   int grid = num_max_blocks > floor_blocks ? num_max_blocks : floor_blocks;
   if (grid > signal_pad_words / world_size) grid = signal_pad_words / world_size;
   return grid > 0 ? grid : HPC_ERR_INVALID;
+}
+
+// Words between the flag groups of consecutive blocks in a signal pad: block b uses words [b * stride, b * stride + ws).
+// Rounds 1-5 packed them (stride = ws, the reference's layout): the 256 blocks' flags of a rank sat in 1-8 KB of UNCACHED
+// memory, behind one or two memory channels.  Now the groups are spread over the whole pad in 64-byte units: stride =
+// floor(pad_words / grid) rounded down to a multiple of 16 words, never below ws.  Rank-invariant like the grid.  Measured
+// at ws = 1 it is worth little (T = 512: 31.4 -> 29.7 us per call with the old fences in place; the fixed cost was the
+// fences, see signal_barrier) - kept because with eight ranks every word is polled across a link and eight times as many
+// words share a line; development key 48 = 1 restores the packed layout.
+extern "C" int hpc_fuse_allreduce_rmsnorm_high_throughput_signal_stride(int world_size, int grid, int signal_pad_words) {
+  if (world_size < 1 || world_size > kMaxWs || grid <= 0 || signal_pad_words < grid * world_size) return HPC_ERR_INVALID;
+  if (hpc_dev_tuning_get(48) == 1) return world_size;  // development key 48 = 1: the packed layout of rounds 1-5 (A/B)
+  const int spread = (signal_pad_words / grid) & ~15;
+  return spread > world_size ? spread : world_size;
 }
 
 extern "C" int hpc_fuse_allreduce_rmsnorm_high_throughput_async(
@@ -577,6 +628,9 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_high_throughput_async(
   a.hidden = hidden_size;
   a.rank = rank;
   a.ws = world_size;
+  a.cas_barrier = hpc_dev_tuning_get(47) == 1;
+  a.sig_stride = hpc_fuse_allreduce_rmsnorm_high_throughput_signal_stride(world_size, grid, signal_pad_words);
+  if (a.sig_stride < world_size) return HPC_ERR_INVALID;
 #define HPC_HT_LAUNCH(WS)                                          \
   if (hidden_size <= 4 * kThreads * 8)                              \
     ht_kernel<WS, 4><<<grid, kThreads, 0, stream>>>(a);             \
@@ -712,6 +766,9 @@ extern "C" int hpc_dev_allreduce_loopback_ht(const void* const* peer_x, void* co
     a.hidden = hidden;
     a.rank = r;
     a.ws = world_size;
+    a.cas_barrier = hpc_dev_tuning_get(47) == 1;
+    a.sig_stride = hpc_fuse_allreduce_rmsnorm_high_throughput_signal_stride(world_size, grid, pad_words);
+    if (a.sig_stride < world_size) return HPC_ERR_INVALID;
   }
   const HtArgs* dev = loopback_args_on_device(host, world_size, stream);
   if (!dev) return HPC_ERR_LAUNCH;

@@ -46,6 +46,9 @@
 //   key 41 router GEMM tile kernel: bit 0 = no weight loads, bit 1 = no activation loads (timing only - wrong results)
 //   key 45 router GEMM: cap on the split count above m = 256 (default 8, clamped to the 16 planes the reduce sums)
 //   key 46 bf16 prefill: 1 = V^T operands built with v_perm_b32 (rounds 3-4) instead of the transposing LDS read
+//   key 47 fused all-reduce (high throughput): 1 = signal barriers of rounds 1-5 (compare-and-swap loops, system-scope release / acquire fences) instead of
+//          poll + store on relaxed accesses behind vmcnt(0)
+//   key 48 fused all-reduce (high throughput): 1 = signal flags packed at the start of the pad (rounds 1-5) instead of spread over it
 //   others: see the launchers that read them
 #pragma once
 

@@ -433,9 +433,12 @@ int64_t hpc_comm_region_bytes_left(const void* ptr);
  * High throughput: this rank owns `num_rows` token rows (slices may differ between ranks); peer_x_ptrs[p] /
  *   peer_out_ptrs[p] address those rows inside rank p's symmetric input / output buffers,
  *   peer_signal_ptrs[p] rank p's signal pad of `signal_pad_words` zero-initialised uint32 (block b uses
- *   words [b * world_size, (b + 1) * world_size)).  The barriers pair block b of every rank, so the grid is a
+ *   words [b * stride, b * stride + world_size), stride = hpc_fuse_allreduce_rmsnorm_high_throughput_signal_stride(
+ *   world_size, grid, signal_pad_words): the blocks' flag groups are spread over the whole pad in 64-byte units - packed
+ *   together they sit behind one channel of the uncached memory and every barrier access serialises there).
+ *   The barriers pair block b of every rank, so the grid is a
  *   function of rank-invariant inputs only: hpc_fuse_allreduce_rmsnorm_high_throughput_grid(world_size,
- *   num_max_blocks, signal_pad_words) = min(max(num_max_blocks, 256), signal_pad_words / world_size); all
+ *   num_max_blocks, signal_pad_words) = min(max(num_max_blocks, 512), signal_pad_words / world_size); all
  *   ranks must pass the same num_max_blocks and pad size.  -2 when the pad cannot hold one block.
  *   hidden <= 16384, world_size <= 8.  (The reference supports H in {4096,5120,7168}.)
  * Low latency (Lamport, token t owned by rank t % world_size): data_buffer_ptrs_dev = device int64
@@ -447,6 +450,7 @@ int64_t hpc_comm_region_bytes_left(const void* ptr);
  *   both entries return HPC_ERR_TIMEOUT instead of launching - after a lost peer the Lamport slots / signal
  *   pads hold leftovers, so the handles must be re-created; hpc_allreduce_reset_timeouts re-arms the entries. */
 int hpc_fuse_allreduce_rmsnorm_high_throughput_grid(int world_size, int num_max_blocks, int signal_pad_words);
+int hpc_fuse_allreduce_rmsnorm_high_throughput_signal_stride(int world_size, int grid, int signal_pad_words);
 int hpc_fuse_allreduce_rmsnorm_high_throughput_async(
     const void* const* peer_x_ptrs, void* const* peer_out_ptrs, void* const* peer_signal_ptrs,
     const void* residual_ptr, void* out_residual_ptr, const void* weight_ptr, float rms_norm_eps,

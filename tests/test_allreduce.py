@@ -454,29 +454,39 @@ def test_high_throughput_grid_is_rank_invariant():
 def test_signal_pad_and_lamport_slot_model():
     """CPU model of the index arithmetic of csrc/allreduce.hip for world sizes 2 / 4 / 8 (reference
     high_throughput.cu:37-43, low_latency.h:208-304): (1) signal pads - workgroup b of rank r posts word
-    b * ws + r of peer t's pad and consumes word b * ws + t of its own: for every grid the entry can pick, all
-    words lie inside the pad and every posted word is consumed by exactly one waiter; (2) Lamport slots - the
+    b * stride + r of peer t's pad and consumes word b * stride + t of its own (round 6: stride from
+    hpc_fuse_allreduce_rmsnorm_high_throughput_signal_stride - the flag groups spread over the whole pad in 64-byte
+    units, never closer than ws words): for every grid the entry can pick, all words lie inside the pad, no two
+    (block, rank) pairs share a word and every posted word is consumed by exactly one waiter; (2) Lamport slots - the
     rotation cur -> cur + 1 (mod 3) driven by buffer_flags, the slot cleaned for the next call, and the scatter /
     broadcast regions of a slot: for rows not divisible by ws every written byte stays inside its slot, the two
     regions never overlap, and a slot is only ever re-used two calls after it was cleaned."""
     lib = ctypes.CDLL(str(ROOT / "hpc-ops_amd" / "hpc" / "libhpc_amd.so"))
     grid_of = lib.hpc_fuse_allreduce_rmsnorm_high_throughput_grid
+    stride_of = lib.hpc_fuse_allreduce_rmsnorm_high_throughput_signal_stride
+    assert stride_of(8, 512, 72 * 256) == 32 and stride_of(1, 256, 72 * 256) == 64  # 128 / 256 B per block: the whole 72 KB pad
+    assert stride_of(8, 2048, 72 * 256) == 8 and stride_of(2, 300, 72 * 16) == 2      # no room to spread: packed
+    assert stride_of(8, 256, 8 * 255) < 0                                               # pad too small for the grid
     for ws in (2, 4, 8):
         for pad_words in (72 * 256, 72 * 16, 64):
             for nmb in (1, 16, 64, 300, 5000):
                 g = grid_of(ws, nmb, pad_words)
                 assert g > 0 and g * ws <= pad_words
+                st = stride_of(ws, g, pad_words)
+                assert st >= ws and (g - 1) * st + ws <= pad_words and (st == ws or st % 16 == 0)
+                blocks = sorted({0, 1, g // 2, g - 2, g - 1} & set(range(g)))
                 posts = {}
                 for r in range(ws):          # sender rank
                     for t in range(ws):      # pad owner
-                        for b in (0, g // 2, g - 1):
-                            w = b * ws + r
+                        for b in blocks:
+                            w = b * st + r
                             assert 0 <= w < pad_words
                             posts[(t, w)] = posts.get((t, w), 0) + 1
-                for t in range(ws):          # waiter: rank t consumes word b * ws + p of ITS pad for every peer p
+                assert all(v == 1 for v in posts.values())  # no two (block, sender) pairs share a word of a pad
+                for t in range(ws):          # waiter: rank t consumes word b * stride + p of ITS pad for every peer p
                     for p in range(ws):
-                        for b in (0, g // 2, g - 1):
-                            assert posts.pop((t, b * ws + p)) == 1
+                        for b in blocks:
+                            assert posts.pop((t, b * st + p)) == 1
                 assert not posts
         # Lamport slots: restate the flag updates of ll_scatter_kernel / ll_reduce_norm_kernel
         H = 8192

@@ -40,18 +40,21 @@ NWG, PERIOD = 8, 5000  # 8 workgroups, one stamp per 5000 reference ticks (50 us
 
 
 # ---- sysfs sampler -----------------------------------------------------------------------------------------------------
+# Every amdgpu card the box exposes is read: an ordinary user cannot tell from sysfs alone which card is the GPU the process
+# was given (the first run of this tool read a neighbour that sat at 1 414 MHz / 263 W through everything); the card whose
+# power MOVES with the load is the one.
 def sysfs_sources():
-    srcs = {}
+    cards = {}
     for card in sorted(glob.glob("/sys/class/drm/card*/device")):
         if not os.path.exists(card + "/pp_dpm_sclk"):
             continue
-        srcs["pp_dpm_sclk"] = card + "/pp_dpm_sclk"
+        srcs = {"pp_dpm_sclk": card + "/pp_dpm_sclk"}
         for hw in glob.glob(card + "/hwmon/hwmon*"):
             for f in ("freq1_input", "power1_average", "power1_input"):
                 if os.path.exists(f"{hw}/{f}"):
                     srcs[f] = f"{hw}/{f}"
-        break
-    return srcs
+        cards[card.split("/")[4]] = srcs
+    return cards
 
 
 def read_sysfs(srcs):
@@ -61,33 +64,40 @@ def read_sysfs(srcs):
             t = open(p).read()
         except OSError:
             continue
-        if k == "pp_dpm_sclk":
-            cur = [ln for ln in t.splitlines() if ln.strip().endswith("*")]
-            if cur:
-                r["sclk_mhz_dpm"] = float(cur[0].split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
-        elif k == "freq1_input":
-            r["sclk_mhz_hwmon"] = float(t) / 1e6
-        else:
-            r["power_w"] = float(t) / 1e6
+        try:
+            if k == "pp_dpm_sclk":
+                cur = [ln for ln in t.splitlines() if ln.strip().endswith("*")]
+                if cur:
+                    r["sclk_mhz_dpm"] = float(cur[0].split(":")[1].strip().rstrip("*").strip().lower().replace("mhz", ""))
+            elif k == "freq1_input":
+                r["sclk_mhz_hwmon"] = float(t) / 1e6
+            else:
+                r["power_w"] = float(t) / 1e6
+        except ValueError:
+            pass
     return r
 
 
 class Sampler(threading.Thread):
-    def __init__(self, srcs):
+    def __init__(self, cards):
         super().__init__(daemon=True)
-        self.srcs, self.rows, self.stop = srcs, [], False
+        self.cards, self.rows, self.stop = cards, {c: [] for c in cards}, False
 
     def run(self):
         while not self.stop:
-            self.rows.append(read_sysfs(self.srcs))
+            for c, srcs in self.cards.items():
+                self.rows[c].append(read_sysfs(srcs))
             time.sleep(0.02)
 
     def summary(self):
-        out = {"samples": len(self.rows)}
-        for k in ("sclk_mhz_dpm", "sclk_mhz_hwmon", "power_w"):
-            v = sorted(r[k] for r in self.rows if k in r)
-            if v:
-                out[k] = {"min": v[0], "median": v[len(v) // 2], "max": v[-1]}
+        out = {}
+        for c, rows in self.rows.items():
+            o = {"samples": len(rows)}
+            for k in ("sclk_mhz_dpm", "sclk_mhz_hwmon", "power_w"):
+                v = sorted(r[k] for r in rows if k in r)
+                if v:
+                    o[k] = {"min": v[0], "median": v[len(v) // 2], "max": v[-1]}
+            out[c] = o
         return out
 
 
