@@ -54,6 +54,13 @@ def _flags():
     ]
 
 
+# Per-file flags.  group_gemm_p8: no SLP vectorizer - in the k-loop of the ride-along body it pairs the four fused
+# multiply-adds of a block's rescale into <2 x float> operations that the backend splits again, each with a `v_mov` splat of
+# the scale in front (VALU instructions in the section that feeds the matrix pipe, 26 instead of 8 spilled SGPRs, 249
+# instead of 243 registers); the hand-written schedule wants the scalar form it was written in.
+_PER_FILE_FLAGS = {"group_gemm_p8": ["-fno-slp-vectorize"]}
+
+
 def _deps_newer(obj: Path, src: Path) -> bool:
     if not obj.exists():
         return True
@@ -66,7 +73,7 @@ def _compile(src: Path, force: bool, dev: bool = False) -> Path:
     obj = (OBJ / "dev" if dev else OBJ) / (src.stem + ".o")
     if not force and not _deps_newer(obj, src):
         return obj
-    cmd = ["hipcc"] + _flags() + (["-DHPC_DEV=1"] if dev else [])
+    cmd = ["hipcc"] + _flags() + (["-DHPC_DEV=1"] if dev else []) + _PER_FILE_FLAGS.get(src.stem, [])
     if src.stem == "library":
         h = _git_hash()
         cmd += ['-DHPC_VERSION_STR="0.0.1.dev0+g%s"' % h, '-DHPC_GIT_HASH_STR="%s"' % h]

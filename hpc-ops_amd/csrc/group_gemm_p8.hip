@@ -47,9 +47,18 @@ namespace {
 constexpr int kThreads = 512;
 constexpr int kBN = 256, kBM = 256, kBK = 128;
 constexpr int kUnit = 128 * kBK;       // 16 KB: 128 rows of 128 k-bytes
-constexpr int kBuf = 4 * kUnit;        // [U0 weights early | U1 tokens early | U2 tokens late | U3 weights late]
-constexpr int kXsOff = 2 * kBuf;       // 2 x 1 KB of token scales + 1 KB nobody reads (idle waves' scale DMA)
-constexpr int kLdsMain = kXsOff + 3 * 1024;
+// LDS image of the full / half-tile bodies (round 6): the two k-tile buffers INTERLEAVED per unit -
+//   [U0 b0 | U0 b1 | U3 b0 | U3 b1 | U1 b0 | U1 b1 | U2 b0 | U2 b1]   (U0 / U3 weights early / late, U1 / U2 tokens early / late)
+// so every weight operand read is ONE base register + a 16-bit immediate (< 64 KB) and every token operand read another:
+// rounds 2-5 laid the buffers end to end (the second one past the offset field of a ds_read) and paid a second set of base
+// registers - four VGPRs the ride-along rows (kExt) need.
+constexpr int kAOff = 0;               // weight units: unit u (0 = U0, 1 = U3), buffer p at kAOff + (2 u + p) * kUnit
+constexpr int kBOff = 4 * kUnit;       // token units: unit u (0 = U1, 1 = U2), buffer p at kBOff + (2 u + p) * kUnit
+constexpr int kXsOff = 8 * kUnit;      // 2 x 1 KB of token scales + 1 KB nobody reads (idle waves' scale DMA)
+// ride-along rows (kExt): 2 buffers x 16 token rows x 128 B, then 2 x 256 B of their scales (lanes 0-15 of a 64-lane piece)
+constexpr int kExtOff = kXsOff + 3 * 1024;
+constexpr int kExtXsOff = kExtOff + 2 * 2048;
+constexpr int kLdsMain = kExtXsOff + 2 * 256;
 // the tail body's layout (p8_tail_body): per-wave weight rings, two chunk buffers of token slabs, their scales
 constexpr int kTW = 3;                               // stages of a wave's weight ring = k-tiles of a token chunk
 constexpr int kTWOff = 0;                            // [8 waves][kTW][32 rows x 128 B]
@@ -82,9 +91,16 @@ struct IntC {
 //     weight tile).  A tail tile costs ~0.6 of a full one, and the dispatcher hands workgroups out in index order: with
 //     the cheap items last the end of the launch is filled evenly (the down GEMM of the MoE has only ~9.4 items per CU).
 //     Measured slower (the launcher says by how much): the tail tiles no longer meet their weight tile in L2.
+// Ride-along rows (round 6, `ext`): a group that ends in a SHORT tail - f full tiles and then t <= 16 f rows - has no tail
+// item at all: full tile mt carries rows [256 f + 16 mt, + 16) of the group as a 17th token block (p8_body<kExt>): one more
+// MFMA per wave and section instead of a tail tile that re-streams the 256 x K weight tile for a dozen rows (at 512 +- 22
+// routed rows per expert a tail tile cost ~0.6 of a full tile and the two GEMMs of the MoE ran 15-19 % behind exactly 512
+// rows per expert).  Longer tails keep their half-tile / tail-body item.
 // One round of lane-parallel loads per 64 groups; with <= 64 groups everything comes from one round.
+constexpr int kExtRows = 16;  // ride-along rows per full tile
 struct Item {
   int e, mt, wt, m_cnt, m0;  // group, 256-token tile of the group, weight tile, rows of the group, its first row
+  int ext0, ext_cnt;         // ride-along rows of this tile: group rows [ext0, ext0 + ext_cnt), ext_cnt = 0: none
   bool valid;
 };
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
@@ -96,19 +112,29 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
   return v;
 }
 __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, const int* cu_seqlens, int num_group,
-                                            int nt, int lane, int lin, int order) {
-  Item it = {0, 0, 0, 0, 0, false};
+                                            int nt, int lane, int lin, int order, int ext_on) {
+  Item it = {0, 0, 0, 0, 0, 0, 0, false};
   const int x = lin & 7, j = lin >> 3;
   // round 0 of every per-group quantity is loaded once, side by side
   const bool on0 = lane < num_group;
   const int c_first = on0 ? cut[lane + 1] - cut[lane] : 0;
   const int len_first = on0 ? seqlens[lane] : 0, row_first = on0 ? cu_seqlens[lane] : 0;
-  auto tiles128 = [&](int g0) { return g0 == 0 ? c_first : (g0 + lane < num_group ? cut[g0 + lane + 1] - cut[g0 + lane] : 0); };
+  // this lane's group of round g0: full tiles f, tail tile h (0 / 1) - a short tail rides along with the full tiles (h = 0)
+  auto split = [&](int g0, int& f, int& h) {
+    const bool on = g0 + lane < num_group;
+    const int c = g0 == 0 ? c_first : (on ? cut[g0 + lane + 1] - cut[g0 + lane] : 0);
+    f = c >> 1;
+    h = c & 1;
+    if (ext_on && h && f > 0) {
+      const int len = g0 == 0 ? len_first : as_const(seqlens)[g0 + lane];
+      if (len - (f << 8) <= kExtRows * f) h = 0;
+    }
+  };
   // pass 1: totals
   int tot_f = 0, tot_h = 0;
   for (int g0 = 0; g0 < num_group; g0 += 64) {
-    const int c = tiles128(g0);
-    int f = c >> 1, h = c & 1;
+    int f, h;
+    split(g0, f, h);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       f += __shfl_xor(f, o, 64);
@@ -140,18 +166,19 @@ __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, co
   // pass 2: the group that holds item idx
   int base = 0;
   for (int g0 = 0; g0 < num_group; g0 += 64) {
-    const int c = tiles128(g0);
-    const int t = kind == 0 ? (c + 1) >> 1 : (kind == 1 ? c >> 1 : c & 1);
+    int f, h;
+    split(g0, f, h);
+    const int t = kind == 0 ? f + h : (kind == 1 ? f : h);
     const int inc = wave_incl_scan(t, lane);
     const unsigned long long hit = __ballot(g0 + lane < num_group && idx < (base + inc) * nt);
     if (hit) {
       const int l = __builtin_ctzll(hit);
-      const int tl = __shfl(t, l, 64), cl = __shfl(c, l, 64);
+      const int tl = __shfl(t, l, 64), fl = __shfl(f, l, 64), hl = __shfl(h, l, 64);
       const int rem = idx - (base + __shfl(inc, l, 64) - tl) * nt;
       it.e = g0 + l;
       if (kind == 2) {
         it.wt = rem;
-        it.mt = cl >> 1;
+        it.mt = fl;
       } else {
         it.wt = rem / tl;
         it.mt = rem % tl;
@@ -162,6 +189,13 @@ __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, co
       } else {
         it.m_cnt = as_const(seqlens)[it.e];
         it.m0 = as_const(cu_seqlens)[it.e];
+      }
+      // ride-along rows: the group has no tail item (hl == 0) but rows past its full tiles
+      if (ext_on && hl == 0 && it.mt < fl) {
+        const int r0 = (fl << 8) + kExtRows * it.mt;
+        const int left = it.m_cnt - r0;
+        it.ext0 = r0;
+        it.ext_cnt = left > kExtRows ? kExtRows : (left > 0 ? left : 0);
       }
       it.valid = true;
       return it;
@@ -222,8 +256,26 @@ struct CfgNoPrio : CfgProduct { static constexpr bool kPrio = false; };
 // and the MFMAs of token blocks 2-3 do not exist: 16 instead of 32 MFMAs, 20 instead of 24 operand reads and 6-7
 // instead of 8-9 DMA pieces per wave and k-tile, and in the fused activation epilogue group 0 finishes everything.
 // The weight units are what they are: a tail tile still re-streams its 256 weight rows.
-template <class Cfg, bool kHasXs, bool kNoDma, bool kAct, bool kHalf, bool kKTail>
-__device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, int mt0, int n0, int m_cnt, int m0) {
+// kExt: the FULL body with 16 ride-along rows (locate_item: a group's short tail dealt to its full tiles) - a 17th token
+// block of the tile, rows [ext0, ext0 + ext_cnt) of the group:
+//   * staging: 2 KB per k-tile (16 rows x 128 B) + 16 scales, fetched in the SCALE slot of the DMA schedule by the waves whose
+//     scale piece fetches nothing (waves 4-7: the four strips' scales are waves 0-3's) - waves 4 / 5 the two 8-row pieces,
+//     wave 6 the scales: not one VMEM instruction more per wave, the counted waits are untouched;
+//   * MFMAs: the block x the tile's 256 weight rows = 16 per k-tile, two per wave: wave (group, strip s) multiplies row
+//     blocks s (rows 0-63 of its half, unit U0) and 4 + s (rows 64-127, U3) - BOTH behind the 16 MFMAs of section X (by then
+//     U3 of this k-tile has landed for the whole group: every wave waited for its pieces in front of the barrier that opened
+//     the section), so the ride-along buffers are read in section X only and refilled in section Y (slot 13), with barriers
+//     in between for either group.  Section X is 18 MFMAs, section Y 16; the two groups alternate, a k-tile is 4 x 17;
+//   * registers: the operands are read JUST IN TIME inside section X into the registers of row blocks that are finished
+//     (the token block + row block s behind MFMA 7, row block 4 + s behind MFMA 11) - the section starts at the kernel's
+//     register peak; what is new at the peak is 8 accumulators, 3 scale values and 5 read bases;
+//   * the rescale pipeline is the section's own (block n follows MFMA n + 2; section X's last two blocks - the ride-along
+//     ones - are folded under section Y's first MFMAs): the arithmetic per output element is that of every other body, so a
+//     row's results do not depend on whether it rode along or went through the tail body (tests/test_fuse_moe_blockwise.py).
+template <class Cfg, bool kHasXs, bool kNoDma, bool kAct, bool kHalf, bool kKTail, bool kExt = false>
+__device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, int mt0, int n0, int m_cnt, int m0, int ext0 = 0,
+                                        int ext_cnt = 0) {
+  static_assert(!kExt || (kHasXs && !kHalf && !kNoDma && !kKTail), "ride-along rows: blockwise full body only");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g4 = lane >> 4;
@@ -261,7 +313,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     // loses every issue slot to the MMA wave of its SIMD (round 4 paid it on every per-tensor call: matrix pipe busy
     // 0.85 -> 0.72)
     const bool k_ok = !kKTail || koff + p_chunk * 16 < K;
-    uint8_t* base = s_mem + kP * kBuf + (kLate ? 3 * kUnit : 0);
+    uint8_t* base = s_mem + kAOff + (2 * kLate + kP) * kUnit;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + (wave * 2 + q) * 1024), 16,
                                              k_ok ? w_voff[q] : 0xffffff00u, koff + (kLate ? late_w : 0), 0, 0);
   };
@@ -294,20 +346,46 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     const long term = a.col_base ? col0 + sc : static_cast<long>(a.row_index ? a.row_index[m0 + sc] : m0 + sc);
     xs_voff = static_cast<unsigned>(term * a.xs_row_stride * 4);
   }
+  if constexpr (kExt) {
+    // waves 4-7 fetch no strip scales: their scale slot carries the ride-along rows (waves 4 / 5: 8 rows each, the DMA
+    // role of a token piece) and the rows' scales (wave 6, lanes 0-15); rows past ext_cnt repeat the last one (not stored)
+    if (wave == 4 || wave == 5) {
+      const int er = (wave - 4) * 8 + p_row;
+      const int tok = ext0 + (er < ext_cnt ? er : ext_cnt - 1);
+      const int xrow = a.row_index ? a.row_index[m0 + tok] : m0 + tok;
+      xs_voff = static_cast<unsigned>(xrow) * static_cast<unsigned>(K) + p_chunk * 16;
+    } else if (wave == 6) {
+      const int er = lane & 15;
+      const int tok = ext0 + (er < ext_cnt ? er : ext_cnt - 1);
+      const long col0 = a.col_base ? static_cast<long>(as_const(a.col_base)[e]) * a.tile_m : 0;
+      const long term = a.col_base ? col0 + tok : static_cast<long>(a.row_index ? a.row_index[m0 + tok] : m0 + tok);
+      xs_voff = static_cast<unsigned>(term * a.xs_row_stride * 4);
+    }
+  }
   const int xs_kb_bytes = static_cast<int>(a.xs_kb_stride * 4);
   auto dma_x = [&](int T, bool on, auto par, auto late, int q) {
     constexpr int kP = decltype(par)::value, kLate = decltype(late)::value;
     const int koff = T * kBK;
     const auto rx = make_rsrc(a.x, on ? a.x_bytes : 0u);
     const bool k_ok = !kKTail || koff + p_chunk * 16 < K;
-    uint8_t* base = s_mem + kP * kBuf + (1 + kLate) * kUnit;
+    uint8_t* base = s_mem + kBOff + (2 * kLate + kP) * kUnit;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(base + (wave * 2 + q) * 1024), 16,
                                              k_ok ? x_voff[kLate][q] : 0xffffff00u, koff, 0, 0);
   };
-  const unsigned xs_nrec = __builtin_amdgcn_readfirstlane(wave < 4 ? 0xffffffffu : 0u);
+  const unsigned xs_nrec = __builtin_amdgcn_readfirstlane(wave < 4 || (kExt && wave == 6) ? 0xffffffffu : 0u);
   auto dma_xs = [&](int T, bool on, auto par) {
     constexpr int kP = decltype(par)::value;
-    if constexpr (kHasXs) {
+    if constexpr (kExt) {
+      if (wave == 4 || wave == 5) {  // (wave-uniform: a scalar branch) this wave's 8 ride-along rows of k-tile T
+        const auto rx = make_rsrc(a.x, on ? a.x_bytes : 0u);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(s_mem + kExtOff + kP * 2048 + (wave - 4) * 1024), 16, xs_voff,
+                                                 T * kBK, 0, 0);
+      } else {
+        const auto rs = make_rsrc(a.xs, on ? xs_nrec : 0u);
+        uint8_t* dst = s_mem + (wave < 4 ? kXsOff + kP * 1024 + wave * 256 : (wave == 6 ? kExtXsOff + kP * 256 : kXsOff + 2048));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 4, xs_voff, T * xs_kb_bytes, 0, 0);
+      }
+    } else if constexpr (kHasXs) {
       // all eight waves issue it (the vmcnt arithmetic needs equal counts); waves 4-7 fetch nothing
       // (the wave's share of the select is hoisted out of the loop: round 4 evaluated `on && wave < 4` through
       // v_cndmask + v_readfirstlane per k-tile - VALU work in a load section, which loses every issue slot to the MMA
@@ -328,27 +406,31 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     for (int j = 0; j < 4; ++j) tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // operand read offsets inside a unit (swizzled): row r, chunk c -> r*128 + ((c ^ (r & 7)) << 4); the rows of a
-  // wave's blocks are 16 apart, so (r & 7) does not depend on the block and block offsets are immediates
-  // Per buffer: the second buffer starts at 64 KB, past the 16-bit offset field of a ds_read - without its own base
-  // registers (made opaque: hipcc would rematerialise them as base + 0x10000) every operand read of an odd k-tile costs
-  // a v_add in a load section, whose VALU work loses every issue slot to the MMA wave of its SIMD.
-  int a_off[2][2], b_off[2][2];
+  // wave's blocks are 16 apart, so (r & 7) does not depend on the block and block offsets are immediates - and so are the
+  // unit and the buffer (the interleaved image above): one base register per operand side and chunk half.  (Any address
+  // arithmetic at a read would be VALU work in a load section, which loses every issue slot to the MMA wave of its SIMD.)
+  int a_off[2], b_off[2];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    a_off[0][c] = (wn * 64 + r16) * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);
-    b_off[0][c] = kUnit + (wm * 32 + r16) * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);
-    a_off[1][c] = a_off[0][c] + kBuf;
-    b_off[1][c] = b_off[0][c] + kBuf;
-    asm volatile("" : "+v"(a_off[1][c]), "+v"(b_off[1][c]));
+    a_off[c] = kAOff + (wn * 64 + r16) * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);
+    b_off[c] = kBOff + (wm * 32 + r16) * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);
+    asm volatile("" : "+v"(a_off[c]), "+v"(b_off[c]));  // opaque: hipcc would otherwise fold the immediates back into copies
   }
   int xs_rd = kXsOff + (wm * 64 + r16) * 4;  // this lane's token scales of token block 0 in scale buffer 0 (opaque base: as above)
   asm volatile("" : "+v"(xs_rd));
-  auto read_a = [&](auto par, int unit_off, u32x4 (&af)[4][2]) {  // unit_off: 0 = U0, 3 * kUnit = U3 of the buffer
+  // ride-along block: row block wm of either weight unit, the 16 rows' operand bytes and scales (read bases: opaque as above)
+  f32x4 tot_ext[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // rows 16 wm .. / 64 + 16 wm .. of the wave's half
+  // their read addresses are derived from a_off[0] / xs_rd INSIDE the MMA section (wave-uniform distances; chunk half c = 1
+  // is the address with bit 6 flipped): a handful of VALU instructions where the wave owns the issue slots, no register held
+  const int ext_sa = wm * 2048;                           // row block wm of a weight unit
+  const int ext_sb = kExtOff - kAOff - wn * 64 * kBK;     // a_off[0] -> row r16 of the ride-along buffer, same chunk slot
+  const int ext_sx = kExtXsOff - kXsOff - wm * 256;       // xs_rd -> the ride-along row's scale
+  auto read_a = [&](auto par, int late, u32x4 (&af)[4][2]) {  // late: 0 = U0, 1 = U3 of the buffer
     constexpr int kP = decltype(par)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) af[i][c] = *reinterpret_cast<const u32x4*>(s_mem + a_off[kP][c] + unit_off + i * 2048);
+      for (int c = 0; c < 2; ++c) af[i][c] = *reinterpret_cast<const u32x4*>(s_mem + a_off[c] + (2 * late + kP) * kUnit + i * 2048);
   };
   auto read_b = [&](auto par, int late, u32x4 (&bf)[2][2]) {
     constexpr int kP = decltype(par)::value;
@@ -356,7 +438,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int c = 0; c < 2; ++c)
-        bf[j][c] = *reinterpret_cast<const u32x4*>(s_mem + b_off[kP][c] + late * kUnit + j * 2048);
+        bf[j][c] = *reinterpret_cast<const u32x4*>(s_mem + b_off[c] + (2 * late + kP) * kUnit + j * 2048);
   };
 
   // One section: 4 row blocks x all 4 token blocks (16 MFMAs), written as the software pipeline it has to be:
@@ -370,24 +452,69 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   // MFMAs of the NEXT section (`pend`, with the scales `fpend` of the k-tile they belong to): the load sections carry no
   // FMA, a section's head needs no hazard padding (its first FMAs read results that are a whole load section old), and
   // the new k-tile's four scale products (`pre`) sit behind MFMA 0 instead of in front of it.
-  constexpr int kN = 4 * kJ;       // MFMAs per section
+  constexpr int kN = 4 * kJ;       // MFMAs per section (kExt: section X has two more - the ride-along block x row blocks wm, 4 + wm)
   constexpr int kD = Cfg::kDist;   // the rescale of block n follows the MFMA of block n + kD
   f32x4 pend[kD];
-  float fpend[4] = {0.f, 0.f, 0.f, 0.f};
+  float f_ext = 0.f;  // kExt: the ride-along block's scale product (formed in section X, used by the folds under section Y's head)
 #pragma unroll
   for (int t = 0; t < kD; ++t) pend[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto section = [&](int i0, const u32x4 (&af)[4][2], const u32x4 (&be)[2][2], const u32x4 (&bl)[2][2], float (&f)[4],
-                     auto&& pre, auto&& hook, auto&& early_leave) {
+  // block b of the section whose row half starts at row block sec_i0: its partial folded into the running sum
+  // (b < kN: row block b / kJ, token block b % kJ; b >= kN: the ride-along block on row block wm of unit b - kN)
+  auto fold = [&](int sec_i0, int b, const f32x4& p, const float (&ff)[4], float ffe) {
+    if (b < kN) {
+      const int pi = b / kJ, pj = b % kJ;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tot[sec_i0 + pi][pj][r] = fmaf(p[r], ff[pj], tot[sec_i0 + pi][pj][r]);
+      // kExt: the scale slot's DMA is a wave-uniform BRANCH (dma_xs), the k-loop is several basic blocks, and hipcc sinks
+      // the folds - pure arithmetic whose results are next read a k-tile later - down to the last block: 64 partials stay
+      // live and the schedule is gone.  An empty asm that "reads and writes" the sum keeps every fold where it is written.
+      if constexpr (kExt) asm volatile("" : "+v"(tot[sec_i0 + pi][pj]));
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tot_ext[b - kN][r] = fmaf(p[r], ffe, tot_ext[b - kN][r]);
+      asm volatile("" : "+v"(tot_ext[b - kN]));
+    }
+  };
+  auto blocks_of = [](int i0) { return kN + (kExt && i0 == 0 ? 2 : 0); };  // section X carries the ride-along MFMAs
+  auto section = [&](auto i0c, auto par, const u32x4 (&af)[4][2], const u32x4 (&be)[2][2], const u32x4 (&bl)[2][2],
+                     float (&f)[4], float wsk, auto&& pre, auto&& hook, auto&& early_leave) {
+    constexpr int i0 = decltype(i0c)::value, kP = decltype(par)::value;
+    constexpr int kNs = blocks_of(i0), kNp = blocks_of(4 - i0);  // blocks of this section / of the one before it
+    u32x4 a_ext[2][2], b_ext[2];  // kExt: row block wm of U0 / U3 and the ride-along rows, read just in time (see above)
+    float xs_ext = 1.f;
     f32x4 pv[kD];  // pv[0] = the newest partial
 #pragma unroll
     for (int t = 0; t < kD; ++t) pv[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int n = 0; n < kN; ++n) {
-      const int i = n / kJ, j = n % kJ;
-      const u32x4(&bf)[2] = j < 2 ? be[j] : bl[j - 2];
-      const i32x8 av = {static_cast<int>(af[i][0][0]), static_cast<int>(af[i][0][1]), static_cast<int>(af[i][0][2]),
-                        static_cast<int>(af[i][0][3]), static_cast<int>(af[i][1][0]), static_cast<int>(af[i][1][1]),
-                        static_cast<int>(af[i][1][2]), static_cast<int>(af[i][1][3])};
+    for (int n = 0; n < kNs; ++n) {
+      if constexpr (kExt && i0 == 0) {
+        if (n == 8) {  // row blocks 0-1 are finished: their registers take the ride-along rows and row block wm of U0
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            b_ext[c] = *reinterpret_cast<const u32x4*>(s_mem + ((a_off[0] + ext_sb) ^ (c * 64)) + kP * 2048);
+            a_ext[0][c] = *reinterpret_cast<const u32x4*>(s_mem + ((a_off[0] + ext_sa) ^ (c * 64)) + kP * kUnit);
+          }
+          xs_ext = *reinterpret_cast<const float*>(s_mem + xs_rd + ext_sx + kP * 256);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (n == 12) {  // row block 2 is finished: row block wm of U3
+#pragma unroll
+          for (int c = 0; c < 2; ++c)
+            a_ext[1][c] = *reinterpret_cast<const u32x4*>(s_mem + ((a_off[0] + ext_sa) ^ (c * 64)) + (2 + kP) * kUnit);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (n == kN) {
+          __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the just-in-time reads (nothing else is outstanding there)
+          f_ext = wsk * xs_ext;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      const int i = n < kN ? n / kJ : 0, j = n < kN ? n % kJ : 0;
+      const u32x4(&bf)[2] = n >= kN ? b_ext : (j < 2 ? be[j] : bl[j - 2]);
+      const u32x4(&ar)[2] = n >= kN ? a_ext[n >= kN ? n - kN : 0] : af[i];
+      const i32x8 av = {static_cast<int>(ar[0][0]), static_cast<int>(ar[0][1]), static_cast<int>(ar[0][2]),
+                        static_cast<int>(ar[0][3]), static_cast<int>(ar[1][0]), static_cast<int>(ar[1][1]),
+                        static_cast<int>(ar[1][2]), static_cast<int>(ar[1][3])};
       const i32x8 bv = {static_cast<int>(bf[0][0]), static_cast<int>(bf[0][1]), static_cast<int>(bf[0][2]),
                         static_cast<int>(bf[0][3]), static_cast<int>(bf[1][0]), static_cast<int>(bf[1][1]),
                         static_cast<int>(bf[1][2]), static_cast<int>(bf[1][3])};
@@ -396,15 +523,13 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
                                                                             0, 0);
         __builtin_amdgcn_sched_barrier(0);  // MFMA n first, then the rescale of block n - kD
         if (n >= kD) {
-          const int pi = (n - kD) / kJ, pj = (n - kD) % kJ;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) tot[i0 + pi][pj][r] = fmaf(pv[kD - 1][r], f[pj], tot[i0 + pi][pj][r]);
+          fold(i0, n - kD, pv[kD - 1], f, f_ext);
         } else if constexpr (Cfg::kCarry) {
-          // block kN - kD + n of the PREVIOUS section (the other row half: 4 - i0), under the scales of its k-tile
-          const int pi = (kN - kD + n) / kJ, pj = (kN - kD + n) % kJ;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) tot[4 - i0 + pi][pj][r] = fmaf(pend[n][r], fpend[pj], tot[4 - i0 + pi][pj][r]);
-          if (n == 0) pre();
+          // block kNp - kD + n of the PREVIOUS section (the other row half: 4 - i0), under the scales of its k-tile
+          // (`f` still holds that k-tile's products: the new k-tile's - `pre` - are formed behind the LAST carried fold, so
+          // the two sets never live side by side: four registers less at the kernel's register peak than rounds 5's `fpend`)
+          fold(4 - i0, kNp - kD + n, pend[n], f, f_ext);
+          if (n == kD - 1) pre();
         }
 #pragma unroll
         for (int t = kD - 1; t > 0; --t) pv[t] = pv[t - 1];
@@ -417,24 +542,18 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       __builtin_amdgcn_sched_barrier(0);
       hook(n);
       __builtin_amdgcn_sched_barrier(0);
-      if (n == kN - 1 - Cfg::kEarly) early_leave();
+      if (n == kNs - 1 - Cfg::kEarly) early_leave();
     }
-    if constexpr (kHasXs) {  // the last kD partials: block kN - kD + t <- pv[kD - 1 - t]
+    if constexpr (kHasXs) {  // the last kD partials: block kNs - kD + t <- pv[kD - 1 - t]
 #pragma unroll
       for (int t = 0; t < kD; ++t) pend[t] = pv[kD - 1 - t];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fpend[j] = f[j];
     }
   };
   // without Cfg::kCarry the pending blocks are folded right behind the barrier that ends the section (round 2-4 form)
-  auto apply_tail = [&](int i0) {
+  auto apply_tail = [&](int i0, const float (&f)[4]) {
     if constexpr (kHasXs && !Cfg::kCarry) {
 #pragma unroll
-      for (int t = 0; t < kD; ++t) {
-        const int pi = (kN - kD + t) / kJ, pj = (kN - kD + t) % kJ;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tot[i0 + pi][pj][r] = fmaf(pend[t][r], fpend[pj], tot[i0 + pi][pj][r]);
-      }
+      for (int t = 0; t < kD; ++t) fold(i0, blocks_of(i0) - kD + t, pend[t], f, f_ext);
     }
   };
 
@@ -585,20 +704,20 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       for (int j = 0; j < 4; ++j) f[j] = wsk * xsv[j];
     };
     if constexpr (!(Cfg::kCarry && kHasXs)) make_f();
-    section(0, a_frag, b_early, b_late, f, make_f, [&](int n) { issue_x(n + 1); }, leave_mma);
+    section(IntC<0>{}, par, a_frag, b_early, b_late, f, wsk, make_f, [&](int n) { issue_x(n + 1); }, leave_mma);
     if constexpr (Cfg::kPrio && Cfg::kEarly > 0) __builtin_amdgcn_s_setprio(0);
-    apply_tail(0);
+    apply_tail(0, f);
     // ---- section Y: rows 64-127 ----------------------------------------------------------------------------
     if constexpr (Cfg::kDmaFirst) {
       issue_y(0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    read_a(par, 3 * kUnit, a_frag);
+    read_a(par, 1, a_frag);
     if constexpr (!Cfg::kDmaFirst) issue_y(0);
     enter_mma(fly_y);
-    section(4, a_frag, b_early, b_late, f, [] {}, [&](int n) { issue_y(n + 1); }, leave_mma);
+    section(IntC<4>{}, par, a_frag, b_early, b_late, f, wsk, [] {}, [&](int n) { issue_y(n + 1); }, leave_mma);
     if constexpr (Cfg::kPrio && Cfg::kEarly > 0) __builtin_amdgcn_s_setprio(0);
-    apply_tail(4);
+    apply_tail(4, f);
   };
   for (int kb = 0; kb < KB; kb += 2) {
     k_tile(kb, IntC<0>{});
@@ -606,11 +725,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   }
   if constexpr (Cfg::kCarry && kHasXs) {  // the last section's pending blocks (row half 4 .. 7)
 #pragma unroll
-    for (int t = 0; t < kD; ++t) {
-      const int pi = (kN - kD + t) / kJ, pj = (kN - kD + t) % kJ;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) tot[4 + pi][pj][r] = fmaf(pend[t][r], fpend[pj], tot[4 + pi][pj][r]);
-    }
+    for (int t = 0; t < kD; ++t) fold(4, kN - kD + t, pend[t], f, f_ext);
   }
   if constexpr (Cfg::kProf) {
     if (a.prof && blockIdx.x < 16)
@@ -711,13 +826,58 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     };
     // group 0 sends its gate values of token blocks 2-3 into the first 32 KB, group 1 its up values of blocks 0-1
     // into the second; each then reads the other's region
+    // ride-along block: the up wave hands its two blocks (columns 16 wm .. and 64 + 16 wm .. of the tile's 128) to the gate
+    // wave of the same strip index through the (now idle) ride-along row buffers; the token's abs-max over the 128 columns
+    // is folded over the four gate waves through the scale buffers - the tail body's epilogue (tail_finish), value for value
+    uint32_t* ext_xch = reinterpret_cast<uint32_t*>(s_mem + kExtOff) + (wm * 2 * 64 + lane) * 2;  // [wm][unit][lane] of 8 B
+    float* ext_red = reinterpret_cast<float*>(s_mem + kExtXsOff);                                 // [wm][16 tokens]
     if (wn == 0) {
       if constexpr (!kHalf) send(IntC<2>{});
     } else {
       xch += 4 * 16 * 64 * 2;
       send(IntC<0>{});
+      if constexpr (kExt) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          *reinterpret_cast<u32x2*>(ext_xch + u * 128) =
+              u32x2{pack_bf16x2(tot_ext[u][0], tot_ext[u][1]), pack_bf16x2(tot_ext[u][2], tot_ext[u][3])};
+      }
     }
     __syncthreads();
+    if constexpr (kExt) {
+      if (wn == 0) {
+        float amax = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const u32x2 ov = *reinterpret_cast<const u32x2*>(ext_xch + u * 128);
+          const uint32_t m01 = pack_bf16x2(tot_ext[u][0], tot_ext[u][1]), m23 = pack_bf16x2(tot_ext[u][2], tot_ext[u][3]);
+          const float gv[4] = {bf16lo_to_f32(m01), bf16hi_to_f32(m01), bf16lo_to_f32(m23), bf16hi_to_f32(m23)};
+          const float uv[4] = {bf16lo_to_f32(ov[0]), bf16hi_to_f32(ov[0]), bf16lo_to_f32(ov[1]), bf16hi_to_f32(ov[1])};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = gv[r] / (1.0f + __expf(-gv[r])) * uv[r];
+            tot_ext[u][r] = v;
+            amax = fmaxf(amax, fabsf(v));
+          }
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        if (g4 == 0) ext_red[wm * 16 + r16] = amax;
+      }
+      __syncthreads();
+      if (wn == 0 && r16 < ext_cnt) {
+        const float amax = fmaxf(fmaxf(ext_red[r16], ext_red[16 + r16]), fmaxf(ext_red[32 + r16], ext_red[48 + r16]));
+        const float scale = amax / 448.0f;
+        const float inv = 1.0f / (scale + 1e-8f);
+        const long row = static_cast<long>(m0 + ext0 + r16);
+        uint8_t* orow = a.act_out + row * inter + col0 + wm * 16 + g4 * 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          *reinterpret_cast<uint32_t*>(orow + u * 64) =
+              quant_4xe4m3(tot_ext[u][0] * inv, tot_ext[u][1] * inv, tot_ext[u][2] * inv, tot_ext[u][3] * inv);
+        if (wm == 0 && g4 == 0) a.act_scale[row * (inter >> 7) + (col0 >> 7)] = scale;
+      }
+    }
     if (wn == 0) {
       xch += 4 * 16 * 64 * 2;
       finish(IntC<0>{}, IntC<1>{});
@@ -742,6 +902,15 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
       const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
       if (slot < m_cnt) *reinterpret_cast<u32x4*>(yrow + i * 16) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+    }
+  }
+  if constexpr (kExt) {  // the ride-along block: rows 16 wm + 4 g4 .. + 3 and 64 + the same of the wave's half, token ext0 + r16
+    if (r16 < ext_cnt) {
+      uint16_t* yrow = a.y + static_cast<long>(m0 + ext0 + r16) * a.N + n0 + wn * 128 + wm * 16 + g4 * 4;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        *reinterpret_cast<u32x2*>(yrow + u * 64) =
+            u32x2{pack_bf16x2(tot_ext[u][0], tot_ext[u][1]), pack_bf16x2(tot_ext[u][2], tot_ext[u][3])};
     }
   }
 }
@@ -1310,7 +1479,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   __shared__ __attribute__((aligned(1024))) uint8_t s_mem[kLds];
   const int nt = a.N / kBN;  // kAct: N = 2 * inter, tile tn = columns [tn * 128, +128) of gate and of up
   const Item it = locate_item(as_const(cu_tiles), a.seqlens, a.cu_seqlens, num_group, nt, threadIdx.x & 63, blockIdx.x,
-                              a.item_order);
+                              a.item_order, kHasXs && !kNoDma && !kKTail ? a.ext_rows : 0);
   if (!it.valid) return;
   const int e = __builtin_amdgcn_readfirstlane(it.e);
   const int m_cnt = __builtin_amdgcn_readfirstlane(it.m_cnt);
@@ -1332,7 +1501,15 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
     p8_tail_body<kHasXs, kAct, kKTail, false>(a, s_mem, e, mt0, n0, m_cnt, m0);
   else if (m_cnt - mt0 <= 128 && a.no_half_tile != 1)
     p8_body<Cfg, kHasXs, kNoDma, kAct, true, kKTail>(a, s_mem, e, mt0, n0, m_cnt, m0);
-  else
+  else if constexpr (kHasXs && !kNoDma && !kKTail) {
+    // a full tile of a group whose short tail rides along (locate_item) carries up to 16 of those rows as a 17th token block
+    const int ext_cnt = __builtin_amdgcn_readfirstlane(it.ext_cnt);
+    if (ext_cnt > 0)
+      p8_body<Cfg, kHasXs, kNoDma, kAct, false, kKTail, true>(a, s_mem, e, mt0, n0, m_cnt, m0,
+                                                              __builtin_amdgcn_readfirstlane(it.ext0), ext_cnt);
+    else
+      p8_body<Cfg, kHasXs, kNoDma, kAct, false, kKTail>(a, s_mem, e, mt0, n0, m_cnt, m0);
+  } else
     p8_body<Cfg, kHasXs, kNoDma, kAct, false, kKTail>(a, s_mem, e, mt0, n0, m_cnt, m0);
 }
 
@@ -1370,6 +1547,9 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int n
   // round5_moe_kernel_choice.txt; the stream is not bound by the bytes in flight at that point.  Removed.)
   a.nt_single = hpc_dev_tuning_get(24) != 1;
   a.tail_regs = hpc_dev_tuning_get(26) == 1;
+  // a group's short tail (<= 16 rows per full tile it has) rides along with its full tiles instead of running as a tail
+  // item (blockwise scales; development key 49 = 1: tail items for every tail, the dispatch of round 5)
+  a.ext_rows = a.has_xs && hpc_dev_tuning_get(49) != 1;
   if (n % kBN || a.K < kBK) return HPC_ERR_UNSUPPORTED;
   const long max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 256)
   const long items = max_tiles * (n / kBN) + 16;  // + 16: the per-XCD chunks of the full and of the tail tiles round up

@@ -49,6 +49,7 @@
 //   key 47 fused all-reduce (high throughput): 1 = signal barriers of rounds 1-5 (compare-and-swap loops, system-scope release / acquire fences) instead of
 //          poll + store on relaxed accesses behind vmcnt(0)
 //   key 48 fused all-reduce (high throughput): 1 = signal flags packed at the start of the pad (rounds 1-5) instead of spread over it
+//   key 49 grouped GEMM 256 x 256 kernel: 1 = no ride-along rows (every tail of a group runs as its own tail / half-tile item: rounds 2-5)
 //   others: see the launchers that read them
 #pragma once
 

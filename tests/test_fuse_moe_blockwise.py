@@ -403,7 +403,9 @@ def test_group_gemm_tail_body_is_bit_identical(n, k):                      # tha
 
     torch.manual_seed(n + k)
     tails = [1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 63, 64, 65, 128, 129, 0, 200]
-    seqlens = torch.tensor([256 * (i % 3) + t for i, t in enumerate(tails)], dtype=torch.int32)
+    seqlens = torch.tensor([256 * (i % 3) + t for i, t in enumerate(tails)] + [512 + 1, 512 + 16, 512 + 17, 512 + 32, 512 + 33,
+                                                                              768 + 40, 768 + 48, 768 + 49, 256 + 16, 256 + 17],
+                           dtype=torch.int32)  # the second list: tails that ride along with 1 / 2 / 3 full tiles, and the first that do not
     num_group, total = len(seqlens), int(seqlens.sum())
     x = (torch.randn((total, k)) / 10).to(F8)
     w = (torch.randn((num_group, n, k)) / 10).to(F8)
@@ -425,22 +427,29 @@ def test_group_gemm_tail_body_is_bit_identical(n, k):                      # tha
     try:
         # half-tile body for the tails / tail body (the product: weights through per-wave LDS rings) / full body only /
         # the register-streamed tail body (development key 26 = 1)
-        for key in (2, 0, 1, "regs"):
-            dev_set(21, 0 if key == "regs" else key)
+        # round 6: groups with f full tiles and a tail of <= 16 f rows have NO tail item - the rows ride along with the full
+        # tiles (p8_body<kExt>: a 17th token block); development key 49 = 1 is the dispatch of round 5 (a tail item for
+        # every tail): "r5" = that with the tail body, "r5half" = that with the half-tile body
+        for key in (2, 0, 1, "regs", "r5", "r5half"):
+            dev_set(21, 2 if key == "r5half" else (0 if key in ("regs", "r5") else key))
             dev_set(26, 1 if key == "regs" else 0)
+            dev_set(49, 1 if key in ("r5", "r5half") else 0)
             outs[key] = hpc.group_gemm_blockwise_fp8(x.cuda(), w.cuda(), seqlens.cuda(), cu.cuda(), xs_t.cuda(), wscale.cuda(),
                                                      num_seq_per_group_avg=avg).cpu()
     finally:
         dev_set(21, 0)
         dev_set(26, 0)
+        dev_set(49, 0)
         dev_set(3, 0)
     assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs["regs"])
+    assert torch.equal(outs[0], outs["r5"]) and torch.equal(outs[0], outs["r5half"])
     assert allclose(gt.float(), outs[0].float(), rtol=0.01, atol=0.02)
 
 
 @pytest.mark.dev
 @pytest.mark.gpu
-@pytest.mark.parametrize("num_tokens,hidden,inter,num_expert,topk", [(530, 512, 256, 4, 2), (1100, 1024, 384, 8, 2), (300, 512, 128, 2, 2)])
+@pytest.mark.parametrize("num_tokens,hidden,inter,num_expert,topk", [(530, 512, 256, 4, 2), (1100, 1024, 384, 8, 2), (300, 512, 128, 2, 2),
+                                                                     (1050, 512, 256, 4, 2)])  # the last: ~525 rows per expert
 def test_fuse_moe_blockwise_tail_body_is_bit_identical(num_tokens, hidden, inter, num_expert, topk):
     """The fused op with experts whose row counts end in a short tail (~265 / ~275 / 300 rows per expert): gate-up GEMM
     with the activation + 128-block quantisation in the tail body's epilogue (up values handed to the gate wave of the
@@ -460,33 +469,38 @@ def test_fuse_moe_blockwise_tail_body_is_bit_identical(num_tokens, hidden, inter
     outs = {}
     dev_set(3, 4)
     try:
-        for key in (2, 0, "regs"):
-            dev_set(21, 0 if key == "regs" else key)
+        for key in (2, 0, "regs", "r5"):  # "r5": development key 49 = 1 - no ride-along rows, every tail its own item
+            dev_set(21, 0 if key in ("regs", "r5") else key)
             dev_set(26, 1 if key == "regs" else 0)
+            dev_set(49, 1 if key == "r5" else 0)
             outs[key] = hpc.fuse_moe_blockwise_fp8(*dev, 0, num_expert).cpu()
     finally:
         dev_set(21, 0)
         dev_set(26, 0)
+        dev_set(49, 0)
         dev_set(3, 0)
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs["regs"])
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs["regs"]) and torch.equal(outs[0], outs["r5"])
     assert allclose(gt.float(), outs[0].float(), rtol=0.01, atol=0.01)
 
 
 @pytest.mark.dev
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [2, 4])  # development key 22: 2 = the round-4 loop (tails behind the barrier), 4 = no s_setprio
+@pytest.mark.parametrize("variant", [2, 4, "r5"])  # development key 22: 2 = the round-4 loop (tails behind the barrier), 4 = no s_setprio;
+                                                   # "r5": key 49 = 1 - the product loop without ride-along rows (a tail item for every tail)
 def test_p8_k_loop_is_bit_identical_to_the_round4_loop_at_the_graded_shape(variant):
     """the k-loop of the 256 x 256 kernel was rewritten in round 5 (the rescale of a section's last
-    two blocks carried under the next section's first MFMAs, `CfgProduct::kCarry`) and again in round 6 (persistent work-item
-    loop); same arithmetic in the same order, so the output has to be BIT-IDENTICAL to the round-4 loop (`CfgRound4`,
+    two blocks carried under the next section's first MFMAs, `CfgProduct::kCarry`) and again in round 6 (a group's short
+    tail rides along with its full tiles as a 17th token block, `p8_body<kExt>`; the scale products of the pending blocks are
+    no longer copied); same arithmetic in the same order, so the output has to be BIT-IDENTICAL to the round-4 loop (`CfgRound4`,
     development key 22 = 2).  At the graded GEMM shapes of configs[3] - the fused op with H = 4096, I = 11008 (gate-up
     N = 22016 / K = 4096 with the activation epilogue, down N = 4096 / K = 11008 = 86 k-tiles) on four experts whose routed
     row counts end in full, half and tail tiles - and on the standalone grouped GEMM of the down shape."""
     import hpc
 
-    g = torch.Generator(device="cuda").manual_seed(22 + variant)
+    vkey = 0 if variant == "r5" else variant
+    g = torch.Generator(device="cuda").manual_seed(22 + vkey)
     T, E, k, H, I = 1100, 4, 2, 4096, 11008
-    torch.manual_seed(variant)
+    torch.manual_seed(vkey)
     topk_ids, _ = torch.sort(torch.multinomial(torch.ones((T, E)), k, replacement=False).to(torch.int32), dim=1)
     counts = torch.bincount(topk_ids.flatten().long(), minlength=E)
     assert int(counts.max()) > 512 and int(((counts % 256 > 0) & (counts % 256 <= 64)).sum()) > 0, counts.tolist()
@@ -510,11 +524,13 @@ def test_p8_k_loop_is_bit_identical_to_the_round4_loop_at_the_graded_shape(varia
     dev_set(3, 4)  # the 256 x 256 kernel
     try:
         for key in (variant, 0):
-            dev_set(22, key)
+            dev_set(22, 0 if key == "r5" else key)
+            dev_set(49, 1 if key == "r5" else 0)
             outs[key] = (hpc.fuse_moe_blockwise_fp8(*args, 0, E).cpu(),
                          hpc.group_gemm_blockwise_fp8(xa, dw, seqlens.cuda(), cu.cuda(), xs_t, dws, num_seq_per_group_avg=avg).cpu())
     finally:
         dev_set(22, 0)
+        dev_set(49, 0)
         dev_set(3, 0)
     assert torch.isfinite(outs[0][0].float()).all() and float(outs[0][0].float().abs().max()) > 0
     assert torch.equal(outs[0][0], outs[variant][0])
