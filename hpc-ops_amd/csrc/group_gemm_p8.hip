@@ -340,7 +340,11 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   }
   unsigned xs_voff = 0;
   if constexpr (kHasXs) {
-    const int slot = mt0 + row_of_slot((wave & 3) * 64 + lane);  // (half tile: lanes 32-63 fetch scales nobody reads)
+    // LDS position `lane` of the strip's 256 B holds the scale of token (lane & 3) * 16 + (lane >> 2): the four scales a lane
+    // multiplies with - token blocks 0-3, row r16 - are 16 contiguous bytes, ONE ds_read_b128 at an immediate offset (rounds
+    // 2-5 kept them in token order, 64 B apart: two ds_read2_b32 and, for the second buffer, a VALU address add in a load
+    // section).  (half tile: the positions of token blocks 2-3 hold scales nobody reads)
+    const int slot = mt0 + row_of_slot((wave & 3) * 64 + (lane & 3) * 16 + (lane >> 2));
     const int sc = slot < m_cnt ? slot : m_cnt - 1;
     const long col0 = a.col_base ? static_cast<long>(as_const(a.col_base)[e]) * a.tile_m : 0;
     const long term = a.col_base ? col0 + sc : static_cast<long>(a.row_index ? a.row_index[m0 + sc] : m0 + sc);
@@ -355,7 +359,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       const int xrow = a.row_index ? a.row_index[m0 + tok] : m0 + tok;
       xs_voff = static_cast<unsigned>(xrow) * static_cast<unsigned>(K) + p_chunk * 16;
     } else if (wave == 6) {
-      const int er = lane & 15;
+      const int er = lane >> 2;  // position 4 r16 = byte 16 r16 of the 256 B: where xs_rd + ext_sx points
       const int tok = ext0 + (er < ext_cnt ? er : ext_cnt - 1);
       const long col0 = a.col_base ? static_cast<long>(as_const(a.col_base)[e]) * a.tile_m : 0;
       const long term = a.col_base ? col0 + tok : static_cast<long>(a.row_index ? a.row_index[m0 + tok] : m0 + tok);
@@ -416,7 +420,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     b_off[c] = kBOff + (wm * 32 + r16) * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);
     asm volatile("" : "+v"(a_off[c]), "+v"(b_off[c]));  // opaque: hipcc would otherwise fold the immediates back into copies
   }
-  int xs_rd = kXsOff + (wm * 64 + r16) * 4;  // this lane's token scales of token block 0 in scale buffer 0 (opaque base: as above)
+  int xs_rd = kXsOff + wm * 256 + r16 * 16;  // this lane's four token scales (token blocks 0-3) in scale buffer 0 (opaque base: as above)
   asm volatile("" : "+v"(xs_rd));
   // ride-along block: row block wm of either weight unit, the 16 rows' operand bytes and scales (read bases: opaque as above)
   f32x4 tot_ext[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // rows 16 wm .. / 64 + 16 wm .. of the wave's half
@@ -449,7 +453,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   // is the caller's (`tail`), behind the barrier that ends the section - otherwise that barrier would wait for the
   // last MFMA's result and the other wave of the SIMD would start its section ~40 cycles late.
   // Cfg::kCarry: the last two blocks' rescale is not done in the load section that follows but rides under the first two
-  // MFMAs of the NEXT section (`pend`, with the scales `fpend` of the k-tile they belong to): the load sections carry no
+  // MFMAs of the NEXT section (`pend`; `f` still holds the scale products of the k-tile they belong to): the load sections carry no
   // FMA, a section's head needs no hazard padding (its first FMAs read results that are a whole load section old), and
   // the new k-tile's four scale products (`pre`) sit behind MFMA 0 instead of in front of it.
   constexpr int kN = 4 * kJ;       // MFMAs per section (kExt: section X has two more - the ride-along block x row blocks wm, 4 + wm)
@@ -693,9 +697,9 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     float xsv[4] = {1.f, 1.f, 1.f, 1.f}, wsk = 1.f;
     if constexpr (kHasXs) {
       wsk = __int_as_float(ws_row[T * a.ws_kb_stride]);
+      const f32x4 x4 = *reinterpret_cast<const f32x4*>(s_mem + xs_rd + kP * 1024);
 #pragma unroll
-      for (int j = 0; j < kJ; ++j)
-        xsv[j] = *reinterpret_cast<const float*>(s_mem + xs_rd + kP * 1024 + j * 64);
+      for (int j = 0; j < kJ; ++j) xsv[j] = x4[j];
     }
     if constexpr (!Cfg::kDmaFirst) issue_x(0);
     enter_mma(fly_x);
