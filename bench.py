@@ -1015,12 +1015,15 @@ def _ar_child(rank, world, local_rank, name, port, q):
             res[key] = row
             q.put((rank, dict(res)))
 
-        for mode, T in (("ll", 8), ("ll", 32), ("ll", 128), ("ll", 512), ("ht", 512), ("ht", 4096), ("ht", 16384)):
+        # "ll1": the one-shot Lamport form (use_two_shot = False: every rank pushes to every rank and reduces itself) next to
+        # the two-shot one at the sizes where one hop could beat two - which wins is a question only real links answer
+        for mode, T in (("ll", 8), ("ll", 32), ("ll", 128), ("ll", 512), ("ll1", 8), ("ll1", 32), ("ht", 512), ("ht", 4096),
+                        ("ht", 16384)):
             Tp = (T + world - 1) // world * world
             residual = torch.randn(Tp, H, dtype=torch.bfloat16, device=dev)
             x = torch.randn(Tp, H, dtype=torch.bfloat16, device=dev)
-            if mode == "ll":
-                M = 2 * math.ceil(T / world) * world * 3
+            if mode in ("ll", "ll1"):
+                M = max(2 * math.ceil(T / world) * world, T * world if mode == "ll1" else 0) * 3
                 ws_buf, hdl = hpc.empty_multimem(comm, [M, H], dtype=torch.bfloat16, device=dev)
                 ws_buf.view(torch.int32).fill_(-(2 ** 31))
                 mc = hdl.get_multimem_buff([M, H], dtype=torch.bfloat16)
@@ -1028,9 +1031,11 @@ def _ar_child(rank, world, local_rank, name, port, q):
                 out, out_res = torch.empty_like(x[:T]), torch.empty_like(x[:T])
                 xin, rin = x[:T].contiguous(), residual[:T].contiguous()
 
+                two_shot = mode == "ll"
+
                 def call():
-                    hpc.fuse_allreduce_rmsnorm_low_latency(xin, mc, hdl.data_buffer_ptrs_dev, ws_buf, flags, world,
-                                                           rank, rin, w, 1e-6, 16, out, out_res, True)
+                    torch.ops.hpc.fuse_allreduce_rmsnorm_low_latency(xin, mc, hdl.data_buffer_ptrs_dev, ws_buf, flags, world, rank,
+                                                                     True, True, two_shot, out, out_res, rin, w, 1e-6)
             else:
                 in_x, in_hdl = hpc.empty_multimem(comm, [Tp, H], dtype=torch.bfloat16, device=dev)
                 out_x, out_hdl = hpc.empty_multimem(comm, [Tp, H], dtype=torch.bfloat16, device=dev)

@@ -316,6 +316,15 @@ struct LlArgs {
   long spin_limit;
   float eps;
   int rows, hidden, rank, ws;
+  // one_shot (the entry's `use_two_shot = false`; the reference takes the flag and runs its two-shot kernel whatever it says,
+  // src/allreduce/entry.cc:84-181): every rank pushes its rows to EVERY rank - slot image [t][rank][hidden] - and every
+  // rank sums the ws copies of a row itself, in rank order, in fp32, rounded to bf16 once: the arithmetic of the owner in
+  // the two-shot form, so the results are bit-identical - with ws times the bytes on the links and one hop instead of two
+  // (no owner, no broadcast, nothing to wait for but the peers' pushes).  Meant for a handful of rows; which form is faster
+  // at which size is a question for a node with real links (none was available: DESIGN 3.4).
+  // fuse_norm = 0 (the reference's rmsnorm_fusion = false, `wait_for_results` in its kernel, low_latency.cu:119-140): the
+  // reduced rows are the output - no residual, no norm.
+  int one_shot, fuse_norm;
 };
 
 __device__ __forceinline__ void ll_scatter_body(const LlArgs& a, int bid, int nblk) {
@@ -333,13 +342,21 @@ __device__ __forceinline__ void ll_scatter_body(const LlArgs& a, int bid, int nb
          o += static_cast<long>(nblk) * kThreads * 16)
       st16_sys(base + o, s);
   }
-  // 2. push my rows to their owners: owner's slot [t / ws][rank][hidden]
+  // 2. push my rows to their owners: owner's slot [t / ws][rank][hidden] (one shot: to every rank, slot [t][rank][hidden])
   const int nvec = a.hidden >> 3;
   for (int t = bid; t < a.rows; t += nblk) {
+    const uint16_t* src = a.x + static_cast<long>(t) * a.hidden;
+    if (a.one_shot) {
+      const long off = static_cast<long>(cur) * slot_bytes + (static_cast<long>(t) * a.ws + a.rank) * a.hidden * 2;
+      for (int v = threadIdx.x; v < nvec; v += kThreads) {
+        const u32x4 xv = sanitize(ld16(src + v * 8));
+        for (int p = 0; p < a.ws; ++p) st16_sys(reinterpret_cast<uint8_t*>(a.peers[p]) + off + v * 16, xv);
+      }
+      continue;
+    }
     const int owner = t % a.ws;
     uint8_t* dst = reinterpret_cast<uint8_t*>(a.peers[owner]) + static_cast<long>(cur) * slot_bytes +
                    (static_cast<long>(t / a.ws) * a.ws + a.rank) * a.hidden * 2;
-    const uint16_t* src = a.x + static_cast<long>(t) * a.hidden;
     for (int v = threadIdx.x; v < nvec; v += kThreads) st16_sys(dst + v * 16, sanitize(ld16(src + v * 8)));
   }
 }
@@ -392,7 +409,7 @@ __device__ __forceinline__ void ll_reduce_norm_body(const LlArgs& a, int bid, in
   if (threadIdx.x == 0) {
     const uint32_t old = atomicAdd(&a.flags[8], 1u);
     if (old == static_cast<uint32_t>(nblk) - 1u) {
-      a.flags[4 + cur] = static_cast<uint32_t>(2 * n_pad * row_bytes);
+      a.flags[4 + cur] = static_cast<uint32_t>(a.one_shot ? static_cast<long>(a.rows) * a.ws * row_bytes : 2 * n_pad * row_bytes);
       a.flags[8] = 0u;
       a.flags[1] = (cur + 2u) % 3u;
       __threadfence();
@@ -406,10 +423,11 @@ __device__ __forceinline__ void ll_reduce_norm_body(const LlArgs& a, int bid, in
     for (int i = 0; i < kVec; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[i][j] = 0.f;
-    if (t % a.ws == a.rank) {
-      // owner: wait for every rank's copy of row t (they land in MY memory), reduce, broadcast
+    if (a.one_shot || t % a.ws == a.rank) {
+      // owner (one shot: every rank, of every row): wait for every rank's copy of row t (they land in MY memory), reduce,
+      // broadcast (two-shot form only)
       const uint8_t* src = a.local_ws + static_cast<long>(cur) * slot_bytes +
-                           static_cast<long>(t / a.ws) * a.ws * row_bytes;
+                           static_cast<long>(a.one_shot ? t : t / a.ws) * a.ws * row_bytes;
       for (int p0 = 0; p0 < a.ws; p0 += 4) {  // 4 peers x all vectors in flight per round
         u32x4 xv[kVec][4];
         const int nper = a.ws - p0 < 4 ? a.ws - p0 : 4;
@@ -438,9 +456,10 @@ __device__ __forceinline__ void ll_reduce_norm_body(const LlArgs& a, int bid, in
             acc[i][2 * j + 1] = bf16hi_to_f32(sum[j]);
           }
           sum = sanitize(sum);
-          for (int p = 0; p < a.ws; ++p)
-            if (p != a.rank)
-              st16_sys(reinterpret_cast<uint8_t*>(a.peers[p]) + bcast_off + t * row_bytes + v * 16, sum);
+          if (!a.one_shot)
+            for (int p = 0; p < a.ws; ++p)
+              if (p != a.rank)
+                st16_sys(reinterpret_cast<uint8_t*>(a.peers[p]) + bcast_off + t * row_bytes + v * 16, sum);
         }
       }
     } else {
@@ -456,7 +475,14 @@ __device__ __forceinline__ void ll_reduce_norm_body(const LlArgs& a, int bid, in
     }
     u32x4 y[kVec];
     const long roff = static_cast<long>(t) * a.hidden;
-    residual_rmsnorm(acc, nvec, a.hidden, a.residual + roff, a.residual_out + roff, a.w, a.eps, y, red);
+    if (a.fuse_norm) {
+      residual_rmsnorm(acc, nvec, a.hidden, a.residual + roff, a.residual_out + roff, a.w, a.eps, y, red);
+    } else {  // the all-reduce alone: acc holds the bf16-rounded sums
+#pragma unroll
+      for (int i = 0; i < kVec; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) y[i][j] = pack_bf16x2(acc[i][2 * j], acc[i][2 * j + 1]);
+    }
 #pragma unroll
     for (int i = 0; i < kVec; ++i) {
       const int v = threadIdx.x + i * kThreads;
@@ -673,15 +699,25 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_low_latency_async(
     void* local_workspace_ptr, void* buffer_flags_dev, const void* residual_in_ptr,
     const void* weight_ptr, float rms_norm_eps, int num_tokens, int hidden_size, int rank,
     int world_size, int64_t workspace_bytes, hipStream_t stream) {
+  return hpc_allreduce_low_latency_async(output_ptr, residual_out_ptr, input_ptr, data_buffer_ptrs_dev, local_workspace_ptr,
+                                         buffer_flags_dev, residual_in_ptr, weight_ptr, rms_norm_eps, num_tokens, hidden_size,
+                                         rank, world_size, workspace_bytes, 1, 1, stream);
+}
+
+extern "C" int hpc_allreduce_low_latency_async(
+    void* output_ptr, void* residual_out_ptr, const void* input_ptr, const void* data_buffer_ptrs_dev,
+    void* local_workspace_ptr, void* buffer_flags_dev, const void* residual_in_ptr,
+    const void* weight_ptr, float rms_norm_eps, int num_tokens, int hidden_size, int rank,
+    int world_size, int64_t workspace_bytes, int rmsnorm_fusion, int use_two_shot, hipStream_t stream) {
   if (int* tw = timeout_word(); tw && *reinterpret_cast<volatile int*>(tw) != 0) return HPC_ERR_TIMEOUT;
-  if (!output_ptr || !residual_out_ptr || !input_ptr || !data_buffer_ptrs_dev || !local_workspace_ptr ||
-      !buffer_flags_dev || !residual_in_ptr || !weight_ptr)
-    return HPC_ERR_INVALID;
+  if (!output_ptr || !input_ptr || !data_buffer_ptrs_dev || !local_workspace_ptr || !buffer_flags_dev) return HPC_ERR_INVALID;
+  if (rmsnorm_fusion && (!residual_out_ptr || !residual_in_ptr || !weight_ptr)) return HPC_ERR_INVALID;
   if (world_size < 1 || world_size > 64 || rank < 0 || rank >= world_size) return HPC_ERR_UNSUPPORTED;
   if ((hidden_size & 7) || hidden_size <= 0 || hidden_size > kMaxVec * kThreads * 8) return HPC_ERR_UNSUPPORTED;
   if (num_tokens <= 0) return HPC_OK;
   const int64_t n_pad = (num_tokens + world_size - 1) / world_size * world_size;
-  const int64_t need = 3 * 2 * n_pad * hidden_size * 2;
+  // a slot holds the scatter + broadcast rows of the two-shot form, or every rank's copy of every row of the one-shot form
+  const int64_t need = 3 * (use_two_shot ? 2 * n_pad : static_cast<int64_t>(num_tokens) * world_size) * hidden_size * 2;
   if (workspace_bytes < need) return HPC_ERR_INVALID;
   LlArgs a;
   a.timeouts = timeout_word();
@@ -701,6 +737,8 @@ extern "C" int hpc_fuse_allreduce_rmsnorm_low_latency_async(
   a.hidden = hidden_size;
   a.rank = rank;
   a.ws = world_size;
+  a.one_shot = use_two_shot ? 0 : 1;
+  a.fuse_norm = rmsnorm_fusion ? 1 : 0;
   const int grid = num_tokens < 2048 ? num_tokens : 2048;
   const bool wide = hidden_size > 4 * kThreads * 8;
   // one launch up to one workgroup per CU (measured at ws = 1, H 8192: T 8 / 128 9.0 / 11.5 us against 10.0 / 12.5 with two
@@ -819,6 +857,9 @@ extern "C" int hpc_dev_allreduce_loopback_ll(void* const* output, void* const* r
     a.hidden = hidden;
     a.rank = r;
     a.ws = world_size;
+    a.one_shot = hpc_dev_tuning_get(52) == 1;   // development key 52 = 1: the one-shot form in the loopback grid
+    a.fuse_norm = hpc_dev_tuning_get(53) != 1;  // development key 53 = 1: the all-reduce alone (rmsnorm_fusion = false)
+    if (a.one_shot && workspace_bytes < 3l * num_tokens * world_size * hidden * 2) return HPC_ERR_INVALID;
   }
   const LlArgs* dev = loopback_args_on_device(host, world_size, stream);
   if (!dev) return HPC_ERR_LAUNCH;

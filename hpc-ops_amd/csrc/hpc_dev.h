@@ -50,6 +50,7 @@
 //          poll + store on relaxed accesses behind vmcnt(0)
 //   key 48 fused all-reduce (high throughput): 1 = signal flags packed at the start of the pad (rounds 1-5) instead of spread over it
 //   key 49 grouped GEMM 256 x 256 kernel: 1 = no ride-along rows (every tail of a group runs as its own tail / half-tile item: rounds 2-5)
+//   key 52 low-latency all-reduce, loopback harness: 1 = the one-shot form; key 53: 1 = the all-reduce alone (no residual / norm)
 //   others: see the launchers that read them
 #pragma once
 

@@ -408,19 +408,22 @@ void fuse_allreduce_rmsnorm_low_latency(const at::Tensor& input_x, const at::Ten
   TORCH_CHECK(buffer_flags.is_cuda() && buffer_flags.is_contiguous() && buffer_flags.numel() >= 9 && buffer_flags.element_size() == 4,
               "buffer_flags must be 9 x uint32 on the device");
   TORCH_CHECK(input_x.dim() == 2, "input_x must be 2D [num_tokens, token_dim]");
-  TORCH_CHECK(rmsnorm_fusion && use_two_shot, "only the fused two-shot mode is implemented");
+  // rmsnorm_fusion = false: the all-reduce alone (the reference kernel's `wait_for_results` path, low_latency.cu:119-140);
+  // use_two_shot = false: the one-shot Lamport form (the reference takes the flag and runs its two-shot kernel either way)
   const int64_t num_tokens = input_x.size(0), hidden = input_x.size(1);
   TORCH_CHECK(hidden % 8 == 0, "token_dim must be divisible by 8");
   TORCH_CHECK(output_x.dim() == 2 && output_x.size(0) == num_tokens && output_x.size(1) == hidden, "output_x shape mismatch");
   TORCH_CHECK(1 <= world_size && world_size <= 64 && 0 <= rank && rank < world_size, "bad world_size / rank");
-  TORCH_CHECK(residual_in.dim() == 2 && residual_in.size(0) == num_tokens && residual_in.size(1) == hidden &&
-                  residual_out.dim() == 2 && residual_out.size(0) == num_tokens && residual_out.size(1) == hidden,
-              "residual shape mismatch");
-  TORCH_CHECK(weight_gamma.dim() == 1 && weight_gamma.size(0) == hidden, "weight_gamma shape mismatch");
-  const int rc = hpc_fuse_allreduce_rmsnorm_low_latency_async(
+  if (rmsnorm_fusion) {
+    TORCH_CHECK(residual_in.dim() == 2 && residual_in.size(0) == num_tokens && residual_in.size(1) == hidden &&
+                    residual_out.dim() == 2 && residual_out.size(0) == num_tokens && residual_out.size(1) == hidden,
+                "residual shape mismatch");
+    TORCH_CHECK(weight_gamma.dim() == 1 && weight_gamma.size(0) == hidden, "weight_gamma shape mismatch");
+  }
+  const int rc = hpc_allreduce_low_latency_async(
       ptr(output_x), ptr(residual_out), ptr(input_x), ptr(data_buffer_ptrs), ptr(multinode_x), ptr(buffer_flags), ptr(residual_in),
       ptr(weight_gamma), static_cast<float>(rms_norm_eps), i32(num_tokens), i32(hidden), i32(rank), i32(world_size),
-      multinode_x.numel() * multinode_x.element_size(), stream_of(input_x));
+      multinode_x.numel() * multinode_x.element_size(), rmsnorm_fusion ? 1 : 0, use_two_shot ? 1 : 0, stream_of(input_x));
   HPC_LAUNCH_CHECK(rc, "fuse_allreduce_rmsnorm_low_latency_async");
 }
 

@@ -110,6 +110,7 @@ _sig("hpc_fuse_allreduce_rmsnorm_high_throughput_grid", I, I, I, I)
 _sig("hpc_fuse_allreduce_rmsnorm_high_throughput_signal_stride", I, I, I, I)
 _sig("hpc_fuse_allreduce_rmsnorm_high_throughput_async", I, PP, PP, PP, P, P, P, F, I, I, I, I, I, I, P)
 _sig("hpc_fuse_allreduce_rmsnorm_low_latency_async", I, P, P, P, P, P, P, P, P, F, I, I, I, I, L, P)
+_sig("hpc_allreduce_low_latency_async", I, P, P, P, P, P, P, P, P, F, I, I, I, I, L, I, I, P)
 _sig("hpc_allreduce_timeouts", I)
 _sig("hpc_allreduce_reset_timeouts", I)
 

@@ -461,6 +461,16 @@ int hpc_fuse_allreduce_rmsnorm_low_latency_async(
     void* local_workspace_ptr, void* buffer_flags_dev, const void* residual_in_ptr,
     const void* weight_ptr, float rms_norm_eps, int num_tokens, int hidden_size, int rank,
     int world_size, int64_t workspace_bytes, hpc_stream_t stream);
+/* The same entry with the two mode flags of the reference op (src/allreduce/entry.cc:84: `rmsnorm_fusion`, `use_two_shot`):
+ *   rmsnorm_fusion = 0: output = the reduced rows (bf16), no residual / norm (residual and weight pointers may be null);
+ *   use_two_shot   = 0: the one-shot Lamport form - every rank pushes its rows to every rank and reduces them itself (the
+ *   reference accepts the flag and runs its two-shot kernel either way; results here are bit-identical between the forms).
+ *   One-shot workspace: 3 x num_tokens x world_size x hidden x 2 bytes (-2 when workspace_bytes is smaller). */
+int hpc_allreduce_low_latency_async(
+    void* output_ptr, void* residual_out_ptr, const void* input_ptr, const void* data_buffer_ptrs_dev,
+    void* local_workspace_ptr, void* buffer_flags_dev, const void* residual_in_ptr,
+    const void* weight_ptr, float rms_norm_eps, int num_tokens, int hidden_size, int rank,
+    int world_size, int64_t workspace_bytes, int rmsnorm_fusion, int use_two_shot, hpc_stream_t stream);
 int hpc_allreduce_timeouts(void);
 int hpc_allreduce_reset_timeouts(void);
 

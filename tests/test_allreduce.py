@@ -72,8 +72,10 @@ def _ar_task(rank, world_size, cases, name, q, device_index):
         comm = hpc.MulticastCommunicator(rank, world_size, device_index, name)
         for mode, N, H, nblk, iters in cases:
             N_pad = (N + world_size - 1) // world_size * world_size
-            if mode == "ll":
-                M_pad = 2 * math.ceil(N / world_size) * world_size * 3
+            ll_kind = mode if mode.startswith("ll") else None  # "ll" | "ll_one_shot" | "ll_sum_only" (the raw op's two mode flags)
+            if ll_kind:
+                mode = "ll"
+                M_pad = max(2 * math.ceil(N / world_size) * world_size, N * world_size if ll_kind == "ll_one_shot" else 0) * 3
                 ws_buf, hdl = hpc.empty_multimem(comm, [M_pad, H], dtype=torch.bfloat16, device=dev)
                 ws_buf.view(torch.int32).fill_(-(2 ** 31))
                 mc = hdl.get_multimem_buff([M_pad, H], dtype=torch.bfloat16)
@@ -99,12 +101,23 @@ def _ar_task(rank, world_size, cases, name, q, device_index):
                     x_d = inputs[rank][:n_it].contiguous().to(dev)
                     out = torch.empty_like(x_d)
                     out_res = torch.empty_like(x_d)
-                    hpc.fuse_allreduce_rmsnorm_low_latency(
-                        x_d, mc, hdl.data_buffer_ptrs_dev, ws_buf, flags, world_size, rank,
-                        res_d[:n_it].contiguous(), w_d, 1e-6, nblk, out, out_res, True)
+                    if ll_kind == "ll":
+                        hpc.fuse_allreduce_rmsnorm_low_latency(
+                            x_d, mc, hdl.data_buffer_ptrs_dev, ws_buf, flags, world_size, rank,
+                            res_d[:n_it].contiguous(), w_d, 1e-6, nblk, out, out_res, True)
+                    else:  # the op itself (the wrapper fixes both flags like the reference's): rmsnorm_fusion, pdl, use_two_shot
+                        torch.ops.hpc.fuse_allreduce_rmsnorm_low_latency(
+                            x_d, mc, hdl.data_buffer_ptrs_dev, ws_buf, flags, world_size, rank, ll_kind != "ll_sum_only", True,
+                            ll_kind != "ll_one_shot", out, out_res, res_d[:n_it].contiguous(), w_d, 1e-6)
                     torch.cuda.synchronize()
-                    assert allclose(ref_res, out_res.cpu(), atol=0.1, rtol=0.1), f"{mode} residual it{it}"
-                    assert allclose(ref_out, out.cpu(), atol=0.1, rtol=0.1), f"{mode} output it{it}"
+                    if ll_kind == "ll_sum_only":  # the all-reduce alone: fp32 sum in rank order, one rounding - bit for bit
+                        acc = torch.zeros((n_it, H), dtype=torch.float32)
+                        for x in inputs:
+                            acc = acc + x[:n_it].float()
+                        assert torch.equal(acc.to(torch.bfloat16).view(torch.int16), out.cpu().view(torch.int16)), f"sum it{it}"
+                    else:
+                        assert allclose(ref_res, out_res.cpu(), atol=0.1, rtol=0.1), f"{mode} residual it{it}"
+                        assert allclose(ref_out, out.cpu(), atol=0.1, rtol=0.1), f"{mode} output it{it}"
                 else:
                     in_x.zero_()
                     in_x[:n_it] = inputs[rank][:n_it].to(dev)
@@ -143,7 +156,8 @@ def _ar_task(rank, world_size, cases, name, q, device_index):
 
 
 CASES = [("ht", 128, 8192, 16, 3), ("ht", 77, 5120, 78, 2), ("ht_uneven", 77, 8192, 64, 2), ("ht", 24, 16384, 64, 2),
-         ("ll", 128, 8192, 16, 5), ("ll", 77, 7168, 78, 4), ("ll", 8, 4096, 4, 3), ("ll", 16, 16384, 4, 2)]
+         ("ll", 128, 8192, 16, 5), ("ll", 77, 7168, 78, 4), ("ll", 8, 4096, 4, 3), ("ll", 16, 16384, 4, 2),
+         ("ll_one_shot", 16, 8192, 4, 4), ("ll_one_shot", 7, 16384, 4, 3), ("ll_sum_only", 24, 8192, 4, 3)]
 
 
 def _spawn(world_size, one_gpu_per_rank=False, tuning="", cases=None, timeout=600):
@@ -277,14 +291,23 @@ def test_allreduce_rmsnorm_ws8_loopback(world_size):
         for mode, N, H, nblk, iters in (("ht", 64, 8192, 4, 3), ("ht", 61, 5120, 3, 2), ("ht_uneven", 96, 4096, 4, 2),
                                         ("ht", 16, 16384, 2, 2), ("ll", 16, 8192, 4, 5), ("ll", 13, 7168, 4, 4),
                                         ("ll", 24, 16384, 4, 3), ("ll_two_launches", 16, 8192, 4, 4),
-                                        ("ll_two_launches", 11, 16384, 4, 2)):
+                                        ("ll_two_launches", 11, 16384, 4, 2),
+                                        # round 6: the one-shot form (every rank pushes to every rank and reduces itself:
+                                        # the entry's use_two_shot = False) and the all-reduce alone (rmsnorm_fusion = False),
+                                        # whose output is checked BIT FOR BIT against the fp32 sum in rank order
+                                        ("ll_one_shot", 16, 8192, 4, 5), ("ll_one_shot", 13, 7168, 4, 4),
+                                        ("ll_one_shot_two_launches", 5, 16384, 4, 3), ("ll_sum_only", 16, 8192, 4, 3),
+                                        ("ll_one_shot_sum_only", 9, 4096, 4, 3)):
             N_pad = (N + ws - 1) // ws * ws
             # round 5: the low-latency entry runs both phases in one launch when the grid is resident at once (these sizes);
             # development key 35 = 1 keeps the scatter / reduce launches apart - the form larger grids still take
-            dev_set(35, 1 if mode == "ll_two_launches" else 0)
+            dev_set(35, 1 if mode.endswith("two_launches") else 0)
+            one_shot, sum_only = "one_shot" in mode, "sum_only" in mode
+            dev_set(52, 1 if one_shot else 0)
+            dev_set(53, 1 if sum_only else 0)
             if mode.startswith("ll"):
                 mode = "ll"
-                M_pad = 2 * math.ceil(N / ws) * ws * 3
+                M_pad = max(2 * math.ceil(N / ws) * ws, N * ws if one_shot else 0) * 3
                 bufs = [torch.full((M_pad, H // 2), -(2 ** 31), dtype=torch.int32, device=dev) for _ in range(ws)]
                 table = torch.tensor([b.data_ptr() for b in bufs], dtype=torch.int64, device=dev)
                 slot_bytes = (M_pad * H * 2 // 3) // 16 * 16
@@ -319,9 +342,19 @@ def test_allreduce_rmsnorm_ws8_loopback(world_size):
                     assert rc == 0, rc
                     torch.cuda.synchronize()
                     assert lib.hpc_allreduce_timeouts() == 0, f"{mode} N={N} H={H} it{it}: a bounded spin timed out"
-                    for r in range(ws):
-                        assert allclose(ref_res, out_res[r].cpu(), atol=0.1, rtol=0.1), f"ll residual rank {r} it{it}"
-                        assert allclose(ref_out, outs[r].cpu(), atol=0.1, rtol=0.1), f"ll output rank {r} it{it}"
+                    if sum_only:  # fp32 sum in rank order (from 0.0f: a -0.0 input is the sentinel and travels as +0.0), one rounding
+                        acc = torch.zeros((n_it, H), dtype=torch.float32)
+                        for x in inputs:
+                            acc = acc + x[:n_it].float()
+                        want = acc.to(torch.bfloat16)
+                        for r in range(ws):
+                            assert torch.equal(want.view(torch.int16), outs[r].cpu().view(torch.int16)), \
+                                f"ll sum rank {r} it{it} one_shot={one_shot}"
+                    else:
+                        for r in range(ws):
+                            assert allclose(ref_res, out_res[r].cpu(), atol=0.1, rtol=0.1), f"ll residual rank {r} it{it}"
+                            assert allclose(ref_out, outs[r].cpu(), atol=0.1, rtol=0.1), f"ll output rank {r} it{it}"
+                            assert torch.equal(outs[r], outs[0]) and torch.equal(out_res[r], out_res[0])  # every rank the same bits
                     assert all(int(f[0]) == (it + 1) % 3 for f in flags)  # every rank rotated its slots
                     continue
                 if mode == "ht_uneven":
@@ -356,6 +389,8 @@ def test_allreduce_rmsnorm_ws8_loopback(world_size):
         dev_set(10, 0)
         dev_set(11, 0)
         dev_set(35, 0)
+        dev_set(52, 0)
+        dev_set(53, 0)
 
 
 @pytest.mark.exclusive_gpu
