@@ -9,7 +9,7 @@ OUT = ROOT / "profiles"
 tag = sys.argv[1] if len(sys.argv) > 1 else subprocess.run(["git", "rev-parse", "--short=7", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
 
 # 1. kernel stats of the bench run (our kernels only)
-f = next(iter((G / "bench").rglob("*kernel_stats.csv")), None)
+f = max((G / "bench").rglob("*kernel_stats.csv"), key=lambda q: q.stat().st_mtime, default=None)  # the newest pass (gpurun_out accumulates)
 if f:
     rows = [r for r in csv.DictReader(open(f)) if "hpc::" in r["Name"]]
     with open(OUT / "round6_bench_kernel_stats.csv", "w") as fo:
