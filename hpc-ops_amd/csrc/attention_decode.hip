@@ -994,7 +994,9 @@ extern "C" int hpc_attention_decode_fp8_async(
     b.ks_row_stride = kscale_row_stride;
     b.ks_head_stride = kscale_head_stride;
     b.scale_log2 = a.scale_log2;
-    if (quant_type == 1) {
+    // quant_type 0 (per-token K scales, per-head V scales) runs there too since round 6 (development key 54 = 1: first generation)
+    b.ktok = quant_type == 0 ? 1 : 0;
+    if (quant_type == 1 || hpc_dev_tuning_get(54) != 1) {
       const int rc = try_second_generation(b, workspace, num_bins, num_batch, num_seq_q, num_head_q, num_head_kv, block_size,
                                            kcache_head_stride, vcache_head_stride, stream);
       if (rc <= 0) return rc;

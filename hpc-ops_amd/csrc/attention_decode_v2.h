@@ -25,6 +25,7 @@ struct Args {
   int ldq, ldy, qscale_stride, new_kv_included;
   int min_range_cost;  // smallest range of the in-kernel plan, in cost units (64-token tiles + 2 per request)
   int bf16;       // 1: bf16 q / K / V (no scales; ldq and every stride in BYTES), 0: fp8 e4m3
+  int ktok = 0;   // fp8: 1 = per-token K scales in the pages' tail rows (kscale + ks_* strides) and per-head V scales (quant_type 0)
   int pair_wgs[4];  // fp8, 4 head pairs: workgroups (= ranges) per pair, [0] = 0: equal shares
   int big_pct;      // > 100: ranges of the first half of the grid are this many percent of the others' length
   int dev_nomem;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing; results are wrong)

@@ -130,6 +130,15 @@ __device__ __forceinline__ void ld_q4(u32x4 (&q)[4], int voff_q, i32x4 rq_in) {
                : "=&v"(q[0]), "=&v"(q[1]), "=&v"(q[2]), "=&v"(q[3])
                : "v"(voff_q), "s"(rq));
 }
+// kKtok: the 64 K scales of a wave-iteration (one dword per lane)
+__device__ __forceinline__ void ld_ks(uint32_t& sc, int voff, i32x4 rs_in) {
+  const i32x4 rs = pin(rs_in);
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=&v"(sc) : "v"(voff), "s"(rs));
+}
+template <int N>
+__device__ __forceinline__ void wait_ks(uint32_t& sc) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(sc) : "n"(N));
+}
 template <int N>
 __device__ __forceinline__ void wait_q8(u32x4 (&q0)[4], u32x4 (&q1)[4]) {
   asm volatile("s_waitcnt vmcnt(%8)"
@@ -190,9 +199,17 @@ constexpr int kFMasked = 32;  // some token of the WI is invisible to some q row
 //        Same MFMA count per byte as the pair form, half the accumulators (2 tiles x 32 registers for 4 heads), half
 //        the exponentials.  A wave-iteration is 16 tokens like the bf16 form (same 8 KB of K + 8 KB of V).
 // kProf: development build that accumulates s_memtime deltas per wave (tools/prof_decode.py reads them)
-template <int kAux, bool kBf16 = false, bool kProf = false, bool kQuad = false>
+// kKtok: fp8 with PER-TOKEN K scales and per-head V scales (quant_type 0; reference tests/test_attention_decode_qkpertoken_
+//        perhead_vperhead_fp8.py).  The scales of a page live in its tail rows - row tok / 32, per head 32 floats = 128 bytes at
+//        the head's place in the row - so the 32 tokens x 2 heads of a wave-iteration are ONE contiguous 256-byte piece: one
+//        buffer_load_dword per wave-iteration (lane = head * 32 + token), issued between the K and the V loads, staged
+//        through 256 bytes of LDS per wave, read back as the four tokens of a lane's score rows.  Scores are scaled
+//        (s * qscale / sqrt(d) * log2 e) * kscale[token] - the first-generation kernel's order.
+template <int kAux, bool kBf16 = false, bool kProf = false, bool kQuad = false, bool kKtok = false>
 __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   static_assert(!(kBf16 && kQuad), "the quad form is fp8");
+  static_assert(!kKtok || (!kBf16 && !kQuad), "per-token K scales: the fp8 head-pair form");
+  __shared__ float s_ks[kKtok ? kWaves : 1][64];
   constexpr bool kWide = kBf16 || kQuad;     // 512-byte stage rows, 16-token wave-iterations
   __shared__ __attribute__((aligned(1024))) uint8_t s_wave[kWaves][kWaveLds];  // stage addresses are (base) ^ (bits 4-7)
   __shared__ float s_m[2][kWaves][16];
@@ -439,6 +456,13 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   const uint32_t kbs = static_cast<uint32_t>(a.k_block_stride), vbs = static_cast<uint32_t>(a.v_block_stride);  // < 4 GB (eligible())
   const bool mem = a.dev_nomem == 0;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing)
   i32x4 dk0, dk1, dv0, dv1;  // descriptors of the WI being issued
+  uint32_t ksr = 0;           // kKtok: the WI's 64 K scales in flight (lane = head * 32 + token)
+  i32x4 dks = i32x4{0, 0, 0, 0x00020000};
+  // K-scale tail row of the wave's WIs: they start at multiples of 32 tokens, so one row (tok / 32 within the page) and
+  // one page hold a WI's scales (pages of 32 / 64 tokens: eligible()); the pair's two heads are 2 x 128 contiguous bytes
+  const uint64_t ksbase_h = reinterpret_cast<uint64_t>(a.kscale) + static_cast<uint64_t>(mem_slice) * 2 * a.ks_head_stride +
+                            static_cast<uint64_t>(in0 >> 5) * a.ks_row_stride;
+  const uint32_t ksbs = static_cast<uint32_t>(a.ks_block_stride);
   auto make_descs = [&](int fl, int pid0, int pid1) __attribute__((always_inline)) {
     const int nrec0 = (fl & kFOn0) && mem ? -1 : 0, nrec1 = (fl & kFOn1) && mem ? -1 : 0;
     const uint64_t ka = kbase_h + static_cast<uint64_t>(static_cast<uint32_t>(pid0)) * kbs;
@@ -454,11 +478,18 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
       dk1 = srd(static_cast<uint32_t>(kb), static_cast<uint32_t>(kb >> 32), nrec1);
       dv1 = srd(static_cast<uint32_t>(vb), static_cast<uint32_t>(vb >> 32), nrec1);
     }
+    if constexpr (kKtok) {
+      const uint64_t sa = ksbase_h + static_cast<uint64_t>(static_cast<uint32_t>(pid0)) * ksbs;
+      dks = srd(static_cast<uint32_t>(sa), static_cast<uint32_t>(sa >> 32), (fl & kFOn0) ? 256 : 0);
+    }
   };
   auto issue_k0 = [&]() __attribute__((always_inline)) { ld_x4x4<kAux>(kr[0], k_voff0, dk0, ks1, ks2, ks3); };
   auto issue_k1 = [&]() __attribute__((always_inline)) { ld_x4x4<kAux>(kr[1], k_voff1, dk1, ks1, ks2, ks3); };
   auto issue_v0 = [&]() __attribute__((always_inline)) { ld_x4x4<kAux>(vr[0], v_voff0, dv0, vs1, vs2, vs3); };
   auto issue_v1 = [&]() __attribute__((always_inline)) { ld_x4x4<kAux>(vr[1], v_voff1, dv1, vs1, vs2, vs3); };
+  auto issue_ks = [&]() __attribute__((always_inline)) {  // (between K and V: the V waits do not change)
+    if constexpr (kKtok) ld_ks(ksr, lane * 4, dks);
+  };
 
   // ---- LDS stage addressing (loop-invariant per lane) ----------------------------------------------------------
   // stage image [row 0..31][256 B]; the 16-byte chunk c of row t sits in slot c ^ key(t), key(t) =
@@ -498,6 +529,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   u32x4 qf[2][kBf16 ? 4 : 2];  // Q fragments of row n: fp8 16-byte chunks g and g + 4; bf16 chunks g, g + 4, g + 8, g + 12
   float row_scale[2];   // qscale * kscale / sqrt(d) * log2(e)
   float out_scale;       // vscale (l_run carries the factor 256 of P~)
+  float out_scale_h[2] = {0.f, 0.f};  // kKtok: per head
   f32x4 o[2][8];         // O^T: o[hh][jj][r] = dim jj * 16 + 4 g + r of q row n
   float m_run[2], l_run[2];
   // Q fragments + q scales of the task's request, straight into qf / qsc.  Called when the PREVIOUS task has been
@@ -732,7 +764,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
       for (int hh = 0; hh < 2; ++hh) {
         float acc[8], M, L;
         combine4(hh, row16, c8, acc, M, L);
-        const float inv = (L > 0.f ? 1.0f / L : 0.f) * out_scale;
+        const float inv = (L > 0.f ? 1.0f / L : 0.f) * (kKtok ? out_scale_h[hh] : out_scale);
         if (row_ok(row16)) {
           if (nchunks == 1) {
             store_y(db, hh, row16, c8, acc, inv);
@@ -788,6 +820,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   make_descs(p2_fl, sgpr(p2_pid0), sgpr(p2_pid1));
   issue_k0();
   issue_k1();
+  issue_ks();
   issue_v0();
   issue_v1();
   p1_tok = p2_tok;
@@ -844,20 +877,29 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
           out_scale = 1.0f;
         } else {
           wait_q<0>(reinterpret_cast<u32x4(&)[2]>(qf[0]), reinterpret_cast<u32x4(&)[2]>(qf[1]), qsc[0], qsc[1]);
-          const float kmul = as_constf(a.kscale)[0];
+          const float kmul = kKtok ? 1.0f : as_constf(a.kscale)[0];
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) row_scale[hh] = a.scale_log2 * __uint_as_float(qsc[hh]) * kmul;
           out_scale = as_constf(a.vscale)[0];  // the 1/256 of the reference formula cancels: l = 256 sum p
+          if constexpr (kKtok) {  // per-head V scales
+            out_scale_h[0] = as_constf(a.vscale)[pr * 2];
+            out_scale_h[1] = as_constf(a.vscale)[pr * 2 + 1];
+          }
         }
       }
     };
     // registers -> the wave's LDS stage (rows of 256 B, chunks swizzled); a register set is free again as soon as
     // it has been written out: the next WI (of this or the next task) goes in flight
-    wait_x4x4<12>(kr[0]);
-    wait_x4x4<8>(kr[1]);
+    // (kKtok: the scale load sits between the K and the V loads - one more load younger than K)
+    wait_x4x4<12 + (kKtok ? 1 : 0)>(kr[0]);
+    wait_x4x4<8 + (kKtok ? 1 : 0)>(kr[1]);
     if constexpr (kProf) { const uint64_t t = now(); pf_wk += t - pf_last; pf_last = t; }
     write_k(0);
     write_k(1);
+    if constexpr (kKtok) {
+      wait_ks<8>(ksr);
+      s_ks[wave][lane] = __uint_as_float(ksr);
+    }
     if constexpr (kProf) { const uint64_t t = now(); pf_wr += t - pf_last; pf_last = t; }
     wait_x4x4<4>(vr[0]);
     wait_x4x4<0>(vr[1]);
@@ -874,6 +916,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     }
     issue_k0();
     issue_k1();
+    issue_ks();
     issue_v0();
     issue_v1();
     q_ready();
@@ -1051,9 +1094,15 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
       for (int hh = 0; hh < 2; ++hh) {
         const float rsc = row_scale[hh];
   #pragma unroll
-        for (int tb = 0; tb < 2; ++tb)
+        for (int tb = 0; tb < 2; ++tb) {
+          f32x4 kt = f32x4{1.f, 1.f, 1.f, 1.f};
+          if constexpr (kKtok) kt = *reinterpret_cast<const f32x4*>(&s_ks[wave][hh * 32 + tb * 16 + g * 4]);
   #pragma unroll
-          for (int r = 0; r < 4; ++r) sacc[hh][tb][r] *= rsc;
+          for (int r = 0; r < 4; ++r) {
+            sacc[hh][tb][r] *= rsc;
+            if constexpr (kKtok) sacc[hh][tb][r] *= kt[r];
+          }
+        }
       }
       if (d_fl & kFMasked) {  // wave-uniform: only the WIs that hold a request's last tokens
         const int sq_row = n >> a.g_shift;
@@ -1172,6 +1221,12 @@ int mode_of(const Args& a, int num_head_q, int block_size, int64_t k_head_stride
                   a.k_block_stride < (1ll << 32) && a.v_block_stride < (1ll << 32) && a.num_batch <= 64 * 16 &&
                   static_cast<int64_t>(a.num_batch) * (a.num_head_kv / 2) * 4 <= kCounterBytes;
   if (!ok) return 0;
+  // per-token K scales (quant_type 0): a wave-iteration's 32 tokens x 2 heads of scales must be one contiguous 256-byte piece
+  // of a page's tail row - pages of 32 / 64 tokens, 32 floats per head and row, adjacent heads 128 bytes apart
+  if (a.ktok && (a.bf16 || block_size < 32 || a.ks_head_stride != 128 || a.ks_block_stride <= 0 || a.ks_block_stride >= (1ll << 32) ||
+                 (a.ks_row_stride % 4) != 0))
+    return 0;
+  if (a.ktok) return 1;
   // fp8 with <= 8 q rows per kv head and a multiple of 4 kv heads can run four heads per workgroup (kQuad).  Measured
   // 3-5 % SLOWER than head pairs on the graded shapes (uniform 8k 188.8 vs 183.0 us, C3 mix 145.4 vs 138.6 us, same box,
   // profiles/round3_decode_fp8_forms_ab.txt): the wider rows do not pay in the kernel although they do in a pure streaming
@@ -1246,7 +1301,9 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
         (num_wg / 2) % (a.num_head_kv / (mode == 2 ? 4 : 2)) == 0)
       a.big_pct = k32;
   }
-  if (a.bf16) {
+  if (a.ktok) {
+    decode2_kernel<2, false, false, false, true><<<num_wg, kThreads, 0, stream>>>(a);
+  } else if (a.bf16) {
     if (temporal)
       decode2_kernel<0, true><<<num_wg, kThreads, 0, stream>>>(a);
     else
