@@ -59,6 +59,11 @@ constexpr int kXsOff = 8 * kUnit;      // 2 x 1 KB of token scales + 1 KB nobody
 constexpr int kExtOff = kXsOff + 3 * 1024;
 constexpr int kExtXsOff = kExtOff + 2 * 2048;
 constexpr int kLdsMain = kExtXsOff + 2 * 256;
+// the HALF-tile body keeps THREE k-tiles in flight (round 6): it has no late-token unit, so three buffers of [U0 | U3 | U1] =
+// 144 KB fit - [U0 b0 b1 b2 | U3 b0 b1 b2 | U1 b0 b1 b2], then 3 x 1 KB of token scales + 1 KB nobody reads
+constexpr int kHalfBOff = 6 * kUnit;
+constexpr int kHalfXsOff = 9 * kUnit;
+constexpr int kLdsHalf = kHalfXsOff + 4 * 1024;
 // the tail body's layout (p8_tail_body): per-wave weight rings, two chunk buffers of token slabs, their scales
 constexpr int kTW = 3;                               // stages of a wave's weight ring = k-tiles of a token chunk
 constexpr int kTWOff = 0;                            // [8 waves][kTW][32 rows x 128 B]
@@ -72,7 +77,7 @@ constexpr int kRXOff = 0;                            // [2 chunk buffers][kTR sl
 constexpr int kRSOff = kRXOff + 2 * kTR * 8192;      // [2][kTR][64 floats]
 constexpr int kRDummy = kRSOff + 2 * kTR * 256;
 static_assert(kRDummy + 256 <= kLdsTail, "the register-streamed tail body fits the tail body's LDS");
-constexpr int kLds = kLdsTail > kLdsMain ? kLdsTail : kLdsMain;
+constexpr int kLds = (kLdsTail > kLdsMain ? kLdsTail : kLdsMain) > kLdsHalf ? (kLdsTail > kLdsMain ? kLdsTail : kLdsMain) : kLdsHalf;
 static_assert(kLds <= 160 * 1024, "one workgroup per CU");
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -282,6 +287,13 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   const int wn = wave >> 2, wm = wave & 3;  // group (weight-row half) / 64-token strip
   const int K = a.K, KB = a.KB;
   constexpr int kJ = kHalf ? 2 : 4;  // token blocks per strip
+  // kNB buffers = k-tiles in flight: k-tile T -> buffer T % kNB.  The full body has room for two; the half-tile body (no late
+  // token unit) for THREE: at 128 rows per group (configs[3] at T = 1024) every tile streams its weight tile from memory, and
+  // with two k-tiles in flight a CU's stream was bound by the round trip - 4.25 TB/s of weights whatever the body computed
+  // (the half body took 63 us per tile against 72 for a full one with twice the MFMAs)
+  constexpr int kNB = kHalf ? 3 : 2;
+  constexpr int kBOffL = kHalf ? kHalfBOff : kBOff;
+  constexpr int kXsOffL = kHalf ? kHalfXsOff : kXsOff;
   // tile-local token slot (strip * 64 + 16 j + r) -> row of the tile
   auto row_of_slot = [](int slot) { return kHalf ? (slot >> 6) * 32 + (slot & 31) : slot; };
 
@@ -302,7 +314,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     const int wrow = kAct ? (ur >> 6) * inter + col0 + (ur & 63) : (ur >> 6) * 128 + (ur & 63);
     w_voff[q] = static_cast<unsigned>(wrow) * static_cast<unsigned>(K) + p_chunk * 16;
   }
-  // k-tile T -> buffer T & 1 (`par`, a compile-time value).  Past the end: empty descriptors (nothing fetched,
+  // k-tile T -> buffer T % kNB (`par`, a compile-time value).  Past the end: empty descriptors (nothing fetched,
   // zeros written, still counted by vmcnt).  One piece (q = 0, 1) per call.
   auto dma_w = [&](int T, bool on, auto par, auto late, int q) {
     constexpr int kP = decltype(par)::value, kLate = decltype(late)::value;
@@ -313,17 +325,20 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     // loses every issue slot to the MMA wave of its SIMD (round 4 paid it on every per-tensor call: matrix pipe busy
     // 0.85 -> 0.72)
     const bool k_ok = !kKTail || koff + p_chunk * 16 < K;
-    uint8_t* base = s_mem + kAOff + (2 * kLate + kP) * kUnit;
+    uint8_t* base = s_mem + kAOff + (kNB * kLate + kP) * kUnit;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(base + (wave * 2 + q) * 1024), 16,
                                              k_ok ? w_voff[q] : 0xffffff00u, koff + (kLate ? late_w : 0), 0, 0);
   };
-  // the weight pieces of k-tiles 0 and 1 do not depend on the token rows: they go out before the row-index loads
+  // the weight pieces of k-tile 0 (two buffers: and the early ones of k-tile 1) do not depend on the token rows: they go out
+  // before the row-index loads
   dma_w(0, true, IntC<0>{}, IntC<0>{}, 0);
   dma_w(0, true, IntC<0>{}, IntC<0>{}, 1);
   dma_w(0, true, IntC<0>{}, IntC<1>{}, 0);
   dma_w(0, true, IntC<0>{}, IntC<1>{}, 1);
-  dma_w(1, 1 < KB, IntC<1>{}, IntC<0>{}, 0);
-  dma_w(1, 1 < KB, IntC<1>{}, IntC<0>{}, 1);
+  if constexpr (kNB == 2) {
+    dma_w(1, 1 < KB, IntC<1>{}, IntC<0>{}, 0);
+    dma_w(1, 1 < KB, IntC<1>{}, IntC<0>{}, 1);
+  }
 
   unsigned x_voff[2][2];
 #pragma unroll
@@ -372,7 +387,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     const int koff = T * kBK;
     const auto rx = make_rsrc(a.x, on ? a.x_bytes : 0u);
     const bool k_ok = !kKTail || koff + p_chunk * 16 < K;
-    uint8_t* base = s_mem + kBOff + (2 * kLate + kP) * kUnit;
+    uint8_t* base = s_mem + kBOffL + (kNB * kLate + kP) * kUnit;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(base + (wave * 2 + q) * 1024), 16,
                                              k_ok ? x_voff[kLate][q] : 0xffffff00u, koff, 0, 0);
   };
@@ -395,7 +410,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       // v_cndmask + v_readfirstlane per k-tile - VALU work in a load section, which loses every issue slot to the MMA
       // wave of its SIMD; what is left is a scalar select on `on`)
       const auto rs = make_rsrc(a.xs, on ? xs_nrec : 0u);
-      uint8_t* dst = s_mem + kXsOff + (wave < 4 ? kP * 1024 + wave * 256 : 2048);
+      uint8_t* dst = s_mem + kXsOffL + (wave < 4 ? kP * 1024 + wave * 256 : kNB * 1024);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 4, xs_voff, T * xs_kb_bytes, 0, 0);
     }
   };
@@ -417,10 +432,19 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
     a_off[c] = kAOff + (wn * 64 + r16) * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);
-    b_off[c] = kBOff + (wm * 32 + r16) * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);
+    b_off[c] = kBOffL + (wm * 32 + r16) * kBK + (((g4 + 4 * c) ^ (r16 & 7)) << 4);
     asm volatile("" : "+v"(a_off[c]), "+v"(b_off[c]));  // opaque: hipcc would otherwise fold the immediates back into copies
   }
-  int xs_rd = kXsOff + wm * 256 + r16 * 16;  // this lane's four token scales (token blocks 0-3) in scale buffer 0 (opaque base: as above)
+  // (three buffers: the late weight unit's third buffer ends past the 16-bit offset field - its own base, the half body has the registers)
+  int a_off_late[2] = {a_off[0], a_off[1]};
+  if constexpr (kNB == 3) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      a_off_late[c] = a_off[c] + kNB * kUnit;
+      asm volatile("" : "+v"(a_off_late[c]));
+    }
+  }
+  int xs_rd = kXsOffL + wm * 256 + r16 * 16;  // this lane's four token scales (token blocks 0-3) in scale buffer 0 (opaque base: as above)
   asm volatile("" : "+v"(xs_rd));
   // ride-along block: row block wm of either weight unit, the 16 rows' operand bytes and scales (read bases: opaque as above)
   f32x4 tot_ext[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};  // rows 16 wm .. / 64 + 16 wm .. of the wave's half
@@ -434,7 +458,9 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int c = 0; c < 2; ++c) af[i][c] = *reinterpret_cast<const u32x4*>(s_mem + a_off[c] + (2 * late + kP) * kUnit + i * 2048);
+      for (int c = 0; c < 2; ++c)
+        af[i][c] = kNB == 3 && late ? *reinterpret_cast<const u32x4*>(s_mem + a_off_late[c] + kP * kUnit + i * 2048)
+                                    : *reinterpret_cast<const u32x4*>(s_mem + a_off[c] + (kNB * late + kP) * kUnit + i * 2048);
   };
   auto read_b = [&](auto par, int late, u32x4 (&bf)[2][2]) {
     constexpr int kP = decltype(par)::value;
@@ -442,7 +468,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int c = 0; c < 2; ++c)
-        bf[j][c] = *reinterpret_cast<const u32x4*>(s_mem + b_off[c] + (2 * late + kP) * kUnit + j * 2048);
+        bf[j][c] = *reinterpret_cast<const u32x4*>(s_mem + b_off[c] + (kNB * late + kP) * kUnit + j * 2048);
   };
 
   // One section: 4 row blocks x all 4 token blocks (16 MFMAs), written as the software pipeline it has to be:
@@ -572,7 +598,9 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
 #pragma unroll
   for (int i = 0; i < 7; ++i) n_yload += y_exists(i) && sy(i) == 0;
   // s_waitcnt immediates: vmcnt = n (split 4 + 2 bits), expcnt untouched, lgkmcnt 0 (or untouched: | 0x0F00)
-  const int fly_x = kPiecesY + n_xload, fly_y = 2 + n_yload;  // compile-time values after inlining (checked below)
+  // (every further buffer puts one more k-tile's pieces - the Y half's and the X half's two - between a piece and its wait: the
+  //  stream a wave issues is [U0 U1 (U2) scales U3] per k-tile, and loads retire in order)
+  const int fly_x = kPiecesY + n_xload + (kNB - 2) * (kPiecesY + 2), fly_y = 2 + n_yload + (kNB - 2) * (kPiecesY + 2);  // compile-time values after inlining
 
   // ---- development: s_memtime log of the section boundaries (Cfg::kProf) -------------------------------------------
   // A = first instruction behind the barrier that opens an MMA section, B = behind its last MFMA, C = behind the barrier
@@ -602,6 +630,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     switch (n) {
 #define HPC_P8_WAIT(N) case N: __builtin_amdgcn_s_waitcnt(0x0070 | ((N) & 15) | (((N) >> 4) << 14)); break;
       HPC_P8_WAIT(2) HPC_P8_WAIT(3) HPC_P8_WAIT(4) HPC_P8_WAIT(5) HPC_P8_WAIT(6) HPC_P8_WAIT(7) HPC_P8_WAIT(8) HPC_P8_WAIT(9)
+      HPC_P8_WAIT(10) HPC_P8_WAIT(11) HPC_P8_WAIT(12) HPC_P8_WAIT(13) HPC_P8_WAIT(14) HPC_P8_WAIT(15) HPC_P8_WAIT(16) HPC_P8_WAIT(17)
 #undef HPC_P8_WAIT
       default: __builtin_amdgcn_s_waitcnt(0x0070); break;  // vmcnt(0)
     }
@@ -635,22 +664,45 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   // that precedes the issue.  Waits: end of load section X leaves fly_x pieces in flight - U3(T), read behind
   // the next barrier but one, has landed; end of load section Y leaves fly_y - all of k-tile T+1 up to its scales
   // has landed.  Here the weight pieces went first, so the first wait leaves k-tile 1's token pieces.
-  dma_x(0, true, IntC<0>{}, IntC<0>{}, 0);
-  dma_x(0, true, IntC<0>{}, IntC<0>{}, 1);
-  if constexpr (!kHalf) {
-    dma_x(0, true, IntC<0>{}, IntC<1>{}, 0);
-    dma_x(0, true, IntC<0>{}, IntC<1>{}, 1);
+  if constexpr (kNB == 2) {
+    dma_x(0, true, IntC<0>{}, IntC<0>{}, 0);
+    dma_x(0, true, IntC<0>{}, IntC<0>{}, 1);
+    if constexpr (!kHalf) {
+      dma_x(0, true, IntC<0>{}, IntC<1>{}, 0);
+      dma_x(0, true, IntC<0>{}, IntC<1>{}, 1);
+    }
+    dma_xs(0, true, IntC<0>{});
+    dma_x(1, 1 < KB, IntC<1>{}, IntC<0>{}, 0);
+    dma_x(1, 1 < KB, IntC<1>{}, IntC<0>{}, 1);
+    if constexpr (!kHalf) {
+      dma_x(1, 1 < KB, IntC<1>{}, IntC<1>{}, 0);
+      dma_x(1, 1 < KB, IntC<1>{}, IntC<1>{}, 1);
+    }
+    dma_xs(1, 1 < KB, IntC<1>{});
+    constexpr int kFly0 = (kHasXs ? 5 : 4) - (kHalf ? 2 : 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70 | kFly0);  // k-tile 0 (and the weight pieces of k-tile 1) have landed
+  } else {
+    // three buffers (half body): the rest of k-tiles 0 .. 2 in the loop's own order - [U0 U1 scales U3] per k-tile; U3 of
+    // k-tile 2 is load section X's of k-tile 0 - so that the loop's waits hold from the first k-tile on (k-tile 0's weight
+    // pieces are older than the loop would have made them: its waits only get more conservative)
+    dma_x(0, true, IntC<0>{}, IntC<0>{}, 0);
+    dma_x(0, true, IntC<0>{}, IntC<0>{}, 1);
+    dma_xs(0, true, IntC<0>{});
+    dma_w(1, 1 < KB, IntC<1>{}, IntC<0>{}, 0);
+    dma_w(1, 1 < KB, IntC<1>{}, IntC<0>{}, 1);
+    dma_x(1, 1 < KB, IntC<1>{}, IntC<0>{}, 0);
+    dma_x(1, 1 < KB, IntC<1>{}, IntC<0>{}, 1);
+    dma_xs(1, 1 < KB, IntC<1>{});
+    dma_w(1, 1 < KB, IntC<1>{}, IntC<1>{}, 0);
+    dma_w(1, 1 < KB, IntC<1>{}, IntC<1>{}, 1);
+    dma_w(2, 2 < KB, IntC<2>{}, IntC<0>{}, 0);
+    dma_w(2, 2 < KB, IntC<2>{}, IntC<0>{}, 1);
+    dma_x(2, 2 < KB, IntC<2>{}, IntC<0>{}, 0);
+    dma_x(2, 2 < KB, IntC<2>{}, IntC<0>{}, 1);
+    dma_xs(2, 2 < KB, IntC<2>{});
+    constexpr int kFly0 = 2 * (4 + (kHasXs ? 1 : 0)) + 2;  // everything younger than k-tile 0's scales
+    __builtin_amdgcn_s_waitcnt(0x0F70 | kFly0);  // k-tile 0 has landed
   }
-  dma_xs(0, true, IntC<0>{});
-  dma_x(1, 1 < KB, IntC<1>{}, IntC<0>{}, 0);
-  dma_x(1, 1 < KB, IntC<1>{}, IntC<0>{}, 1);
-  if constexpr (!kHalf) {
-    dma_x(1, 1 < KB, IntC<1>{}, IntC<1>{}, 0);
-    dma_x(1, 1 < KB, IntC<1>{}, IntC<1>{}, 1);
-  }
-  dma_xs(1, 1 < KB, IntC<1>{});
-  constexpr int kFly0 = (kHasXs ? 5 : 4) - (kHalf ? 2 : 0);
-  __builtin_amdgcn_s_waitcnt(0x0F70 | kFly0);  // k-tile 0 (and the weight pieces of k-tile 1) have landed
   __builtin_amdgcn_s_barrier();
   if (wn == 1) __builtin_amdgcn_s_barrier();  // the second group runs one barrier behind from here on
   __builtin_amdgcn_sched_barrier(0);
@@ -659,17 +711,18 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   float f[4] = {1.f, 1.f, 1.f, 1.f};
   auto k_tile = [&](int T, auto par) {
     constexpr int kP = decltype(par)::value;
-    const bool on1 = T + 1 < KB, on2 = T + 2 < KB;
-    auto x_piece = [&](int i) { dma_w(T + 1, on1, IntC<1 - kP>{}, IntC<1>{}, i); };  // U3(T + 1), piece q = i
+    // (kNB buffers: "T + 1" / "T + 2" of the two-buffer schedule are T + kNB - 1 / T + kNB)
+    const bool on1 = T + kNB - 1 < KB, on2 = T + kNB < KB;
+    auto x_piece = [&](int i) { dma_w(T + kNB - 1, on1, IntC<(kP + kNB - 1) % kNB>{}, IntC<1>{}, i); };  // U3(T + 1), piece q = i
     auto y_piece = [&](int i) {  // U0(T + 2) q0 q1, U1(T + 2) q0 q1, U2(T + 2) q0 q1, scales(T + 2)
       if (i < 2) {
-        dma_w(T + 2, on2, IntC<kP>{}, IntC<0>{}, i);
+        dma_w(T + kNB, on2, IntC<kP>{}, IntC<0>{}, i);
       } else if (i < 4) {
-        dma_x(T + 2, on2, IntC<kP>{}, IntC<0>{}, i - 2);
+        dma_x(T + kNB, on2, IntC<kP>{}, IntC<0>{}, i - 2);
       } else if (i < 6) {
-        if constexpr (!kHalf) dma_x(T + 2, on2, IntC<kP>{}, IntC<1>{}, i - 4);
+        if constexpr (!kHalf) dma_x(T + kNB, on2, IntC<kP>{}, IntC<1>{}, i - 4);
       } else {
-        dma_xs(T + 2, on2, IntC<kP>{});
+        dma_xs(T + kNB, on2, IntC<kP>{});
       }
     };
     auto issue_x = [&](int slot) {
@@ -723,9 +776,11 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     if constexpr (Cfg::kPrio && Cfg::kEarly > 0) __builtin_amdgcn_s_setprio(0);
     apply_tail(4, f);
   };
-  for (int kb = 0; kb < KB; kb += 2) {
+  for (int kb = 0; kb < KB; kb += kNB) {
     k_tile(kb, IntC<0>{});
     if (kb + 1 < KB) k_tile(kb + 1, IntC<1>{});
+    if constexpr (kNB == 3)
+      if (kb + 2 < KB) k_tile(kb + 2, IntC<2>{});
   }
   if constexpr (Cfg::kCarry && kHasXs) {  // the last section's pending blocks (row half 4 .. 7)
 #pragma unroll
