@@ -508,9 +508,9 @@ def moe_block(dev, hpc, with_cpu=True, iters=10, low_latency=True, big=True):
         torch.cuda.empty_cache()
     if not low_latency:
         return out
-    # the low-latency end of the same configuration: weight streaming, HBM-bound
+    # the low-latency end of the same configuration (BASELINE configs[3]: T in {16, 64, 256, 1024, 4096}): weight streaming, HBM-bound
     low = {}
-    for Tl in (16, 256):
+    for Tl in (16, 64, 256, 1024):
         ml = c4_inputs(dev, w, tokens=Tl)
         for kk in ("guw", "guws", "dw", "dws"):
             ml[kk] = m[kk]

@@ -389,7 +389,8 @@ def test_group_gemm_blockwise_many_groups(tiled_mode, num_group):
 
 @pytest.mark.dev
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,k", [(512, 512), (768, 1408), (256, 2048)])  # 4, 11 and 16 k-tiles: shorter than / not a multiple of / longer
+@pytest.mark.parametrize("n,k", [(512, 512), (768, 1408), (256, 2048),    # 4, 11 and 16 k-tiles: shorter than / not a multiple of / longer
+                                 (256, 128), (256, 256), (512, 384)])    # 1, 2, 3 k-tiles: shorter than every prefetch depth (round 6: three buffers in the half body)
 def test_group_gemm_tail_body_is_bit_identical(n, k):                      # than the rings' period of 6 k-tiles
     """A group's last token tile with <= 64 rows runs the TAIL body of the 256 x 256 kernel (round 5: per-wave weight
     rings, 64-token chunks of three k-slabs, one barrier per three k-tiles; a group's ONLY tile - every third group here -
