@@ -280,7 +280,10 @@ struct CfgNoPrio : CfgProduct { static constexpr bool kPrio = false; };
 template <class Cfg, bool kHasXs, bool kNoDma, bool kAct, bool kHalf, bool kKTail, bool kExt = false>
 __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, int mt0, int n0, int m_cnt, int m0, int ext0 = 0,
                                         int ext_cnt = 0) {
-  static_assert(!kExt || (kHasXs && !kHalf && !kNoDma && !kKTail), "ride-along rows: blockwise full body only");
+  static_assert(!kExt || (!kHalf && !kNoDma && !kKTail), "ride-along rows: full body only");
+  // per-tensor scales + ride-along rows: there is no scale piece to ride in, so the body gets the seventh DMA slot anyway
+  // (waves 4 / 5 fetch the rows, the others an empty piece: equal counts), and the block accumulates in the matrix pipe
+  constexpr bool kXsSlot = kHasXs || kExt;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r16 = lane & 15, g4 = lane >> 4;
@@ -373,7 +376,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       const int tok = ext0 + (er < ext_cnt ? er : ext_cnt - 1);
       const int xrow = a.row_index ? a.row_index[m0 + tok] : m0 + tok;
       xs_voff = static_cast<unsigned>(xrow) * static_cast<unsigned>(K) + p_chunk * 16;
-    } else if (wave == 6) {
+    } else if (kHasXs && wave == 6) {
       const int er = lane >> 2;  // position 4 r16 = byte 16 r16 of the 256 B: where xs_rd + ext_sx points
       const int tok = ext0 + (er < ext_cnt ? er : ext_cnt - 1);
       const long col0 = a.col_base ? static_cast<long>(as_const(a.col_base)[e]) * a.tile_m : 0;
@@ -391,7 +394,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(base + (wave * 2 + q) * 1024), 16,
                                              k_ok ? x_voff[kLate][q] : 0xffffff00u, koff, 0, 0);
   };
-  const unsigned xs_nrec = __builtin_amdgcn_readfirstlane(wave < 4 || (kExt && wave == 6) ? 0xffffffffu : 0u);
+  const unsigned xs_nrec = __builtin_amdgcn_readfirstlane(kHasXs && (wave < 4 || (kExt && wave == 6)) ? 0xffffffffu : 0u);
   auto dma_xs = [&](int T, bool on, auto par) {
     constexpr int kP = decltype(par)::value;
     if constexpr (kExt) {
@@ -400,7 +403,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(s_mem + kExtOff + kP * 2048 + (wave - 4) * 1024), 16, xs_voff,
                                                  T * kBK, 0, 0);
       } else {
-        const auto rs = make_rsrc(a.xs, on ? xs_nrec : 0u);
+        const auto rs = make_rsrc(kHasXs ? static_cast<const void*>(a.xs) : static_cast<const void*>(a.x), on ? xs_nrec : 0u);
         uint8_t* dst = s_mem + (wave < 4 ? kXsOff + kP * 1024 + wave * 256 : (wave == 6 ? kExtXsOff + kP * 256 : kXsOff + 2048));
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)dst, 4, xs_voff, T * xs_kb_bytes, 0, 0);
       }
@@ -524,7 +527,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
             b_ext[c] = *reinterpret_cast<const u32x4*>(s_mem + ((a_off[0] + ext_sb) ^ (c * 64)) + kP * 2048);
             a_ext[0][c] = *reinterpret_cast<const u32x4*>(s_mem + ((a_off[0] + ext_sa) ^ (c * 64)) + kP * kUnit);
           }
-          xs_ext = *reinterpret_cast<const float*>(s_mem + xs_rd + ext_sx + kP * 256);
+          if constexpr (kHasXs) xs_ext = *reinterpret_cast<const float*>(s_mem + xs_rd + ext_sx + kP * 256);
           __builtin_amdgcn_sched_barrier(0);
         }
         if (n == 12) {  // row block 2 is finished: row block wm of U3
@@ -535,7 +538,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
         }
         if (n == kN) {
           __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the just-in-time reads (nothing else is outstanding there)
-          f_ext = wsk * xs_ext;
+          if constexpr (kHasXs) f_ext = wsk * xs_ext;
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -567,7 +570,16 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       } else {
         // per-tensor: one scale per group: accumulate straight into the running sum, scale once in the epilogue
         // (the reference scales every k-tile: same value up to fp32 rounding)
-        tot[i0 + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, tot[i0 + i][j], 0, 0, 0, 0, 0, 0);
+        if (n < kN) {
+          tot[i0 + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, tot[i0 + i][j], 0, 0, 0, 0, 0, 0);
+          // (kExt: the scale slot's DMA is a wave-uniform branch and the loop several basic blocks - keep every MFMA where it
+          //  is written, like the folds of the blockwise form)
+          if constexpr (kExt) asm volatile("" : "+v"(tot[i0 + i][j]));
+        } else {
+          tot_ext[n >= kN ? n - kN : 0] =
+              __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, tot_ext[n >= kN ? n - kN : 0], 0, 0, 0, 0, 0, 0);
+          asm volatile("" : "+v"(tot_ext[n >= kN ? n - kN : 0]));
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       hook(n);
@@ -590,8 +602,8 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
   // ---- DMA schedule (see the Cfg structs): slots of this body's pieces and the two waits that follow from them ------
   auto sx = [](int i) { return kHalf ? Cfg::hx(i) : Cfg::fx(i); };
   auto sy = [](int i) { return kHalf ? Cfg::hy(i) : Cfg::fy(i); };
-  auto y_exists = [](int i) { return i < 4 || (i < 6 ? !kHalf : kHasXs); };
-  constexpr int kPiecesY = (kHalf ? 4 : 6) + (kHasXs ? 1 : 0);
+  auto y_exists = [](int i) { return i < 4 || (i < 6 ? !kHalf : kXsSlot); };
+  constexpr int kPiecesY = (kHalf ? 4 : 6) + (kXsSlot ? 1 : 0);
   int n_xload = 0, n_yload = 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) n_xload += sx(i) == 0;
@@ -679,7 +691,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       dma_x(1, 1 < KB, IntC<1>{}, IntC<1>{}, 1);
     }
     dma_xs(1, 1 < KB, IntC<1>{});
-    constexpr int kFly0 = (kHasXs ? 5 : 4) - (kHalf ? 2 : 0);
+    constexpr int kFly0 = (kXsSlot ? 5 : 4) - (kHalf ? 2 : 0);
     __builtin_amdgcn_s_waitcnt(0x0F70 | kFly0);  // k-tile 0 (and the weight pieces of k-tile 1) have landed
   } else {
     // three buffers (half body): the rest of k-tiles 0 .. 2 in the loop's own order - [U0 U1 scales U3] per k-tile; U3 of
@@ -700,7 +712,7 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     dma_x(2, 2 < KB, IntC<2>{}, IntC<0>{}, 0);
     dma_x(2, 2 < KB, IntC<2>{}, IntC<0>{}, 1);
     dma_xs(2, 2 < KB, IntC<2>{});
-    constexpr int kFly0 = 2 * (4 + (kHasXs ? 1 : 0)) + 2;  // everything younger than k-tile 0's scales
+    constexpr int kFly0 = 2 * (4 + (kXsSlot ? 1 : 0)) + 2;  // everything younger than k-tile 0's scales
     __builtin_amdgcn_s_waitcnt(0x0F70 | kFly0);  // k-tile 0 has landed
   }
   __builtin_amdgcn_s_barrier();
@@ -799,6 +811,10 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) tot[i][j] *= gs;
+    if constexpr (kExt) {
+      tot_ext[0] *= gs;
+      tot_ext[1] *= gs;
+    }
   }
   if constexpr (kAct) {
     // ---- fused activation epilogue ------------------------------------------------------------------------------
@@ -903,7 +919,33 @@ __device__ __forceinline__ void p8_body(const Args& a, uint8_t* s_mem, int e, in
       }
     }
     __syncthreads();
-    if constexpr (kExt) {
+    if constexpr (kExt && !kHasXs) {
+      // per-tensor API: a = silu(g) * u (bf16-rounded factors and product when use_bf16_mul), times one scale - `finish` above,
+      // value for value; no abs-max, so no second barrier
+      if (wn == 0 && r16 < ext_cnt) {
+        const float sc = a.act_mul_scale[0];
+        uint8_t* orow = a.act_out + static_cast<long>(m0 + ext0 + r16) * inter + col0 + wm * 16 + g4 * 4;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const u32x2 ov = *reinterpret_cast<const u32x2*>(ext_xch + u * 128);
+          const uint32_t m01 = pack_bf16x2(tot_ext[u][0], tot_ext[u][1]), m23 = pack_bf16x2(tot_ext[u][2], tot_ext[u][3]);
+          const float gv[4] = {bf16lo_to_f32(m01), bf16hi_to_f32(m01), bf16lo_to_f32(m23), bf16hi_to_f32(m23)};
+          const float uv[4] = {bf16lo_to_f32(ov[0]), bf16hi_to_f32(ov[0]), bf16lo_to_f32(ov[1]), bf16hi_to_f32(ov[1])};
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sv = gv[r] / (1.0f + __expf(-gv[r]));
+            if (a.use_bf16_mul)
+              sv = bf16_to_f32(f32_to_bf16(bf16_to_f32(f32_to_bf16(sv)) * uv[r]));
+            else
+              sv *= uv[r];
+            v[r] = sv * sc;
+          }
+          *reinterpret_cast<uint32_t*>(orow + u * 64) = quant_4xe4m3(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    if constexpr (kExt && kHasXs) {
       if (wn == 0) {
         float amax = 0.f;
 #pragma unroll
@@ -1538,7 +1580,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   __shared__ __attribute__((aligned(1024))) uint8_t s_mem[kLds];
   const int nt = a.N / kBN;  // kAct: N = 2 * inter, tile tn = columns [tn * 128, +128) of gate and of up
   const Item it = locate_item(as_const(cu_tiles), a.seqlens, a.cu_seqlens, num_group, nt, threadIdx.x & 63, blockIdx.x,
-                              a.item_order, kHasXs && !kNoDma && !kKTail ? a.ext_rows : 0);
+                              a.item_order, !kNoDma && !kKTail ? a.ext_rows : 0);
   if (!it.valid) return;
   const int e = __builtin_amdgcn_readfirstlane(it.e);
   const int m_cnt = __builtin_amdgcn_readfirstlane(it.m_cnt);
@@ -1560,7 +1602,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
     p8_tail_body<kHasXs, kAct, kKTail, false>(a, s_mem, e, mt0, n0, m_cnt, m0);
   else if (m_cnt - mt0 <= 128 && a.no_half_tile != 1)
     p8_body<Cfg, kHasXs, kNoDma, kAct, true, kKTail>(a, s_mem, e, mt0, n0, m_cnt, m0);
-  else if constexpr (kHasXs && !kNoDma && !kKTail) {
+  else if constexpr (!kNoDma && !kKTail) {
     // a full tile of a group whose short tail rides along (locate_item) carries up to 16 of those rows as a 17th token block
     const int ext_cnt = __builtin_amdgcn_readfirstlane(it.ext_cnt);
     if (ext_cnt > 0)
@@ -1608,7 +1650,7 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int n
   a.tail_regs = hpc_dev_tuning_get(26) == 1;
   // a group's short tail (<= 16 rows per full tile it has) rides along with its full tiles instead of running as a tail
   // item (blockwise scales; development key 49 = 1: tail items for every tail, the dispatch of round 5)
-  a.ext_rows = a.has_xs && hpc_dev_tuning_get(49) != 1;
+  a.ext_rows = hpc_dev_tuning_get(49) != 1;
   if (n % kBN || a.K < kBK) return HPC_ERR_UNSUPPORTED;
   const long max_tiles = m / kBM + num_group;  // upper bound of sum_g ceil(len_g / 256)
   const long items = max_tiles * (n / kBN) + 16;  // + 16: the per-XCD chunks of the full and of the tail tiles round up

@@ -81,7 +81,8 @@ def test_fuse_moe_pertensor_activation_epilogue(use_bf16_mul, num_seq, hidden, i
 @pytest.mark.dev
 @pytest.mark.gpu
 @pytest.mark.parametrize("use_bf16_mul", [False, True])
-@pytest.mark.parametrize("num_seq,hidden,inter,num_expert,topk", [(530, 512, 256, 4, 2), (300, 1088, 128, 2, 2)])  # 1088: K % 128 == 64
+@pytest.mark.parametrize("num_seq,hidden,inter,num_expert,topk", [(530, 512, 256, 4, 2), (300, 1088, 128, 2, 2),  # 1088: K % 128 == 64
+                                                                  (1050, 1024, 384, 4, 2), (2100, 512, 256, 8, 2)])
 def test_fuse_moe_pertensor_tail_body_is_bit_identical(use_bf16_mul, num_seq, hidden, inter, num_expert, topk):
     """Per-tensor fused op with experts that end in a short tail: the tail body of the 256 x 256 kernel (gate-up GEMM with
     silu(gate) * up * scale -> e4m3 in its epilogue, down GEMM; K % 128 == 64 through the k-tail instantiation) against
@@ -103,15 +104,20 @@ def test_fuse_moe_pertensor_tail_body_is_bit_identical(use_bf16_mul, num_seq, hi
     outs = {}
     dev_set(3, 4)
     try:
-        for key in (2, 0, "regs"):  # half-tile body / tail body (the product) / register-streamed tail body (development variant)
-            dev_set(21, 0 if key == "regs" else key)
+        # half-tile body / tail body (the product) / register-streamed tail body (development variant) / "r5": development key
+        # 49 = 1 - no ride-along rows (round 6: a short tail rides along with the group's full tiles in the per-tensor kernels too;
+        # the K % 128 == 64 instantiation has none)
+        for key in (2, 0, "regs", "r5"):
+            dev_set(21, 0 if key in ("regs", "r5") else key)
             dev_set(26, 1 if key == "regs" else 0)
+            dev_set(49, 1 if key == "r5" else 0)
             outs[key] = run()
     finally:
         dev_set(21, 0)
         dev_set(26, 0)
+        dev_set(49, 0)
         dev_set(3, 0)
-    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs["regs"])
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[0], outs["regs"]) and torch.equal(outs[0], outs["r5"])
     assert allclose(gt.float(), outs[0].float(), rtol=0.08, atol=0.1)
 
 

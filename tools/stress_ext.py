@@ -31,6 +31,20 @@ for (T, E, k, H, I) in [(257, 2, 2, 1024, 384), (530, 4, 2, 512, 256), (1050, 4,
         nb += 0 if torch.equal(run(), ref) else 1
     calls += REP; bad += nb
     print(f"fused T={T} E={E} k={k} H={H} I={I}: {rides} experts with ride-along rows, {nb} of {REP} calls differ from the round-5 dispatch", flush=True)
+# the per-tensor fused op (the kernels accumulate in the matrix pipe; the ride-along block too)
+for (T, E, k, H, I, bf) in [(530, 4, 2, 512, 256, False), (1050, 4, 2, 1024, 384, True), (2100, 8, 2, 512, 256, True), (4200, 16, 2, 2048, 768, False)]:
+    torch.manual_seed(T)
+    ids = torch.sort(torch.multinomial(torch.ones(T, E), k, replacement=False).to(torch.int32), dim=1)[0].cuda()
+    x = (torch.randn((T, H), device="cuda") / 100).to(F8)
+    guw = torch.randn((E, I * 2, H), device="cuda").to(F8)
+    dw = torch.randn((E, H, I), device="cuda").to(F8)
+    gus, ds, ams = torch.rand(E, device="cuda") + 0.5, torch.rand(E, device="cuda") + 0.5, torch.rand(1, device="cuda") + 0.5
+    sc = torch.rand((T, k), device="cuda") / k
+    run = lambda: hpc.fuse_moe_pertensor_fp8(x, guw, dw, gus, ds, ams, ids, sc, 0, E, use_bf16_mul=bf)
+    dev_set(49, 1); ref = run(); dev_set(49, 0)
+    nb = sum(0 if torch.equal(run(), ref) else 1 for _ in range(REP))
+    calls += REP; bad += nb
+    print(f"per-tensor fused T={T} E={E} H={H} I={I} bf16_mul={bf}: {nb} of {REP} calls differ from the round-5 dispatch", flush=True)
 # the standalone grouped GEMM, plain epilogue
 for (n, kk) in [(512, 512), (768, 1408), (256, 2048), (4096, 1024)]:
     torch.manual_seed(n + kk)
