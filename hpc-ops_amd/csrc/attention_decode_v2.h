@@ -37,6 +37,8 @@ struct Args {
   long k_block_stride, k_token_stride;  // bytes
   long v_block_stride, v_token_stride;
   long ks_block_stride, ks_row_stride, ks_head_stride;  // bytes
+  int hnd = 0;    // fp8: 1 = HND pages [page][head][token][128 B] (k / v_head_stride below; token strides are 128)
+  long k_head_stride = 0, v_head_stride = 0;  // bytes (read by the HND form only)
   float scale_log2;
   void* prof;  // development: per-wave timing sums [workgroups][4][12] uint64 (null = off)
 };
@@ -45,9 +47,10 @@ struct Args {
 // the first time a workspace is used (the kernel leaves it zero); its place and size do not depend on the call.
 constexpr int64_t kCounterBytes = 64 * 1024;
 int64_t workspace_bytes(int num_wg);  // partial slots (2 per workgroup x 2 heads), after the first-generation region
-// 0: not served here; 1: served (NHD pages with adjacent heads contiguous - 128 B apart for fp8, 256 B for bf16 -, an
-// even number of kv heads, <= 16 q rows per kv head, <= 1024 requests).
-int mode_of(const Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride);
+// 0: not served here; 1: served (NHD pages with adjacent heads contiguous - 128 B apart for fp8, 256 B for bf16 -, or, fp8
+// with per-tensor scales and development key 55 = 1, HND pages with a head's tokens contiguous (a.hnd is set then); an even number of kv heads,
+// <= 16 q rows per kv head, <= 1024 requests).
+int mode_of(Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride);
 int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStream_t stream);
 #ifdef HPC_DEV
 // development build: arrivals that drew a ticket ABOVE their request's chunk count since the last reset - the signature of

@@ -205,10 +205,16 @@ constexpr int kFMasked = 32;  // some token of the WI is invisible to some q row
 //        buffer_load_dword per wave-iteration (lane = head * 32 + token), issued between the K and the V loads, staged
 //        through 256 bytes of LDS per wave, read back as the four tokens of a lane's score rows.  Scores are scaled
 //        (s * qscale / sqrt(d) * log2 e) * kscale[token] - the first-generation kernel's order.
-template <int kAux, bool kBf16 = false, bool kProf = false, bool kQuad = false, bool kKtok = false>
+// kHnd:  fp8 head pairs on HND pages [page][head][token][128 B] (round 6, development key 55 = 1; the product keeps the first-generation kernel there).  A kv head's
+//        tokens are contiguous there, so a load instruction fetches 8 tokens x 128 B of ONE head (1 KB contiguous - the widest
+//        piece the probe knows, and no workgroup fixes byte-address bits 8-9) and a 16-row block is two instructions per head.
+//        Only the lane -> (row, chunk) map of the loads and of the stage writes differs: the LDS image, and with it everything
+//        downstream, is the NHD form's.
+template <int kAux, bool kBf16 = false, bool kProf = false, bool kQuad = false, bool kKtok = false, bool kHnd = false>
 __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   static_assert(!(kBf16 && kQuad), "the quad form is fp8");
   static_assert(!kKtok || (!kBf16 && !kQuad), "per-token K scales: the fp8 head-pair form");
+  static_assert(!kHnd || (!kBf16 && !kQuad && !kKtok), "HND pages: the fp8 head-pair form with per-tensor scales");
   __shared__ float s_ks[kKtok ? kWaves : 1][64];
   constexpr bool kWide = kBf16 || kQuad;     // 512-byte stage rows, 16-token wave-iterations
   __shared__ __attribute__((aligned(1024))) uint8_t s_wave[kWaves][kWaveLds];  // stage addresses are (base) ^ (bits 4-7)
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   constexpr int kH = kQuad ? 4 : 2;          // kv heads per workgroup
   constexpr int kW = kWide ? 16 : 32;        // tokens (= stage rows) per wave-iteration
   constexpr int kRowB = kWide ? 512 : 256;   // bytes of a stage row: the workgroup's heads of a token
-  constexpr int kRpi = kWide ? 2 : 4;        // rows per load instruction (64 lanes x 16 B = 1 KB)
+  constexpr int kRpi = kHnd ? 8 : kWide ? 2 : 4;  // rows per load instruction (64 lanes x 16 B = 1 KB; HND: 8 tokens of one head)
   constexpr int kCpr = 64 / kRpi;            // 16-byte chunks per row
 
   const int tid = threadIdx.x;
@@ -448,11 +454,15 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   const int lane_off = (lane % kCpr) * 16;
   const int k_voff0 = static_cast<int>((in0 + lane / kCpr) * k_rs) + lane_off, k_voff1 = static_cast<int>((in1 + lane / kCpr) * k_rs) + lane_off;
   const int v_voff0 = static_cast<int>((in0 + lane / kCpr) * v_rs) + lane_off, v_voff1 = static_cast<int>((in1 + lane / kCpr) * v_rs) + lane_off;
-  const int ks1 = sgpr(kRpi * k_rs), ks2 = sgpr(2 * kRpi * k_rs), ks3 = sgpr(3 * kRpi * k_rs);
-  const int vs1 = sgpr(kRpi * v_rs), vs2 = sgpr(2 * kRpi * v_rs), vs3 = sgpr(3 * kRpi * v_rs);
+  // the four instructions of a 16-row block: rows 0-3 | 4-7 | 8-11 | 12-15 of the pair's rows; HND: (tokens 0-7 | 8-15) of the
+  // first head, then of the second one (a head stride further)
+  const int ks1 = sgpr(kRpi * k_rs), ks2 = sgpr(kHnd ? static_cast<uint32_t>(a.k_head_stride) : 2 * kRpi * k_rs);
+  const int ks3 = sgpr(kHnd ? static_cast<uint32_t>(a.k_head_stride) + kRpi * k_rs : 3 * kRpi * k_rs);
+  const int vs1 = sgpr(kRpi * v_rs), vs2 = sgpr(kHnd ? static_cast<uint32_t>(a.v_head_stride) : 2 * kRpi * v_rs);
+  const int vs3 = sgpr(kHnd ? static_cast<uint32_t>(a.v_head_stride) + kRpi * v_rs : 3 * kRpi * v_rs);
   const int mem_slice = a.dev_slice > 0 ? a.dev_slice - 1 : pr;
-  const uint64_t kbase_h = reinterpret_cast<uint64_t>(a.kcache) + static_cast<uint64_t>(mem_slice) * kRowB;
-  const uint64_t vbase_h = reinterpret_cast<uint64_t>(a.vcache) + static_cast<uint64_t>(mem_slice) * kRowB;
+  const uint64_t kbase_h = reinterpret_cast<uint64_t>(a.kcache) + static_cast<uint64_t>(mem_slice) * (kHnd ? 2 * static_cast<uint64_t>(a.k_head_stride) : kRowB);
+  const uint64_t vbase_h = reinterpret_cast<uint64_t>(a.vcache) + static_cast<uint64_t>(mem_slice) * (kHnd ? 2 * static_cast<uint64_t>(a.v_head_stride) : kRowB);
   const uint32_t kbs = static_cast<uint32_t>(a.k_block_stride), vbs = static_cast<uint32_t>(a.v_block_stride);  // < 4 GB (eligible())
   const bool mem = a.dev_nomem == 0;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing)
   i32x4 dk0, dk1, dv0, dv1;  // descriptors of the WI being issued
@@ -516,8 +526,10 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   //      of its 8 x 16 tile = token 4 (g % 2) + j % 4 + 8 (j / 4) (the k-slot order permlane32_swap gives P), half i % 2 -
   //      the 32 lanes of a pass cover all 16 tokens of one chunk: 16 different slots x 2 halves
   const int qtok = 4 * (g & 1) + (tj & 3) + 8 * (tj >> 2);
-  const uint32_t w0_inv = kWide ? lds0 + (lane >> 5) * kRowB + (((lane & 31) ^ (lane >> 5)) * 16)
-                                : lds0 + (lane >> 4) * kRowB + (((lane & 15) ^ (lane >> 4)) * 16);
+  // HND writes: lane (r8 = lane / 8, c = lane % 8) of instruction (tb, q) holds chunk (q / 2) * 8 + c of row tb * 16 + (q % 2) * 8 + r8
+  const uint32_t w0_inv = kHnd ? lds0 + (lane >> 3) * kRowB + (((lane & 7) ^ (lane >> 3)) * 16)
+                          : kWide ? lds0 + (lane >> 5) * kRowB + (((lane & 31) ^ (lane >> 5)) * 16)
+                                  : lds0 + (lane >> 4) * kRowB + (((lane & 15) ^ (lane >> 4)) * 16);
   const uint32_t w1_inv = lds0 + kVOff + (lane >> 5) * kRowB + (((lane & 31) ^ ((lane >> 5) << 1)) * 16);  // bf16 V stage
   const uint32_t r0_inv = lds0 + n * kRowB + ((g ^ n) * 16);
   const uint32_t t0_inv = kBf16 ? lds0 + kVOff + btok * kRowB + (((((lane & 3) >> 1) ^ bkey)) * 16) + (lane & 1) * 8
@@ -850,7 +862,9 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     auto write_k = [&](int tb) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if constexpr (kWide)
+        if constexpr (kHnd)
+          *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ ((((q >> 1) << 3) ^ ((q & 1) << 3) ^ (tb << 3)) * 16)) + (tb * 16 + (q & 1) * 8) * kRowB)) = kr[tb][q];
+        else if constexpr (kWide)
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q << 1) ^ (tb << 3)) * 16)) + (tb * 8 + q * 2) * kRowB)) = kr[tb][q];
         else
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q << 2) ^ (tb << 3)) * 16)) + (tb * 16 + q * 4) * kRowB)) = kr[tb][q];
@@ -859,7 +873,9 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     auto write_v = [&](int tb) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if constexpr (kBf16)
+        if constexpr (kHnd)
+          *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ ((((q >> 1) << 3) ^ ((q & 1) << 3) ^ (tb << 3)) * 16)) + kVOff + (tb * 16 + (q & 1) * 8) * kRowB)) = vr[tb][q];
+        else if constexpr (kBf16)
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w1 ^ (((q << 2) ^ tb) * 16)) + (tb * 8 + q * 2) * kRowB)) = vr[tb][q];
         else if constexpr (kQuad)
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q << 1) ^ (tb << 3)) * 16)) + kVOff + (tb * 8 + q * 2) * kRowB)) = vr[tb][q];
@@ -1210,17 +1226,36 @@ int64_t workspace_bytes(int num_wg) {
   return part_o + part_lse;
 }
 
-int mode_of(const Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride) {
+int mode_of(Args& a, int num_head_q, int block_size, int64_t k_head_stride, int64_t v_head_stride) {
   if (a.num_head_kv <= 0 || num_head_q % a.num_head_kv) return 0;
   const int group = num_head_q / a.num_head_kv;
   const int head_bytes = a.bf16 ? 256 : 128;  // strides in BYTES: adjacent kv heads of a token must be contiguous (NHD pages)
+  // ... or (fp8, per-tensor scales) a head's tokens: HND pages - development key 55 = 1 only.  Measured (profiles/round6_decode_ab.txt,
+  // call 3): against the first-generation kernel the HND form wins on length mixes (C3 mix 137.3 vs 141.2 us, 32 x 128 + 32 x 4k
+  // 57.8 vs 60.6) and loses where the task map gives every workgroup one whole (request, head) and this kernel's plan cuts every
+  // request in two (uniform 8k: 181.7 us = 0.74 against 164-178 us = 0.75-0.82) - and 1 KB contiguous pieces stream no faster
+  // through this pipeline than the NHD form's 256-byte slices do (0.74 vs 0.76 on uniform 8k): the access pattern is not what
+  // bounds it.  HND pages stay on the first generation.
+  a.hnd = 0;
+  a.k_head_stride = k_head_stride;
+  a.v_head_stride = v_head_stride;
+  const bool hnd = !a.bf16 && !a.ktok && a.k_token_stride == 128 && a.v_token_stride == 128 && k_head_stride >= 128 * block_size &&
+                   v_head_stride >= 128 * block_size && (k_head_stride % 16) == 0 && (v_head_stride % 16) == 0 &&
+                   k_head_stride < (1ll << 28) && v_head_stride < (1ll << 28) && a.num_head_kv > 1 && hpc_dev_tuning_get(55) == 1;
+  if (hnd) {
+    a.hnd = 1;
+    k_head_stride = v_head_stride = head_bytes;  // the checks below are the NHD form's
+  }
   const bool ok = a.lens != nullptr && (a.num_head_kv % 2) == 0 && a.num_seq_q * group <= 16 && k_head_stride == head_bytes &&
                   v_head_stride == head_bytes && (block_size == 64 || block_size == 32 || block_size == 16) &&
                   (a.k_token_stride % 16) == 0 && (a.v_token_stride % 16) == 0 && (a.k_block_stride % 16) == 0 &&
                   (a.v_block_stride % 16) == 0 && a.k_block_stride > 0 && a.v_block_stride > 0 &&
                   a.k_block_stride < (1ll << 32) && a.v_block_stride < (1ll << 32) && a.num_batch <= 64 * 16 &&
                   static_cast<int64_t>(a.num_batch) * (a.num_head_kv / 2) * 4 <= kCounterBytes;
-  if (!ok) return 0;
+  if (!ok) {
+    a.hnd = 0;
+    return 0;
+  }
   // per-token K scales (quant_type 0): a wave-iteration's 32 tokens x 2 heads of scales must be one contiguous 256-byte piece
   // of a page's tail row - pages of 32 / 64 tokens, 32 floats per head and row, adjacent heads 128 bytes apart
   if (a.ktok && (a.bf16 || block_size < 32 || a.ks_head_stride != 128 || a.ks_block_stride <= 0 || a.ks_block_stride >= (1ll << 32) ||
@@ -1232,7 +1267,7 @@ int mode_of(const Args& a, int num_head_q, int block_size, int64_t k_head_stride
   // profiles/round3_decode_fp8_forms_ab.txt): the wider rows do not pay in the kernel although they do in a pure streaming
   // probe - the waves sit in the load issue either way (tools/prof_decode.py: 52-57 % of a wave's cycles).  So head
   // pairs stay the default and development key 29 = 2 selects the four-head form (kept: tested, half the softmax work).
-  const bool quad = !a.bf16 && (a.num_head_kv % 4) == 0 && a.num_seq_q * group <= 8 && hpc_dev_tuning_get(29) == 2;
+  const bool quad = !a.bf16 && !a.hnd && (a.num_head_kv % 4) == 0 && a.num_seq_q * group <= 8 && hpc_dev_tuning_get(29) == 2;
   return quad ? 2 : 1;
 }
 
@@ -1269,7 +1304,9 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
     const int k36 = hpc_dev_tuning_get(36);
     int mask = (a.bf16 || mode == 2 || npair == 2) ? 1 : 2;
     if (k36 > 0) mask = k36 - 1;
-    const bool ok = cus > 0 && num_wg > cus && (npair & (npair - 1)) == 0 && mask > 0 && mask < npair && cus % npair == 0;
+    // (HND pages: a workgroup walks whole 1 KB pieces of a head - no slice fixes address bits 8-9, the rule has nothing to separate)
+    const bool ok = cus > 0 && num_wg > cus && (npair & (npair - 1)) == 0 && mask > 0 && mask < npair && cus % npair == 0 &&
+                    (!a.hnd || k36 > 0);
     a.pair_xor = ok ? mask : 0;
     a.mate_from = ok ? cus : 0;
   }
@@ -1303,6 +1340,11 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
   }
   if (a.ktok) {
     decode2_kernel<2, false, false, false, true><<<num_wg, kThreads, 0, stream>>>(a);
+  } else if (a.hnd) {
+    if (kHpcDevBuild && a.prof)
+      decode2_kernel<2, false, true, false, false, true><<<num_wg, kThreads, 0, stream>>>(a);
+    else
+      decode2_kernel<2, false, false, false, false, true><<<num_wg, kThreads, 0, stream>>>(a);
   } else if (a.bf16) {
     if (temporal)
       decode2_kernel<0, true><<<num_wg, kThreads, 0, stream>>>(a);

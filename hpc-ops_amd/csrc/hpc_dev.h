@@ -52,6 +52,7 @@
 //   key 49 grouped GEMM 256 x 256 kernel: 1 = no ride-along rows (every tail of a group runs as its own tail / half-tile item: rounds 2-5)
 //   key 52 low-latency all-reduce, loopback harness: 1 = the one-shot form; key 53: 1 = the all-reduce alone (no residual / norm)
 //   key 54 fp8 decode, quant_type 0 (per-token K scales): 1 = the first-generation kernel (rounds 1-5) instead of the head-pair kernel
+//   key 55 fp8 decode on HND pages (per-tensor scales): 1 = the head-pair kernel's HND form (1 KB pieces of one head per load) instead of the first-generation kernel
 //   others: see the launchers that read them
 #pragma once
 

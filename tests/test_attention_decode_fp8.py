@@ -141,6 +141,22 @@ def test_attn_fp8_bins_of_short_requests(k_per_token, num_seq_q, solo):
         dev_set(5, 0)
 
 
+@pytest.mark.dev
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_seq_q,heads,block_size", [(1, (8, 64), 64), (2, (4, 32), 32), (4, (2, 8), 16), (1, (4, 16), 64)])
+def test_attn_fp8_head_pair_kernel_hnd_form(num_seq_q, heads, block_size):
+    """Development key 55 = 1: HND pages on the head-pair kernel (a load instruction = 8 tokens x 128 B of one head, the stage
+    image and everything behind it the NHD form's) - measured a wash against the first-generation kernel, so the product keeps
+    that one (profiles/round6_decode_ab.txt, call 4).  Split requests, short ones, empty ones, pages of 16 / 32 / 64 tokens."""
+    lens = torch.tensor([20000, 3, 9000, 130, 64, 63, 65, 4097, 700, 1, 127, 129, 31000, 2, 0, 255, 256, 257], dtype=torch.int32)
+    dev_set(55, 1)
+    try:
+        for _ in range(2):  # twice: the arrival counters are left zero
+            _run(len(lens), num_seq_q, lens, block_size, heads, False, True, True, "HND", 0.2)
+    finally:
+        dev_set(55, 0)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["last_arriver", "poisoned_partials"])
 def test_attn_fp8_split_request_merge_variants(mode):

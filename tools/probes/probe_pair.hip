@@ -122,6 +122,109 @@ __global__ __launch_bounds__(256, 1) void k2(const char* __restrict__ kp, const 
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+// Whole-row form (round 6 question): 512 workgroups x 4 waves, two per CU.  A workgroup walks a token range of ALL 8 heads in stages of
+// 32 tokens: wave w fetches rows 8 w .. 8 w + 7 of K and of V as whole 1 KB rows (one instruction per row), the next stage's loads
+// are issued right after the landed registers went to the SHARED LDS stage [pair][row][256 B] (K 32 KB + V 32 KB), then barrier,
+// every wave reads ITS pair's 256-byte slices of all 32 rows (what it would feed the MFMAs), spins, barrier.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k3(const char* __restrict__ kp, const char* __restrict__ vp,
+                                             const int* __restrict__ pages, int pages_per_req, int nreq, unsigned* out,
+                                             int spin, int nsplit) {
+  __shared__ __attribute__((aligned(1024))) unsigned char s_stage[2][4][32][256];  // [K | V][pair][row][256 B]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x % nreq, split = blockIdx.x / nreq;
+  const int tok_per = pages_per_req * 64 / nsplit;
+  const int tok0 = split * tok_per, tok1 = tok0 + tok_per;
+  const int* pg = pages + (long)b * pages_per_req;
+  unsigned acc = 0;
+  u32x4 rk[8], rv[8];
+  auto load = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int tok = t + wave * 8 + i;
+      const long off = (long)pg[tok >> 6] * 65536 + (long)(tok & 63) * 1024 + lane * 16;
+      rk[i] = NT ? __builtin_nontemporal_load((const u32x4*)(kp + off)) : *(const u32x4*)(kp + off);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int tok = t + wave * 8 + i;
+      const long off = (long)pg[tok >> 6] * 65536 + (long)(tok & 63) * 1024 + lane * 16;
+      rv[i] = NT ? __builtin_nontemporal_load((const u32x4*)(vp + off)) : *(const u32x4*)(vp + off);
+    }
+  };
+  const int wp = lane >> 4, wc = lane & 15;  // a lane's chunk of a row: pair, 16-byte chunk of the pair's slice
+  load(tok0);
+  for (int t = tok0; t < tok1; t += 32) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = wave * 8 + i;
+      *(u32x4*)&s_stage[0][wp][row][((wc ^ (row & 15)) << 4)] = rk[i];
+      *(u32x4*)&s_stage[1][wp][row][((wc ^ (row & 15)) << 4)] = rv[i];
+    }
+    if (t + 32 < tok1) load(t + 32);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {  // 32 rows x 256 B of K and of V of this wave's pair
+      const int row = i * 4 + (lane >> 4);
+      const u32x4 a = *(const u32x4*)&s_stage[0][wave][row][((wc ^ (row & 15)) << 4)];
+      const u32x4 c = *(const u32x4*)&s_stage[1][wave][row][((wc ^ (row & 15)) << 4)];
+      acc += a[0] ^ a[3] ^ c[0] ^ c[3];
+    }
+    for (int i = 0; i < spin; ++i) acc = acc * 1664525u + 1013904223u;
+    __syncthreads();
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+// the same walk with the pair form's access pattern (a workgroup = one pair, private per-wave stages, no barriers): the control
+template <int NT>
+__global__ __launch_bounds__(256, 2) void k4(const char* __restrict__ kp, const char* __restrict__ vp,
+                                             const int* __restrict__ pages, int pages_per_req, int nreq, unsigned* out,
+                                             int spin, int nsplit) {
+  __shared__ __attribute__((aligned(1024))) unsigned char s_stage[4][2][32][256];  // [wave][K | V][row][256 B]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hg = blockIdx.x % 4, rest = blockIdx.x / 4;
+  const int b = rest % nreq, split = rest / nreq;
+  const int tok_per = pages_per_req * 64 / nsplit;
+  const int tok0 = split * tok_per, tok1 = tok0 + tok_per;
+  const int* pg = pages + (long)b * pages_per_req;
+  unsigned acc = 0;
+  u32x4 rk[8], rv[8];
+  const int lr = lane >> 4, wc = lane & 15;
+  auto load = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int tok = t + i * 4 + lr;
+      const long off = (long)pg[tok >> 6] * 65536 + (long)(tok & 63) * 1024 + hg * 256 + wc * 16;
+      rk[i] = NT ? __builtin_nontemporal_load((const u32x4*)(kp + off)) : *(const u32x4*)(kp + off);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int tok = t + i * 4 + lr;
+      const long off = (long)pg[tok >> 6] * 65536 + (long)(tok & 63) * 1024 + hg * 256 + wc * 16;
+      rv[i] = NT ? __builtin_nontemporal_load((const u32x4*)(vp + off)) : *(const u32x4*)(vp + off);
+    }
+  };
+  if (tok0 + wave * 32 < tok1) load(tok0 + wave * 32);
+  for (int t = tok0 + wave * 32; t < tok1; t += 128) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = i * 4 + lr;
+      *(u32x4*)&s_stage[wave][0][row][((wc ^ (row & 15)) << 4)] = rk[i];
+      *(u32x4*)&s_stage[wave][1][row][((wc ^ (row & 15)) << 4)] = rv[i];
+    }
+    if (t + 128 < tok1) load(t + 128);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = i * 4 + lr;
+      const u32x4 a = *(const u32x4*)&s_stage[wave][0][row][((wc ^ (row & 15)) << 4)];
+      const u32x4 c = *(const u32x4*)&s_stage[wave][1][row][((wc ^ (row & 15)) << 4)];
+      acc += a[0] ^ a[3] ^ c[0] ^ c[3];
+    }
+    for (int i = 0; i < spin; ++i) acc = acc * 1664525u + 1013904223u;
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
 int main() {
   const int nreq = 64, ppr = 128;  // 8192 tokens per request
   const int npages = nreq * ppr + 100;
@@ -163,5 +266,12 @@ int main() {
   run("k2 + 200 dependent ops per stage", [&] { k2<1><<<256, 256>>>(kp, vp, pages, ppr, nreq, out, 200); });
   run("k2 + 400 dependent ops per stage", [&] { k2<1><<<256, 256>>>(kp, vp, pages, ppr, nreq, out, 400); });
   run("k2 + 800 dependent ops per stage", [&] { k2<1><<<256, 256>>>(kp, vp, pages, ppr, nreq, out, 800); });
+  for (int spin : {0, 200, 400, 800}) {
+    char nm[96];
+    snprintf(nm, sizeof nm, "k4: pair slices, private stages, spin %d", spin);
+    run(nm, [&] { k4<1><<<512, 256>>>(kp, vp, pages, ppr, nreq, out, spin, 2); });
+    snprintf(nm, sizeof nm, "k3: whole rows, shared stage + 2 barriers, spin %d", spin);
+    run(nm, [&] { k3<1><<<512, 256>>>(kp, vp, pages, ppr, nreq, out, spin, 8); });
+  }
   return 0;
 }
