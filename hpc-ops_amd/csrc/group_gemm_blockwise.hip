@@ -81,38 +81,15 @@ __global__ __launch_bounds__(64 * kWaves, (kWaves == 8 || kMT * kR >= 8) ? 1 : 2
 
   const int npass = (m_cnt + kTok - 1) / kTok;
   for (int p = 0; p < npass; ++p) {
-    // ---- this lane's roles in staging the activation tile ------------------------------------------
-    // x rows: instruction i = wave*kXI + j loads tile rows 4i .. 4i+3, lane -> (row 4i + g4, chunk r16)
-    unsigned x_voff[kXI];
-    int x_lds[kXI];
-#pragma unroll
-    for (int j = 0; j < kXI; ++j) {
-      const int trow = 4 * (wave * kXI + j) + g4;
-      const int slot = p * kTok + trow;
-      const int sc = slot < m_cnt ? slot : m_cnt - 1;
-      const int xrow = a.row_index ? a.row_index[m0 + sc] : m0 + sc;
-      x_voff[j] = static_cast<unsigned>(xrow) * static_cast<unsigned>(K) + r16 * 16;
-      x_lds[j] = trow * kXRow + r16 * 16;
-    }
-    // scales: waves 0/1 load k-block 0/1 of the stage, lane -> token `lane`
-    unsigned xs_voff = 0;
-    const bool xs_role = wave < 2 && lane < kTok;
-    if (xs_role) {
-      const int slot = p * kTok + lane;
-      const int sc = slot < m_cnt ? slot : m_cnt - 1;
-      const long term = a.col_base ? col0 + sc : static_cast<long>(a.row_index ? a.row_index[m0 + sc] : m0 + sc);
-      xs_voff = static_cast<unsigned>(term * a.xs_row_stride * 4);
-    }
-
+    // The weight loads of the first kDepth stages go out BEFORE the lane's activation roles are known (round 6): those hang on a
+    // chain of dependent loads (row_index -> activation row -> its address) that the weights do not need, and a workgroup only
+    // lives for ~16 stages - two memory round trips in front of its first weight byte were ~10 % of its life.
     u32x4 wb[kDepth][2][kR][2];  // [stage][k-block of the stage][row block][64-byte half]
-    u32x4 xb[kDepth][kXI];
-    float xsb[kDepth];
-    auto issue = [&](int d, int st) {
-      const int kb0 = 2 * st;
-      const int koff = kb0 * 128;
+    auto issue_w = [&](int d, int st) {
       // Weights: whole stage on/off (a descriptor with num_records = 0 fetches nothing).  When K is
       // not a multiple of 256 the tail of the last stage reads into the next weight row - finite
       // e4m3 data that meets ZERO activations: the activation loads below are bounded per lane.
+      const int koff = 2 * st * 128;
       const unsigned w_on = st < nstage ? w_bytes : 0u;
 #pragma unroll
       for (int rb = 0; rb < kR; ++rb) {
@@ -120,6 +97,48 @@ __global__ __launch_bounds__(64 * kWaves, (kWaves == 8 || kMT * kR >= 8) ? 1 : 2
 #pragma unroll
         for (int qd = 0; qd < 4; ++qd) wb[d][qd >> 1][rb][qd & 1] = buf_ld16<2>(rw, w_voff, koff + qd * 4 * K);
       }
+    };
+    // ---- this lane's roles in staging the activation tile ------------------------------------------
+    // x rows: instruction i = wave*kXI + j loads tile rows 4i .. 4i+3, lane -> (row 4i + g4, chunk r16)
+    // (the row_index lookups are requested first and consumed AFTER the weight loads have been issued: they retire first - in
+    // order - so waiting for them leaves the kDepth stages of weights in flight)
+    const bool xs_role = wave < 2 && lane < kTok;
+    int xrow_j[kXI], xrow_s = 0, sc_s = 0;
+#pragma unroll
+    for (int j = 0; j < kXI; ++j) {
+      const int slot = p * kTok + 4 * (wave * kXI + j) + g4;
+      const int sc = slot < m_cnt ? slot : m_cnt - 1;
+      xrow_j[j] = a.row_index ? a.row_index[m0 + sc] : m0 + sc;
+    }
+    if (xs_role) {
+      const int slot = p * kTok + lane;
+      sc_s = slot < m_cnt ? slot : m_cnt - 1;
+      xrow_s = a.row_index ? a.row_index[m0 + sc_s] : m0 + sc_s;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) issue_w(d, d);
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned x_voff[kXI];
+    int x_lds[kXI];
+#pragma unroll
+    for (int j = 0; j < kXI; ++j) {
+      const int trow = 4 * (wave * kXI + j) + g4;
+      x_voff[j] = static_cast<unsigned>(xrow_j[j]) * static_cast<unsigned>(K) + r16 * 16;
+      x_lds[j] = trow * kXRow + r16 * 16;
+    }
+    // scales: waves 0/1 load k-block 0/1 of the stage, lane -> token `lane`
+    unsigned xs_voff = 0;
+    if (xs_role) {
+      const long term = a.col_base ? col0 + sc_s : static_cast<long>(xrow_s);
+      xs_voff = static_cast<unsigned>(term * a.xs_row_stride * 4);
+    }
+
+    u32x4 xb[kDepth][kXI];
+    float xsb[kDepth];
+    auto issue_x = [&](int d, int st) {
+      const int kb0 = 2 * st;
+      const int koff = kb0 * 128;
       // activation quarter: one 16-byte chunk of the 256-byte slab per lane; chunks at k >= K get an
       // out-of-range offset and read as zero
       const auto rx = make_rsrc(a.x, a.x_bytes);
@@ -134,7 +153,7 @@ __global__ __launch_bounds__(64 * kWaves, (kWaves == 8 || kMT * kR >= 8) ? 1 : 2
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int d = 0; d < kDepth; ++d) {
-      issue(d, d);
+      issue_x(d, d);
       __builtin_amdgcn_sched_barrier(0);  // keep issue order = consumption order (in-order vmcnt)
     }
 
@@ -216,7 +235,8 @@ __global__ __launch_bounds__(64 * kWaves, (kWaves == 8 || kMT * kR >= 8) ? 1 : 2
             __builtin_amdgcn_sched_barrier(0);  // stop hipcc hoisting every LDS read of the stage (VGPRs)
           }
         }
-        issue(d, st + kDepth);
+        issue_w(d, st + kDepth);
+        issue_x(d, st + kDepth);
       }
     }
 
@@ -231,6 +251,205 @@ __global__ __launch_bounds__(64 * kWaves, (kWaves == 8 || kMT * kR >= 8) ? 1 : 2
           pk[1] = pack_bf16x2(tot[rb][mt][2], tot[rb][mt][3]);
           *reinterpret_cast<u32x2*>(a.y + static_cast<long>(m0 + slot) * a.N + n0 + rb * 16 + g4 * 4) = pk;
         }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // retire stores before the next pass (see attention_decode.hip)
+    __syncthreads();
+  }
+}
+
+
+// Round 6: the stream's stage loop re-ordered for the latency of ONE stage (<= 32 tokens per pass, 4 waves x 16 rows).
+// In the kernel above a wave's stage is a serial chain - wait for the stage's loads, stage writes, operand reads, barrier, then per
+// k-block a scalar load of the weight scale that is waited for on the spot, an LDS read of the token scale, four dependent MFMAs -
+// and the refill of the stage's registers is issued at its very END: ~1 200 of the ~2 000 cycles a stage may take at the HBM rate
+// pass before the memory pipeline hears from the wave again, so fewer than the kDepth stages are really in flight (0.76-0.78 of
+// 8 TB/s at T = 16 ... 64 against 0.87 for a pure stream of the same weights with the same 16 KB per wave in flight,
+// tools/probes/probe_wstream.hip).  Here
+//  * the refill goes out as soon as the stage's registers have been written to LDS (they are dead then), in front of the barrier
+//    and the MFMAs;
+//  * the weight scales of the stage are requested at its top, branch-free (clamped index, zeroed afterwards), and the token
+//    scales ride in the same LDS read batch as the B operands;
+//  * the token-scale load uses a wave-uniform descriptor (the lane-dependent one above cost a waterfall loop per stage);
+//  * the weight loads of the first kDepth stages are issued before the lane's activation roles are known (see above).
+// Same arithmetic in the same order: bit-identical to the kernel above.  Development key 56 = 1 keeps that one.
+template <int kMT, int kDepth>
+__global__ __launch_bounds__(256, 2) void gemm_blockwise_stream2_kernel(const Args a) {
+  constexpr int kWaves = 4;
+  constexpr int kTok = 16 * kMT;
+  constexpr int kXI = 4 * kMT / kWaves;  // activation staging instructions (4 rows x 256 B each) per wave
+  static_assert(kXI >= 1, "need at least one staging instruction per wave");
+  __shared__ __attribute__((aligned(16))) uint8_t s_x[2][kTok * kXRow];
+  __shared__ float s_xs[2][2][kTok];
+  __shared__ __attribute__((aligned(16))) uint8_t s_w[kWaves][2][16 * kXRow];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, g4 = lane >> 4;
+  const int e = blockIdx.y;
+  const int m_cnt = as_const(a.seqlens)[e];
+  if (m_cnt <= 0) return;
+  const int n0 = (blockIdx.x * kWaves + wave) * 16;
+  const int m0 = as_const(a.cu_seqlens)[e];
+  const int K = a.K, KB = a.KB;
+  const int nstage = (KB + 1) >> 1;
+
+  const uint8_t* wbase = a.w + (static_cast<long>(e) * a.N + n0) * K;
+  const unsigned w_bytes = 16u * static_cast<unsigned>(K);
+  const int w_voff = g4 * K + r16 * 16;
+  const cint_ptr ws_row = as_const(reinterpret_cast<const int*>(a.ws)) +
+                          static_cast<long>(e) * a.ws_group_stride + (n0 >> 7) * a.ws_ntile_stride;
+  const int xs_kb_bytes = static_cast<int>(a.xs_kb_stride * 4);
+  const long col0 = a.col_base ? static_cast<long>(as_const(a.col_base)[e]) * a.tile_m : 0;
+  const bool has_xs = a.has_xs != 0;
+
+  const int npass = (m_cnt + kTok - 1) / kTok;
+  for (int p = 0; p < npass; ++p) {
+    const bool xs_role = wave < 2 && lane < kTok;
+    int xrow_j[kXI], xrow_s = 0, sc_s = 0;
+#pragma unroll
+    for (int j = 0; j < kXI; ++j) {
+      const int slot = p * kTok + 4 * (wave * kXI + j) + g4;
+      const int sc = slot < m_cnt ? slot : m_cnt - 1;
+      xrow_j[j] = a.row_index ? a.row_index[m0 + sc] : m0 + sc;
+    }
+    {
+      const int slot = p * kTok + (lane < kTok ? lane : 0);
+      sc_s = slot < m_cnt ? slot : m_cnt - 1;
+      xrow_s = a.row_index ? a.row_index[m0 + sc_s] : m0 + sc_s;
+    }
+    u32x4 wb[kDepth][4];
+    auto issue_w = [&](int d, int st) {
+      const int koff = 2 * st * 128;
+      const auto rw = make_rsrc(wbase, st < nstage ? w_bytes : 0u);
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) wb[d][qd] = buf_ld16<2>(rw, w_voff, koff + qd * 4 * K);
+    };
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) issue_w(d, d);
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned x_voff[kXI];
+    int x_lds[kXI];
+#pragma unroll
+    for (int j = 0; j < kXI; ++j) {
+      x_voff[j] = static_cast<unsigned>(xrow_j[j]) * static_cast<unsigned>(K) + r16 * 16;
+      x_lds[j] = (4 * (wave * kXI + j) + g4) * kXRow + r16 * 16;
+    }
+    // scales: waves 0 / 1 load k-block 0 / 1 of the stage, lane -> token `lane` (lanes past the tile: token 0, never stored)
+    const long term = a.col_base ? col0 + sc_s : static_cast<long>(xrow_s);
+    const unsigned xs_voff = static_cast<unsigned>(term * a.xs_row_stride * 4);
+    const int xs_wave = wave < 2 ? wave : 0;
+
+    u32x4 xb[kDepth][kXI];
+    float xsb[kDepth];
+    auto issue_x = [&](int d, int st) {
+      const int kb0 = 2 * st;
+      const int koff = kb0 * 128;
+      const auto rx = make_rsrc(a.x, a.x_bytes);
+      const bool x_ok = koff + r16 * 16 < K;
+#pragma unroll
+      for (int j = 0; j < kXI; ++j) xb[d][j] = buf_ld16<0>(rx, x_ok ? x_voff[j] : 0xffffff00u, koff);
+      // wave-uniform, and pinned so that hipcc sees it (a descriptor it cannot prove uniform costs a waterfall loop per load)
+      const auto rs = make_rsrc(a.xs, __builtin_amdgcn_readfirstlane((has_xs && wave < 2 && kb0 + xs_wave < KB) ? 0xffffffffu : 0u));
+      xsb[d] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, xs_voff, (kb0 + xs_wave) * xs_kb_bytes, 0));
+    };
+#pragma unroll
+    for (int d = 0; d < kDepth; ++d) {
+      issue_x(d, d);
+      __builtin_amdgcn_sched_barrier(0);  // keep issue order = consumption order (in-order vmcnt)
+    }
+
+    f32x4 tot[kMT];
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) tot[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int st0 = 0; st0 < nstage; st0 += kDepth) {
+#pragma unroll
+      for (int d = 0; d < kDepth; ++d) {
+        const int st = st0 + d;
+        const int buf = (kDepth & 1) ? (st & 1) : (d & 1);
+        // this stage's two weight scales: requested now, used after the barrier (clamped index, zeroed past the end: no branch)
+        const int kb_a = 2 * st, kb_b = 2 * st + 1;
+        const int wsi_a = ws_row[(kb_a < KB ? kb_a : KB - 1) * a.ws_kb_stride];
+        const int wsi_b = ws_row[(kb_b < KB ? kb_b : KB - 1) * a.ws_kb_stride];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < kXI; ++j) *reinterpret_cast<u32x4*>(&s_x[buf][x_lds[j]]) = xb[d][j];
+        if (xs_role) s_xs[buf][wave][lane] = xsb[d];
+        uint8_t* wt = s_w[wave][buf];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) *reinterpret_cast<u32x4*>(wt + (4 * qd + g4) * kXRow + r16 * 16) = wb[d][qd];
+        __builtin_amdgcn_sched_barrier(0);
+        // the stage's registers are in LDS: refill them now - the loads travel while this stage is computed
+        issue_w(d, st + kDepth);
+        issue_x(d, st + kDepth);
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 wf[2][2];
+#pragma unroll
+        for (int kbl = 0; kbl < 2; ++kbl)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            wf[kbl][h] = *reinterpret_cast<const u32x4*>(wt + r16 * kXRow + (kbl * 8 + h * 4 + g4) * 16);
+        __syncthreads();
+        u32x4 b0[2][kMT], b1[2][kMT];
+        float f[2][kMT];
+        const float wsk[2] = {kb_a < KB ? __int_as_float(wsi_a) : 0.f, kb_b < KB ? __int_as_float(wsi_b) : 0.f};
+        auto read_b = [&](int kbl) {
+#pragma unroll
+          for (int q = 0; q < kMT; ++q) {
+            const uint8_t* xp = &s_x[buf][(q * 16 + r16) * kXRow + kbl * 128 + g4 * 16];
+            b0[kbl][q] = *reinterpret_cast<const u32x4*>(xp);
+            b1[kbl][q] = *reinterpret_cast<const u32x4*>(xp + 64);
+            f[kbl][q] = has_xs ? s_xs[buf][kbl][q * 16 + r16] * wsk[kbl] : wsk[kbl];
+          }
+        };
+        if constexpr (kMT == 1) {  // one batch of LDS reads for the whole stage (two token blocks: per k-block - registers)
+          read_b(0);
+          read_b(1);
+        }
+#pragma unroll
+        for (int kbl = 0; kbl < 2; ++kbl) {
+          if constexpr (kMT != 1) {
+            read_b(kbl);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          f32x4 part[kMT];
+#pragma unroll
+          for (int q = 0; q < kMT; ++q) part[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int q = 0; q < kMT; ++q)
+            part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(wf[kbl][0][0], wf[kbl][0][1]),
+                                                                 pack64(b0[kbl][q][0], b0[kbl][q][1]), part[q], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < kMT; ++q)
+            part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(wf[kbl][0][2], wf[kbl][0][3]),
+                                                                 pack64(b0[kbl][q][2], b0[kbl][q][3]), part[q], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < kMT; ++q)
+            part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(wf[kbl][1][0], wf[kbl][1][1]),
+                                                                 pack64(b1[kbl][q][0], b1[kbl][q][1]), part[q], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < kMT; ++q)
+            part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(wf[kbl][1][2], wf[kbl][1][3]),
+                                                                 pack64(b1[kbl][q][2], b1[kbl][q][3]), part[q], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < kMT; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tot[q][i] = fmaf(part[q][i], f[kbl][q], tot[q][i]);
+        }
+      }
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < kMT; ++mt) {
+      const int slot = p * kTok + mt * 16 + r16;
+      if (slot < m_cnt) {
+        u32x2 pk;
+        pk[0] = pack_bf16x2(tot[mt][0], tot[mt][1]);
+        pk[1] = pack_bf16x2(tot[mt][2], tot[mt][3]);
+        *reinterpret_cast<u32x2*>(a.y + static_cast<long>(m0 + slot) * a.N + n0 + g4 * 4) = pk;
       }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // retire stores before the next pass (see attention_decode.hip)
@@ -295,7 +514,12 @@ int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const v
     gemm_blockwise_stream_kernel<2, 1, 8><<<grid, 512, 0, stream>>>(a);
   } else {
     dim3 grid(n / 64, num_group);
-    if (mt == 1)
+    const bool v2 = hpc_dev_tuning_get(56) != 1;  // development key 56 = 1: the stage loop of rounds 1-5
+    if (mt == 1 && v2)
+      gemm_blockwise_stream2_kernel<1, 4><<<grid, kThreads, 0, stream>>>(a);
+    else if (mt == 2 && v2)
+      gemm_blockwise_stream2_kernel<2, 4><<<grid, kThreads, 0, stream>>>(a);
+    else if (mt == 1)
       gemm_blockwise_stream_kernel<1, 1><<<grid, kThreads, 0, stream>>>(a);
     else if (mt == 3)
       gemm_blockwise_stream_kernel<3, 1, 4, 3><<<grid, kThreads, 0, stream>>>(a);

@@ -53,6 +53,8 @@
 //   key 52 low-latency all-reduce, loopback harness: 1 = the one-shot form; key 53: 1 = the all-reduce alone (no residual / norm)
 //   key 54 fp8 decode, quant_type 0 (per-token K scales): 1 = the first-generation kernel (rounds 1-5) instead of the head-pair kernel
 //   key 55 fp8 decode on HND pages (per-tensor scales): 1 = the head-pair kernel's HND form (1 KB pieces of one head per load) instead of the first-generation kernel
+//   key 56 streaming grouped GEMM (16 / 32 tokens per pass): 1 = the stage loop of rounds 1-5 (refill at the end of a stage, scalar scale loads
+//          waited for on the spot) instead of the re-ordered one (gemm_blockwise_stream2_kernel)
 //   others: see the launchers that read them
 #pragma once
 
