@@ -285,6 +285,34 @@ def test_group_gemm_blockwise(num_group, actual_m, n, k, forced_mt):
     assert allclose(gt.float(), my.cpu().float(), rtol=0.01, atol=0.02)
 
 
+@pytest.mark.dev
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_tokens,hidden,inter,num_expert,topk", [(16, 512, 256, 8, 2), (64, 1024, 384, 16, 4), (100, 512, 128, 8, 2),
+                                                                     (40, 4096, 1408, 8, 4)])
+def test_fuse_moe_blockwise_streaming_kernel_reordered_stage_is_bit_identical(num_tokens, hidden, inter, num_expert, topk):
+    """Decode-size batches (below 16 rows per expert) run the streaming grouped GEMM; round 6 re-ordered its stage loop
+    (gemm_blockwise_stream2_kernel: refill as soon as the stage's registers are in LDS, early branch-free scale loads, a
+    wave-uniform scale descriptor, weight loads in front of the row-index chain).  Same arithmetic in the same order:
+    development key 56 = 1 (the stage loop of rounds 1-5) must give the same bits, and both meet the oracle's bar."""
+    import hpc
+    from oracle import fuse_moe as omoe
+
+    args = _inputs(num_tokens, topk, hidden, inter, num_expert, 1, False, seed=num_tokens)
+    x, x_scale, guw, guws, dw, dws, topk_ids, topk_scale, _ = args
+    assert num_tokens * topk // num_expert < 16  # the streaming kernel's range
+    gt = omoe.fuse_moe_blockwise_fp8(x, x_scale, guw, guws, dw, dws, topk_ids, topk_scale, 0, num_expert, None)
+    dev = [t.cuda() for t in args[:8]]
+    outs = {}
+    try:
+        for key in (1, 0):
+            dev_set(56, key)
+            outs[key] = hpc.fuse_moe_blockwise_fp8(*dev, 0, num_expert).cpu()
+    finally:
+        dev_set(56, 0)
+    assert torch.equal(outs[0], outs[1])
+    assert allclose(gt.float(), outs[0].float(), rtol=0.01, atol=0.01)
+
+
 @pytest.mark.gpu
 def test_reduce():
     import hpc
