@@ -669,7 +669,11 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
         u32x4 x0[2][2][2], x1[2][2][2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+          // (round 6: a second chunk that does not exist is neither loaded nor folded - rounds 3-5 loaded the first one again
+          // and gave it weight zero; most split requests have two or three chunks, and a duplicate of a written-through partial
+          // is one more trip past L2 at the very end of the launch.  Development key 58 = 1: the duplicate loads.)
           const int c = c0 + u * kWaves < nchunks ? c0 + u * kWaves : c0;
+          if (u > 0 && c0 + u * kWaves >= nchunks && !(kHpcDevBuild && a.dev_merge_dup)) continue;  // wave-uniform
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh) {
             const long slot = slot_of(c, hh);
@@ -686,6 +690,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
           const bool real = c0 + u * kWaves < nchunks;
+          if (!real && !(kHpcDevBuild && a.dev_merge_dup)) continue;  // wave-uniform
 #pragma unroll
           for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
@@ -1291,6 +1296,7 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
   a.dev_slice = hpc_dev_tuning_get(37);
   a.xcd_map = hpc_dev_tuning_get(38);
   a.dev_sleep = hpc_dev_tuning_get(39);
+  a.dev_merge_dup = hpc_dev_tuning_get(58) == 1;
   // the second workgroup of every CU on the slice across address bit 9 (see the kernel): slices of 256 B (fp8 pairs) -> pair
   // index bit 1, of 512 B (bf16 pairs, fp8 quads) -> bit 0.  Measured per shape (profiles/round5_decode_pair_map_ab.txt):
   // fp8 8 / 64 heads +4-6 %, 16 / 128 heads +4 % (bit 8: +2 %, bit 10: 0), bf16 8 / 64 +1-2.5 % (bit 10: 0); with two pairs
