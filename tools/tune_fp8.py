@@ -31,7 +31,9 @@ cases = (("uniform8k", torch.full((B,), 8192, dtype=torch.int32)), ("mixed", mix
          ("uniform512", torch.full((B,), 512, dtype=torch.int32)),
          ("extreme", torch.tensor([64] * 15 + [16384] + [0] * 48, dtype=torch.int32)),
          ("one64k", torch.tensor([65536] + [4096] * 31 + [0] * 32, dtype=torch.int32)),
-         ("two32k", torch.tensor([32768] * 2 + [4096] * 30 + [0] * 32, dtype=torch.int32)))
+         ("two32k", torch.tensor([32768] * 2 + [4096] * 30 + [0] * 32, dtype=torch.int32)),
+         ("one64k_7", torch.tensor([65536] + [4096] * 7 + [0] * 56, dtype=torch.int32)),
+         ("one128k", torch.tensor([131072] + [4096] * 31 + [0] * 32, dtype=torch.int32)))
 args = sys.argv[1:]
 heads_list = [(8, 64)]
 if args and args[0].startswith("heads="):
