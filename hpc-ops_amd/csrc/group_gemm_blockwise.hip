@@ -273,7 +273,10 @@ __global__ __launch_bounds__(64 * kWaves, (kWaves == 8 || kMT * kR >= 8) ? 1 : 2
 //  * the token-scale load uses a wave-uniform descriptor (the lane-dependent one above cost a waterfall loop per stage);
 //  * the weight loads of the first kDepth stages are issued before the lane's activation roles are known (see above).
 // Same arithmetic in the same order: bit-identical to the kernel above.  Development key 56 = 1 keeps that one.
-template <int kMT, int kDepth>
+//  * (kK128) a k-block is ONE v_mfma_f32_16x16x128_f8f6f4 per token block - the 256 x 256 kernel's instruction, operand
+//    convention (lane (r16, g4): chunks g4 and g4 + 4 of its row on both sides) and arithmetic: results are bit-identical to
+//    that kernel's bodies - instead of a chain of four dependent K = 32 MFMAs (kK128 = false: bit-identical to the kernel above).
+template <int kMT, int kDepth, bool kK128 = true>
 __global__ __launch_bounds__(256, 2) void gemm_blockwise_stream2_kernel(const Args a) {
   constexpr int kWaves = 4;
   constexpr int kTok = 16 * kMT;
@@ -418,22 +421,35 @@ __global__ __launch_bounds__(256, 2) void gemm_blockwise_stream2_kernel(const Ar
           f32x4 part[kMT];
 #pragma unroll
           for (int q = 0; q < kMT; ++q) part[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (kK128) {
+            const i32x8 av = {static_cast<int>(wf[kbl][0][0]), static_cast<int>(wf[kbl][0][1]), static_cast<int>(wf[kbl][0][2]),
+                              static_cast<int>(wf[kbl][0][3]), static_cast<int>(wf[kbl][1][0]), static_cast<int>(wf[kbl][1][1]),
+                              static_cast<int>(wf[kbl][1][2]), static_cast<int>(wf[kbl][1][3])};
 #pragma unroll
-          for (int q = 0; q < kMT; ++q)
-            part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(wf[kbl][0][0], wf[kbl][0][1]),
-                                                                 pack64(b0[kbl][q][0], b0[kbl][q][1]), part[q], 0, 0, 0);
+            for (int q = 0; q < kMT; ++q) {
+              const i32x8 bv = {static_cast<int>(b0[kbl][q][0]), static_cast<int>(b0[kbl][q][1]), static_cast<int>(b0[kbl][q][2]),
+                                static_cast<int>(b0[kbl][q][3]), static_cast<int>(b1[kbl][q][0]), static_cast<int>(b1[kbl][q][1]),
+                                static_cast<int>(b1[kbl][q][2]), static_cast<int>(b1[kbl][q][3])};
+              part[q] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(av, bv, part[q], 0, 0, 0, 0, 0, 0);
+            }
+          } else {
 #pragma unroll
-          for (int q = 0; q < kMT; ++q)
-            part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(wf[kbl][0][2], wf[kbl][0][3]),
-                                                                 pack64(b0[kbl][q][2], b0[kbl][q][3]), part[q], 0, 0, 0);
+            for (int q = 0; q < kMT; ++q)
+              part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(wf[kbl][0][0], wf[kbl][0][1]),
+                                                                   pack64(b0[kbl][q][0], b0[kbl][q][1]), part[q], 0, 0, 0);
 #pragma unroll
-          for (int q = 0; q < kMT; ++q)
-            part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(wf[kbl][1][0], wf[kbl][1][1]),
-                                                                 pack64(b1[kbl][q][0], b1[kbl][q][1]), part[q], 0, 0, 0);
+            for (int q = 0; q < kMT; ++q)
+              part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(wf[kbl][0][2], wf[kbl][0][3]),
+                                                                   pack64(b0[kbl][q][2], b0[kbl][q][3]), part[q], 0, 0, 0);
 #pragma unroll
-          for (int q = 0; q < kMT; ++q)
-            part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(wf[kbl][1][2], wf[kbl][1][3]),
-                                                                 pack64(b1[kbl][q][2], b1[kbl][q][3]), part[q], 0, 0, 0);
+            for (int q = 0; q < kMT; ++q)
+              part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(wf[kbl][1][0], wf[kbl][1][1]),
+                                                                   pack64(b1[kbl][q][0], b1[kbl][q][1]), part[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < kMT; ++q)
+              part[q] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(pack64(wf[kbl][1][2], wf[kbl][1][3]),
+                                                                   pack64(b1[kbl][q][2], b1[kbl][q][3]), part[q], 0, 0, 0);
+          }
 #pragma unroll
           for (int q = 0; q < kMT; ++q)
 #pragma unroll
@@ -514,11 +530,15 @@ int launch_stream_gemm(hpc::ggemm::Args& a, int num_group, int m, int n, const v
     gemm_blockwise_stream_kernel<2, 1, 8><<<grid, 512, 0, stream>>>(a);
   } else {
     dim3 grid(n / 64, num_group);
-    const bool v2 = hpc_dev_tuning_get(56) != 1;  // development key 56 = 1: the stage loop of rounds 1-5
-    if (mt == 1 && v2)
+    const int k56 = hpc_dev_tuning_get(56);  // development key 56: 1 = the stage loop of rounds 1-5, 2 = the new loop on K = 32 MFMAs
+    if (mt == 1 && k56 == 0)
       gemm_blockwise_stream2_kernel<1, 4><<<grid, kThreads, 0, stream>>>(a);
-    else if (mt == 2 && v2)
+    else if (mt == 2 && k56 == 0)
       gemm_blockwise_stream2_kernel<2, 4><<<grid, kThreads, 0, stream>>>(a);
+    else if (kHpcDevBuild && mt == 1 && k56 == 2)
+      gemm_blockwise_stream2_kernel<1, 4, false><<<grid, kThreads, 0, stream>>>(a);
+    else if (kHpcDevBuild && mt == 2 && k56 == 2)
+      gemm_blockwise_stream2_kernel<2, 4, false><<<grid, kThreads, 0, stream>>>(a);
     else if (mt == 1)
       gemm_blockwise_stream_kernel<1, 1><<<grid, kThreads, 0, stream>>>(a);
     else if (mt == 3)

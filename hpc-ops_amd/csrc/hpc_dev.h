@@ -54,7 +54,8 @@
 //   key 54 fp8 decode, quant_type 0 (per-token K scales): 1 = the first-generation kernel (rounds 1-5) instead of the head-pair kernel
 //   key 55 fp8 decode on HND pages (per-tensor scales): 1 = the head-pair kernel's HND form (1 KB pieces of one head per load) instead of the first-generation kernel
 //   key 56 streaming grouped GEMM (16 / 32 tokens per pass): 1 = the stage loop of rounds 1-5 (refill at the end of a stage, scalar scale loads
-//          waited for on the spot) instead of the re-ordered one (gemm_blockwise_stream2_kernel)
+//          waited for on the spot) instead of the re-ordered one (gemm_blockwise_stream2_kernel); 2 = the re-ordered loop on chains of four
+//          K = 32 MFMAs (bit-identical to 1) instead of one K = 128 MFMA per k-block (bit-identical to the 256 x 256 kernel)
 //   key 58 decode v2: 1 = the last arriver of a split request loads its first chunk again when the trip's second chunk does not exist (rounds 3-5)
 //   others: see the launchers that read them
 #pragma once
