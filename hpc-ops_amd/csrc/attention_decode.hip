@@ -870,7 +870,7 @@ static int try_second_generation(hpc::decode2::Args& b, void* workspace, int num
   const int mode = hpc::decode2::mode_of(b, num_head_q, block_size, k_head_stride_bytes, v_head_stride_bytes);
   int dev = 0;
   if (mode == 0 || hipGetDevice(&dev) != hipSuccess) return 1;
-  const int unit = num_head_kv / (mode == 2 ? 4 : 2);  // workgroup = (token range, head pair or quad)
+  const int unit = mode == 3 ? num_head_kv : num_head_kv / (mode == 2 ? 4 : 2);  // workgroup = (token range, head pair, quad or head)
   int num_wg = 2 * hpc_get_cu_count(dev);  // two 4-wave workgroups per CU (<= 256 registers, 65 KB of LDS each)
   const int wg_dev = hpc_dev_tuning_get(14);
   if (wg_dev > 0) num_wg = wg_dev;

@@ -48,6 +48,7 @@ struct Args {
 // the first time a workspace is used (the kernel leaves it zero); its place and size do not depend on the call.
 constexpr int64_t kCounterBytes = 64 * 1024;
 int64_t workspace_bytes(int num_wg);  // partial slots (2 per workgroup x 2 heads), after the first-generation region
+// 3: one kv head per workgroup (fp8, per-tensor scales, 17 ... 32 q rows per kv head, any page layout, pages of 32 / 64 tokens);
 // 0: not served here; 1: served (NHD pages with adjacent heads contiguous - 128 B apart for fp8, 256 B for bf16 -, or, fp8
 // with per-tensor scales and development key 55 = 1, HND pages with a head's tokens contiguous (a.hnd is set then); an even number of kv heads,
 // <= 16 q rows per kv head, <= 1024 requests).

@@ -210,8 +210,16 @@ constexpr int kFMasked = 32;  // some token of the WI is invisible to some q row
 //        piece the probe knows, and no workgroup fixes byte-address bits 8-9) and a 16-row block is two instructions per head.
 //        Only the lane -> (row, chunk) map of the loads and of the stage writes differs: the LDS image, and with it everything
 //        downstream, is the NHD form's.
-template <int kAux, bool kBf16 = false, bool kProf = false, bool kQuad = false, bool kKtok = false, bool kHnd = false>
+// kSolo: fp8, ONE kv head per workgroup with up to 32 q rows (round 6: speculative steps with num_seq_q * group in 17 ... 32 - the
+//        first-generation kernel's two-block form ran those at 0.49 of 8 TB/s on the C3 mix, one workgroup per CU with 506
+//        registers).  The workgroup's two "heads" hh = 0, 1 are the q-row halves [16 hh, 16 hh + 16) of the kv head: both read the
+//        SAME K / V.  A stage row is one token's 128 bytes, a wave-iteration 64 tokens (the same 8 KB of K + 8 KB of V in flight),
+//        a load instruction 8 tokens x 128 B; S^T = one K = 128 MFMA per 16-token block and half, the softmax runs over 64
+//        tokens, O^T += V^T P^T takes two K = 32 steps per 16 dims whose V^T operands (transposing reads) serve both halves.
+//        The head's rows sit at k / v_head_stride * head, tokens at k / v_token_stride: NHD and HND pages alike.
+template <int kAux, bool kBf16 = false, bool kProf = false, bool kQuad = false, bool kKtok = false, bool kHnd = false, bool kSolo = false>
 __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
+  static_assert(!kSolo || (!kBf16 && !kQuad && !kKtok && !kHnd), "one head per workgroup: fp8 with per-tensor scales");
   static_assert(!(kBf16 && kQuad), "the quad form is fp8");
   static_assert(!kKtok || (!kBf16 && !kQuad), "per-token K scales: the fp8 head-pair form");
   static_assert(!kHnd || (!kBf16 && !kQuad && !kKtok), "HND pages: the fp8 head-pair form with per-tensor scales");
@@ -221,10 +229,10 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   __shared__ float s_m[2][kWaves][16];
   __shared__ float s_l[2][kWaves][16];
   __shared__ int s_ticket[2];
-  constexpr int kH = kQuad ? 4 : 2;          // kv heads per workgroup
-  constexpr int kW = kWide ? 16 : 32;        // tokens (= stage rows) per wave-iteration
-  constexpr int kRowB = kWide ? 512 : 256;   // bytes of a stage row: the workgroup's heads of a token
-  constexpr int kRpi = kHnd ? 8 : kWide ? 2 : 4;  // rows per load instruction (64 lanes x 16 B = 1 KB; HND: 8 tokens of one head)
+  constexpr int kH = kSolo ? 1 : kQuad ? 4 : 2;  // kv heads per workgroup
+  constexpr int kW = kSolo ? 64 : kWide ? 16 : 32;        // tokens (= stage rows) per wave-iteration
+  constexpr int kRowB = kSolo ? 128 : kWide ? 512 : 256;  // bytes of a stage row: the workgroup's heads of a token
+  constexpr int kRpi = (kHnd || kSolo) ? 8 : kWide ? 2 : 4;  // rows per load instruction (64 lanes x 16 B = 1 KB; HND / solo: 8 tokens of one head)
   constexpr int kCpr = 64 / kRpi;            // 16-byte chunks per row
 
   const int tid = threadIdx.x;
@@ -237,7 +245,8 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   const int G = 1 << a.g_shift;
   const int rows_valid = Sq << a.g_shift;
   // tile row (= MFMA column) r16 -> does it hold a q row?  quad: rows 0..7 head 2p, 8..15 head 2p + 1
-  auto row_ok = [&](int r16) __attribute__((always_inline)) { return (kQuad ? (r16 & 7) : r16) < rows_valid; };
+  // (solo: tile hh holds q rows 16 hh ... 16 hh + 15 of the one kv head)
+  auto row_ok = [&](int r16, int hh = 0) __attribute__((always_inline)) { return (kQuad ? (r16 & 7) : kSolo ? 16 * hh + r16 : r16) < rows_valid; };
   const int page_mask = (1 << a.page_shift) - 1;
   const cint_ptr lens = as_const(a.lens);
   const int mpl_tiles = as_const(a.task_map)[6] >> 6;  // scalar load, in flight beside the length loads of the plan
@@ -461,8 +470,8 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   const int vs1 = sgpr(kRpi * v_rs), vs2 = sgpr(kHnd ? static_cast<uint32_t>(a.v_head_stride) : 2 * kRpi * v_rs);
   const int vs3 = sgpr(kHnd ? static_cast<uint32_t>(a.v_head_stride) + kRpi * v_rs : 3 * kRpi * v_rs);
   const int mem_slice = a.dev_slice > 0 ? a.dev_slice - 1 : pr;
-  const uint64_t kbase_h = reinterpret_cast<uint64_t>(a.kcache) + static_cast<uint64_t>(mem_slice) * (kHnd ? 2 * static_cast<uint64_t>(a.k_head_stride) : kRowB);
-  const uint64_t vbase_h = reinterpret_cast<uint64_t>(a.vcache) + static_cast<uint64_t>(mem_slice) * (kHnd ? 2 * static_cast<uint64_t>(a.v_head_stride) : kRowB);
+  const uint64_t kbase_h = reinterpret_cast<uint64_t>(a.kcache) + static_cast<uint64_t>(mem_slice) * (kSolo ? static_cast<uint64_t>(a.k_head_stride) : kHnd ? 2 * static_cast<uint64_t>(a.k_head_stride) : kRowB);
+  const uint64_t vbase_h = reinterpret_cast<uint64_t>(a.vcache) + static_cast<uint64_t>(mem_slice) * (kSolo ? static_cast<uint64_t>(a.v_head_stride) : kHnd ? 2 * static_cast<uint64_t>(a.v_head_stride) : kRowB);
   const uint32_t kbs = static_cast<uint32_t>(a.k_block_stride), vbs = static_cast<uint32_t>(a.v_block_stride);  // < 4 GB (eligible())
   const bool mem = a.dev_nomem == 0;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing)
   i32x4 dk0, dk1, dv0, dv1;  // descriptors of the WI being issued
@@ -527,12 +536,18 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   //      the 32 lanes of a pass cover all 16 tokens of one chunk: 16 different slots x 2 halves
   const int qtok = 4 * (g & 1) + (tj & 3) + 8 * (tj >> 2);
   // HND writes: lane (r8 = lane / 8, c = lane % 8) of instruction (tb, q) holds chunk (q / 2) * 8 + c of row tb * 16 + (q % 2) * 8 + r8
-  const uint32_t w0_inv = kHnd ? lds0 + (lane >> 3) * kRowB + (((lane & 7) ^ (lane >> 3)) * 16)
+  // solo (64 rows of 128 B = 8 chunks; key(t) = (t & 7) ^ ((t >> 4) & 1) * 4 - the 8 rows of a transpose read, tokens 4 g + j and
+  //      16 + 4 g + j, fall on 8 different slots): writes: lane (r8 = lane / 8, c = lane % 8) of instruction (tb, q) holds chunk c of
+  //      row tb * 32 + q * 8 + r8; K reads: lane (n, g), row tb * 16 + n, chunks g and g + 4; V transpose reads: k-step s, lane
+  //      (i, g): stage row 32 s + 16 (j / 4) + 4 g + j % 4 with j = i / 2, 8-byte half i % 2, chunk jj
+  const uint32_t w0_inv = kSolo ? lds0 + (lane >> 3) * kRowB + (((lane & 7) ^ (lane >> 3)) * 16)
+                          : kHnd ? lds0 + (lane >> 3) * kRowB + (((lane & 7) ^ (lane >> 3)) * 16)
                           : kWide ? lds0 + (lane >> 5) * kRowB + (((lane & 31) ^ (lane >> 5)) * 16)
                                   : lds0 + (lane >> 4) * kRowB + (((lane & 15) ^ (lane >> 4)) * 16);
   const uint32_t w1_inv = lds0 + kVOff + (lane >> 5) * kRowB + (((lane & 31) ^ ((lane >> 5) << 1)) * 16);  // bf16 V stage
-  const uint32_t r0_inv = lds0 + n * kRowB + ((g ^ n) * 16);
+  const uint32_t r0_inv = kSolo ? lds0 + n * kRowB + ((g ^ (n & 7)) * 16) : lds0 + n * kRowB + ((g ^ n) * 16);
   const uint32_t t0_inv = kBf16 ? lds0 + kVOff + btok * kRowB + (((((lane & 3) >> 1) ^ bkey)) * 16) + (lane & 1) * 8
+                          : kSolo ? lds0 + kVOff + ttok * kRowB + ((((ttok & 7) ^ (((ttok >> 4) & 1) << 2))) * 16) + (lane & 1) * 8
                           : kQuad ? lds0 + kVOff + qtok * kRowB + ((((g >> 1) << 3) ^ qtok) * 16) + (lane & 1) * 8
                                   : lds0 + kVOff + ttok * kRowB + ((((ttok & 15) ^ ((ttok >> 4) << 3))) * 16) + (lane & 1) * 8;
   const uint32_t p_keep = (n >> 3) == (g >> 1) ? 0xffffffffu : 0u;  // quad: this lane group carries k-slots of the column's head
@@ -570,6 +585,19 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
                                static_cast<unsigned>(((Sq - 1) * a.qscale_stride + kH * G) * 4));
       ld_q3(reinterpret_cast<u32x4(&)[2]>(qf[0]), qsc[0], q_voff, rq, s_voff, rsq);
       ld_q3(reinterpret_cast<u32x4(&)[2]>(qf[1]), qsc[1], okc ? q_voff + 2 * G * 128 : -256, rq, okc ? s_voff + 2 * G * 4 : -256, rsq);
+      return;
+    }
+    if constexpr (kSolo) {  // tile hh = q rows 16 hh + n of the kv head; rows past the call's Sq * G read zeros (bounded descriptors)
+      const i32x4 rq = srd_of(qbase + static_cast<long>(db) * Sq * a.ldq + (pr << a.g_shift) * 128,
+                              static_cast<unsigned>((Sq - 1) * a.ldq + G * 128));
+      const i32x4 rsq = srd_of(a.qscale + static_cast<long>(db) * Sq * a.qscale_stride + (pr << a.g_shift),
+                               static_cast<unsigned>(((Sq - 1) * a.qscale_stride + G) * 4));
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int r = 16 * hh + n;
+        ld_q3(reinterpret_cast<u32x4(&)[2]>(qf[hh]), qsc[hh], (r >> a.g_shift) * a.ldq + (r & (G - 1)) * 128 + g * 16, rq,
+              ((r >> a.g_shift) * a.qscale_stride + (r & (G - 1))) * 4, rsq);
+      }
       return;
     }
     const int q_voff = (n >> a.g_shift) * a.ldq + (n & (G - 1)) * 128 + g * 16;
@@ -627,9 +655,9 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     }
   };
   auto store_y = [&](int db, int hh, int row16, int c8, const float (&acc)[8], float inv) __attribute__((always_inline)) {
-    const int qrow = kQuad ? (row16 & 7) : row16;  // quad: tile hh = heads 2 hh, 2 hh + 1 of the workgroup
+    const int qrow = kQuad ? (row16 & 7) : kSolo ? 16 * hh + row16 : row16;  // quad: tile hh = heads 2 hh, 2 hh + 1 of the workgroup
     const int rs = qrow >> a.g_shift;
-    const int h = kQuad ? pr * kH + hh * 2 + (row16 >> 3) : pr * kH + hh;
+    const int h = kQuad ? pr * kH + hh * 2 + (row16 >> 3) : kSolo ? pr : pr * kH + hh;
     uint16_t* dst = a.y + (static_cast<long>(db) * Sq + rs) * a.ldy + ((h << a.g_shift) + (qrow & (G - 1))) * 128 + c8 * 8;
     u32x4 pk;
 #pragma unroll
@@ -725,9 +753,9 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     }
     __syncthreads();
     const int row16 = tid >> 4, c8 = tid & 15;
-    if (row_ok(row16)) {
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
+    for (int hh = 0; hh < 2; ++hh) {
+      if (row_ok(row16, hh)) {
         float acc[8], M, L;
         combine4(hh, row16, c8, acc, M, L);
         store_y(db, hh, row16, c8, acc, L > 0.f ? 1.0f / L : 0.f);
@@ -782,7 +810,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
         float acc[8], M, L;
         combine4(hh, row16, c8, acc, M, L);
         const float inv = (L > 0.f ? 1.0f / L : 0.f) * (kKtok ? out_scale_h[hh] : out_scale);
-        if (row_ok(row16)) {
+        if (row_ok(row16, hh)) {
           if (nchunks == 1) {
             store_y(db, hh, row16, c8, acc, inv);
           } else {
@@ -867,7 +895,9 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     auto write_k = [&](int tb) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if constexpr (kHnd)
+        if constexpr (kSolo)
+          *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q >> 1) << 2) * 16)) + (tb * 32 + q * 8) * kRowB)) = kr[tb][q];
+        else if constexpr (kHnd)
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ ((((q >> 1) << 3) ^ ((q & 1) << 3) ^ (tb << 3)) * 16)) + (tb * 16 + (q & 1) * 8) * kRowB)) = kr[tb][q];
         else if constexpr (kWide)
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q << 1) ^ (tb << 3)) * 16)) + (tb * 8 + q * 2) * kRowB)) = kr[tb][q];
@@ -878,7 +908,9 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     auto write_v = [&](int tb) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if constexpr (kHnd)
+        if constexpr (kSolo)
+          *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q >> 1) << 2) * 16)) + kVOff + (tb * 32 + q * 8) * kRowB)) = vr[tb][q];
+        else if constexpr (kHnd)
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ ((((q >> 1) << 3) ^ ((q & 1) << 3) ^ (tb << 3)) * 16)) + kVOff + (tb * 16 + (q & 1) * 8) * kRowB)) = vr[tb][q];
         else if constexpr (kBf16)
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w1 ^ (((q << 2) ^ tb) * 16)) + (tb * 8 + q * 2) * kRowB)) = vr[tb][q];
@@ -1089,6 +1121,96 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
               pack64(static_cast<uint32_t>(vt[u][0]), static_cast<uint32_t>(vt[u][1])), pack64(pf[p][0], pf[p][1]), o[p][u], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
+    } else if constexpr (kSolo) {
+      // S^T = K Q^T: one K = 128 MFMA per 16-token block and q-row half; the K fragments of a block serve both halves
+      f32x4 sacc[2][4];
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) {
+        const u32x4 k0 = *reinterpret_cast<const lds_u32x4*>(static_cast<uint32_t>((r0 ^ (((tb & 1) << 2) * 16)) + tb * 16 * kRowB));
+        const u32x4 k1 = *reinterpret_cast<const lds_u32x4*>(static_cast<uint32_t>((r0 ^ ((((tb & 1) << 2) ^ 4) * 16)) + tb * 16 * kRowB));
+        const i32x8 kv8 = {static_cast<int>(k0[0]), static_cast<int>(k0[1]), static_cast<int>(k0[2]), static_cast<int>(k0[3]),
+                           static_cast<int>(k1[0]), static_cast<int>(k1[1]), static_cast<int>(k1[2]), static_cast<int>(k1[3])};
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const u32x4 q0 = qf[hh][0], q1 = qf[hh][1];
+          const i32x8 qv8 = {static_cast<int>(q0[0]), static_cast<int>(q0[1]), static_cast<int>(q0[2]), static_cast<int>(q0[3]),
+                             static_cast<int>(q1[0]), static_cast<int>(q1[1]), static_cast<int>(q1[2]), static_cast<int>(q1[3])};
+          sacc[hh][tb] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(kv8, qv8, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0, 0, 0, 0);
+        }
+      }
+      // online softmax in base 2 over the 64 tokens; lane (n, g) holds tokens 16 tb + 4 g + r of q row 16 hh + n.  P~ = e4m3(256 p)
+      // as in the pair form.
+      uint32_t pf[2][4];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const float rsc = row_scale[hh];
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc[hh][tb][r] *= rsc;
+      }
+      if (d_fl & kFMasked) {  // wave-uniform: only the WIs that hold a request's last tokens
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int sq_row = (16 * hh + n) >> a.g_shift;
+          const int lim = (q0_end - 1 < q0_ltot - Sq + sq_row) ? q0_end - 1 : q0_ltot - Sq + sq_row;
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[hh][tb][r] = (d_tok + tb * 16 + g * 4 + r) <= lim ? sacc[hh][tb][r] : kNegInf;
+        }
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float mt = kNegInf;
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mt = __builtin_fmaxf(mt, sacc[hh][tb][r]);
+        mt = row4_max(mt);
+        const float m_new = fmaxf(m_run[hh], mt);
+        const float m_use = m_new == kNegInf ? 0.f : m_new;
+        const float m8 = m_use - 8.0f;
+        float psum = 0.f;
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+          float prb[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            prb[r] = __builtin_amdgcn_exp2f(sacc[hh][tb][r] - m8);
+            psum += prb[r];
+          }
+          int w = __builtin_amdgcn_cvt_pk_fp8_f32(prb[0], prb[1], 0, false);
+          w = __builtin_amdgcn_cvt_pk_fp8_f32(prb[2], prb[3], w, true);
+          pf[hh][tb] = static_cast<uint32_t>(w);
+        }
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run[hh]) != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(m_run[hh] - m_use);
+          l_run[hh] *= alpha;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) o[hh][jj] *= alpha;
+          m_run[hh] = m_new;
+        }
+        l_run[hh] += psum;
+      }
+      // O^T += V^T P^T: two K = 32 steps (tokens 32 s ... 32 s + 31); a step's eight transposing reads feed both halves
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        v2i32 vt[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          vt[u] = __builtin_amdgcn_ds_read_tr8_b64_v2i32(
+              reinterpret_cast<lds_v2i32*>(static_cast<uint32_t>((t0 ^ (u * 16)) + st * 32 * kRowB)));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            o[hh][u] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(
+                pack64(static_cast<uint32_t>(vt[u][0]), static_cast<uint32_t>(vt[u][1])), pack64(pf[hh][2 * st], pf[hh][2 * st + 1]),
+                o[hh][u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else {
       // S^T = K Q^T: one K = 128 MFMA per 16-row block and 128-byte half (lane (n, g) supplies chunks g and g + 4 of its
       // row on both sides - a dot product does not care which lane slot a dim sits in)
@@ -1244,6 +1366,25 @@ int mode_of(Args& a, int num_head_q, int block_size, int64_t k_head_stride, int6
   a.hnd = 0;
   a.k_head_stride = k_head_stride;
   a.v_head_stride = v_head_stride;
+  // One kv head per workgroup with up to 32 q rows (kSolo, mode 3): speculative steps with 17 ... 32 q rows per kv head (round 6).
+  // Any head / token strides (NHD and HND pages), any head count, pages of 32 / 64 tokens.  Measured against the first generation's
+  // two-block form (profiles/round6_decode_ab.txt, call 8; C3 lengths, us): num_seq_q 3, 8 / 64 heads NHD mix 195.6 -> 163.8,
+  // uniform 8k 220 -> 196; HND 193 -> 150 / 218 -> 180; num_seq_q 4: 4 / 32 heads 112 -> 87.5 / 112 -> 95, 1 / 8 heads 49.5 -> 41.4.
+  // Development key 60: 1 = never (rounds 1-5), 2 = also every other fp8 call with per-tensor scales that the pair form does not
+  // take (<= 16 q rows on HND pages or with an odd head count) - there the first generation stays ahead (one kv head, 8 q rows:
+  // 31 against 38-40 us; HND mix 138 / 139, 32 x 128 + 32 x 4k 63 against 71 us).
+  {
+    const int rows = a.num_seq_q * group, k60 = hpc_dev_tuning_get(60);
+    const bool pair_case = (a.num_head_kv % 2) == 0 && rows <= 16 && k_head_stride == head_bytes && v_head_stride == head_bytes;
+    const bool shape_ok = !a.bf16 && !a.ktok && a.lens != nullptr && rows <= 32 && (block_size == 64 || block_size == 32) &&
+                          (a.k_token_stride % 16) == 0 && (a.v_token_stride % 16) == 0 && (k_head_stride % 16) == 0 &&
+                          (v_head_stride % 16) == 0 && (a.k_block_stride % 16) == 0 && (a.v_block_stride % 16) == 0 &&
+                          a.k_block_stride > 0 && a.v_block_stride > 0 && a.k_block_stride < (1ll << 32) &&
+                          a.v_block_stride < (1ll << 32) && a.k_token_stride * 32 < (1ll << 31) && a.v_token_stride * 32 < (1ll << 31) &&
+                          a.num_batch <= 64 * 16 && static_cast<int64_t>(a.num_batch) * a.num_head_kv * 4 <= kCounterBytes;
+    const bool wanted = k60 == 2 ? !pair_case : (k60 == 0 && rows > 16);
+    if (shape_ok && wanted) return 3;
+  }
   const bool hnd = !a.bf16 && !a.ktok && a.k_token_stride == 128 && a.v_token_stride == 128 && k_head_stride >= 128 * block_size &&
                    v_head_stride >= 128 * block_size && (k_head_stride % 16) == 0 && (v_head_stride % 16) == 0 &&
                    k_head_stride < (1ll << 28) && v_head_stride < (1ll << 28) && a.num_head_kv > 1 && hpc_dev_tuning_get(55) == 1;
@@ -1293,6 +1434,34 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
   a.part_lse = reinterpret_cast<float*>(ws);
   a.arrive = static_cast<int*>(counters);
   const bool temporal = hpc_dev_tuning_get(0) == 1;
+  if (mode == 3) {  // one kv head per workgroup
+    a.dev_slice = a.xcd_map = a.dev_sleep = 0;
+    a.pair_xor = a.mate_from = 0;
+    a.pair_wgs[0] = a.pair_wgs[1] = a.pair_wgs[2] = a.pair_wgs[3] = 0;
+    a.big_pct = 100;
+    {  // the pair form's CU-mate rule (a CU's two workgroups on slices across an address bit) makes no difference here - masks 1, 2,
+       // 4, 6 on 8 heads: C3 mix 160.6-164.3 us with and without, call 8 - so it is off; development key 36 = mask + 1 switches it on
+      int dev = 0;
+      const int cus = hipGetDevice(&dev) == hipSuccess ? hpc_get_cu_count(dev) : 0;
+      const int k36 = hpc_dev_tuning_get(36);
+      const int mask = k36 > 0 ? k36 - 1 : 0;
+      const int np = a.num_head_kv;
+      if (cus > 0 && num_wg > cus && (np & (np - 1)) == 0 && mask > 0 && mask < np && cus % np == 0) {
+        a.pair_xor = mask;
+        a.mate_from = cus;
+      }
+    }
+    if (kHpcDevBuild && a.prof)
+      decode2_kernel<2, false, true, false, false, false, true><<<num_wg, kThreads, 0, stream>>>(a);
+    else
+      decode2_kernel<2, false, false, false, false, false, true><<<num_wg, kThreads, 0, stream>>>(a);
+    if (hipGetLastError() != hipSuccess) {
+      (void)hipMemsetAsync(counters, 0, kCounterBytes, stream);
+      (void)hipGetLastError();
+      return HPC_ERR_LAUNCH;
+    }
+    return HPC_OK;
+  }
   a.dev_slice = hpc_dev_tuning_get(37);
   a.xcd_map = hpc_dev_tuning_get(38);
   a.dev_sleep = hpc_dev_tuning_get(39);

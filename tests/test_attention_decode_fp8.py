@@ -157,6 +157,26 @@ def test_attn_fp8_head_pair_kernel_hnd_form(num_seq_q, heads, block_size):
         dev_set(55, 0)
 
 
+@pytest.mark.dev
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_seq_q,heads,block_size,shape,key", [(3, (8, 64), 64, "NHD", 0), (4, (4, 32), 32, "HND", 0), (4, (1, 8), 64, "NHD", 0),
+                                                                  (3, (2, 16), 32, "NHD", 0), (2, (3, 24), 64, "NHD", 2), (1, (2, 8), 64, "HND", 2),
+                                                                  (4, (3, 12), 32, "NHD", 2), (3, (2, 16), 64, "NHD", 1), (4, (4, 32), 64, "HND", 1)])
+def test_attn_fp8_one_head_per_workgroup_form(num_seq_q, heads, block_size, shape, key):
+    """Speculative steps with 17 ... 32 q rows per kv head (num_seq_q 3 / 4 at 8 q heads per kv head, 2 at 16) run ONE kv head per
+    workgroup on the head-pair kernel's pipeline since round 6 (attention_decode_v2.hip, kSolo: 64-token wave-iterations of
+    128-byte rows, both q-row halves on the same K / V; any page layout and head count).  Development key 60 = 2 sends every
+    other per-tensor call there that the pair form does not take (odd head counts, HND pages); key 60 = 1 keeps the
+    first generation's two-block form under test.  Split, short and empty requests; twice (arrival counters left zero)."""
+    lens = torch.tensor([20000, 3, 9000, 130, 64, 63, 65, 4097, 700, 1, 127, 129, 31000, 2, 0, 255, 256, 257], dtype=torch.int32)
+    dev_set(60, key)
+    try:
+        for _ in range(2):
+            _run(len(lens), num_seq_q, lens, block_size, heads, False, True, True, shape, 0.2)
+    finally:
+        dev_set(60, 0)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["last_arriver", "poisoned_partials"])
 def test_attn_fp8_split_request_merge_variants(mode):
