@@ -140,6 +140,10 @@ __device__ __forceinline__ void wait_ks(uint32_t& sc) {
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(sc) : "n"(N));
 }
 template <int N>
+__device__ __forceinline__ void wait_ks2(uint32_t& sc0, uint32_t& sc1) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(sc0), "+v"(sc1) : "n"(N));
+}
+template <int N>
 __device__ __forceinline__ void wait_q8(u32x4 (&q0)[4], u32x4 (&q1)[4]) {
   asm volatile("s_waitcnt vmcnt(%8)"
                : "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3]), "+v"(q1[0]), "+v"(q1[1]), "+v"(q1[2]), "+v"(q1[3])
@@ -219,7 +223,7 @@ constexpr int kFMasked = 32;  // some token of the WI is invisible to some q row
 //        The head's rows sit at k / v_head_stride * head, tokens at k / v_token_stride: NHD and HND pages alike.
 template <int kAux, bool kBf16 = false, bool kProf = false, bool kQuad = false, bool kKtok = false, bool kHnd = false, bool kSolo = false>
 __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
-  static_assert(!kSolo || (!kBf16 && !kQuad && !kKtok && !kHnd), "one head per workgroup: fp8 with per-tensor scales");
+  static_assert(!kSolo || (!kBf16 && !kQuad && !kHnd), "one head per workgroup: fp8");
   static_assert(!(kBf16 && kQuad), "the quad form is fp8");
   static_assert(!kKtok || (!kBf16 && !kQuad), "per-token K scales: the fp8 head-pair form");
   static_assert(!kHnd || (!kBf16 && !kQuad && !kKtok), "HND pages: the fp8 head-pair form with per-tensor scales");
@@ -476,11 +480,17 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   const bool mem = a.dev_nomem == 0;  // development key 15 = 1: K / V loads fetch nothing (compute-only timing)
   i32x4 dk0, dk1, dv0, dv1;  // descriptors of the WI being issued
   uint32_t ksr = 0;           // kKtok: the WI's 64 K scales in flight (lane = head * 32 + token)
+  uint32_t ksr1 = 0;          // kKtok + kSolo: tokens 32 ... 63 of the one head (ksr: tokens 0 ... 31; lanes l and l + 32 hold the same)
   i32x4 dks = i32x4{0, 0, 0, 0x00020000};
+  i32x4 dks1 = i32x4{0, 0, 0, 0x00020000};
   // K-scale tail row of the wave's WIs: they start at multiples of 32 tokens, so one row (tok / 32 within the page) and
   // one page hold a WI's scales (pages of 32 / 64 tokens: eligible()); the pair's two heads are 2 x 128 contiguous bytes
-  const uint64_t ksbase_h = reinterpret_cast<uint64_t>(a.kscale) + static_cast<uint64_t>(mem_slice) * 2 * a.ks_head_stride +
+  // (one head per workgroup: the 64 tokens of a wave-iteration are two 128-byte pieces - tail rows in0 / 32 and in0 / 32 + 1 of the
+  // page, or row in1 / 32 of the next page when a page holds 32 tokens)
+  const uint64_t ksbase_h = reinterpret_cast<uint64_t>(a.kscale) + static_cast<uint64_t>(mem_slice) * (kSolo ? 1 : 2) * a.ks_head_stride +
                             static_cast<uint64_t>(in0 >> 5) * a.ks_row_stride;
+  const uint64_t ksbase1_h = reinterpret_cast<uint64_t>(a.kscale) + static_cast<uint64_t>(mem_slice) * a.ks_head_stride +
+                             static_cast<uint64_t>(blk1_same_page ? (in0 >> 5) + 1 : in1 >> 5) * a.ks_row_stride;
   const uint32_t ksbs = static_cast<uint32_t>(a.ks_block_stride);
   auto make_descs = [&](int fl, int pid0, int pid1) __attribute__((always_inline)) {
     const int nrec0 = (fl & kFOn0) && mem ? -1 : 0, nrec1 = (fl & kFOn1) && mem ? -1 : 0;
@@ -499,7 +509,11 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     }
     if constexpr (kKtok) {
       const uint64_t sa = ksbase_h + static_cast<uint64_t>(static_cast<uint32_t>(pid0)) * ksbs;
-      dks = srd(static_cast<uint32_t>(sa), static_cast<uint32_t>(sa >> 32), (fl & kFOn0) ? 256 : 0);
+      dks = srd(static_cast<uint32_t>(sa), static_cast<uint32_t>(sa >> 32), (fl & kFOn0) ? (kSolo ? 128 : 256) : 0);
+      if constexpr (kSolo) {
+        const uint64_t sb = ksbase1_h + static_cast<uint64_t>(static_cast<uint32_t>(blk1_same_page ? pid0 : pid1)) * ksbs;
+        dks1 = srd(static_cast<uint32_t>(sb), static_cast<uint32_t>(sb >> 32), (fl & kFOn1) ? 128 : 0);
+      }
     }
   };
   auto issue_k0 = [&]() __attribute__((always_inline)) { ld_x4x4<kAux>(kr[0], k_voff0, dk0, ks1, ks2, ks3); };
@@ -507,7 +521,12 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   auto issue_v0 = [&]() __attribute__((always_inline)) { ld_x4x4<kAux>(vr[0], v_voff0, dv0, vs1, vs2, vs3); };
   auto issue_v1 = [&]() __attribute__((always_inline)) { ld_x4x4<kAux>(vr[1], v_voff1, dv1, vs1, vs2, vs3); };
   auto issue_ks = [&]() __attribute__((always_inline)) {  // (between K and V: the V waits do not change)
-    if constexpr (kKtok) ld_ks(ksr, lane * 4, dks);
+    if constexpr (kKtok && kSolo) {
+      ld_ks(ksr, (lane & 31) * 4, dks);
+      ld_ks(ksr1, (lane & 31) * 4, dks1);
+    } else if constexpr (kKtok) {
+      ld_ks(ksr, lane * 4, dks);
+    }
   };
 
   // ---- LDS stage addressing (loop-invariant per lane) ----------------------------------------------------------
@@ -935,8 +954,8 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
           for (int hh = 0; hh < 2; ++hh) row_scale[hh] = a.scale_log2 * __uint_as_float(qsc[hh]) * kmul;
           out_scale = as_constf(a.vscale)[0];  // the 1/256 of the reference formula cancels: l = 256 sum p
           if constexpr (kKtok) {  // per-head V scales
-            out_scale_h[0] = as_constf(a.vscale)[pr * 2];
-            out_scale_h[1] = as_constf(a.vscale)[pr * 2 + 1];
+            out_scale_h[0] = as_constf(a.vscale)[kSolo ? pr : pr * 2];
+            out_scale_h[1] = as_constf(a.vscale)[kSolo ? pr : pr * 2 + 1];
           }
         }
       }
@@ -944,12 +963,16 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     // registers -> the wave's LDS stage (rows of 256 B, chunks swizzled); a register set is free again as soon as
     // it has been written out: the next WI (of this or the next task) goes in flight
     // (kKtok: the scale load sits between the K and the V loads - one more load younger than K)
-    wait_x4x4<12 + (kKtok ? 1 : 0)>(kr[0]);
-    wait_x4x4<8 + (kKtok ? 1 : 0)>(kr[1]);
+    constexpr int kNks = kKtok ? (kSolo ? 2 : 1) : 0;  // scale loads between the K and the V loads
+    wait_x4x4<12 + kNks>(kr[0]);
+    wait_x4x4<8 + kNks>(kr[1]);
     if constexpr (kProf) { const uint64_t t = now(); pf_wk += t - pf_last; pf_last = t; }
     write_k(0);
     write_k(1);
-    if constexpr (kKtok) {
+    if constexpr (kKtok && kSolo) {
+      wait_ks2<8>(ksr, ksr1);
+      s_ks[wave][lane] = __uint_as_float(lane < 32 ? ksr : ksr1);  // index = token of the wave-iteration
+    } else if constexpr (kKtok) {
       wait_ks<8>(ksr);
       s_ks[wave][lane] = __uint_as_float(ksr);
     }
@@ -1145,9 +1168,15 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
       for (int hh = 0; hh < 2; ++hh) {
         const float rsc = row_scale[hh];
 #pragma unroll
-        for (int tb = 0; tb < 4; ++tb)
+        for (int tb = 0; tb < 4; ++tb) {
+          f32x4 kt = f32x4{1.f, 1.f, 1.f, 1.f};
+          if constexpr (kKtok) kt = *reinterpret_cast<const f32x4*>(&s_ks[wave][tb * 16 + g * 4]);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) sacc[hh][tb][r] *= rsc;
+          for (int r = 0; r < 4; ++r) {
+            sacc[hh][tb][r] *= rsc;
+            if constexpr (kKtok) sacc[hh][tb][r] *= kt[r];
+          }
+        }
       }
       if (d_fl & kFMasked) {  // wave-uniform: only the WIs that hold a request's last tokens
 #pragma unroll
@@ -1375,8 +1404,11 @@ int mode_of(Args& a, int num_head_q, int block_size, int64_t k_head_stride, int6
   // 31 against 38-40 us; HND mix 138 / 139, 32 x 128 + 32 x 4k 63 against 71 us).
   {
     const int rows = a.num_seq_q * group, k60 = hpc_dev_tuning_get(60);
-    const bool pair_case = (a.num_head_kv % 2) == 0 && rows <= 16 && k_head_stride == head_bytes && v_head_stride == head_bytes;
-    const bool shape_ok = !a.bf16 && !a.ktok && a.lens != nullptr && rows <= 32 && (block_size == 64 || block_size == 32) &&
+    const bool pair_case = (a.num_head_kv % 2) == 0 && rows <= 16 && k_head_stride == head_bytes && v_head_stride == head_bytes &&
+                           (!a.ktok || a.ks_head_stride == 128);
+    const bool ks_ok = !a.ktok || (a.ks_block_stride > 0 && a.ks_block_stride < (1ll << 32) && (a.ks_row_stride % 4) == 0 &&
+                                   (a.ks_head_stride % 4) == 0);
+    const bool shape_ok = !a.bf16 && ks_ok && a.lens != nullptr && rows <= 32 && (block_size == 64 || block_size == 32) &&
                           (a.k_token_stride % 16) == 0 && (a.v_token_stride % 16) == 0 && (k_head_stride % 16) == 0 &&
                           (v_head_stride % 16) == 0 && (a.k_block_stride % 16) == 0 && (a.v_block_stride % 16) == 0 &&
                           a.k_block_stride > 0 && a.v_block_stride > 0 && a.k_block_stride < (1ll << 32) &&
@@ -1451,7 +1483,9 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
         a.mate_from = cus;
       }
     }
-    if (kHpcDevBuild && a.prof)
+    if (a.ktok)
+      decode2_kernel<2, false, false, false, true, false, true><<<num_wg, kThreads, 0, stream>>>(a);
+    else if (kHpcDevBuild && a.prof)
       decode2_kernel<2, false, true, false, false, false, true><<<num_wg, kThreads, 0, stream>>>(a);
     else
       decode2_kernel<2, false, false, false, false, false, true><<<num_wg, kThreads, 0, stream>>>(a);

@@ -162,7 +162,7 @@ def test_attn_fp8_head_pair_kernel_hnd_form(num_seq_q, heads, block_size):
 @pytest.mark.parametrize("num_seq_q,heads,block_size,shape,key", [(3, (8, 64), 64, "NHD", 0), (4, (4, 32), 32, "HND", 0), (4, (1, 8), 64, "NHD", 0),
                                                                   (3, (2, 16), 32, "NHD", 0), (2, (3, 24), 64, "NHD", 2), (1, (2, 8), 64, "HND", 2),
                                                                   (4, (3, 12), 32, "NHD", 2), (3, (2, 16), 64, "NHD", 1), (4, (4, 32), 64, "HND", 1)])
-def test_attn_fp8_one_head_per_workgroup_form(num_seq_q, heads, block_size, shape, key):
+def test_attn_fp8_one_head_per_workgroup_form(num_seq_q, heads, block_size, shape, key, k_per_token=False):
     """Speculative steps with 17 ... 32 q rows per kv head (num_seq_q 3 / 4 at 8 q heads per kv head, 2 at 16) run ONE kv head per
     workgroup on the head-pair kernel's pipeline since round 6 (attention_decode_v2.hip, kSolo: 64-token wave-iterations of
     128-byte rows, both q-row halves on the same K / V; any page layout and head count).  Development key 60 = 2 sends every
@@ -172,9 +172,19 @@ def test_attn_fp8_one_head_per_workgroup_form(num_seq_q, heads, block_size, shap
     dev_set(60, key)
     try:
         for _ in range(2):
-            _run(len(lens), num_seq_q, lens, block_size, heads, False, True, True, shape, 0.2)
+            _run(len(lens), num_seq_q, lens, block_size, heads, k_per_token, True, True, shape, 0.1 if k_per_token else 0.2)
     finally:
         dev_set(60, 0)
+
+
+@pytest.mark.dev
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_seq_q,heads,block_size,shape,key", [(4, (4, 32), 64, "NHD", 0), (4, (1, 8), 32, "NHD", 0), (3, (2, 16), 64, "HND", 0),
+                                                                  (3, (8, 64), 32, "HND", 0), (4, (4, 32), 64, "NHD", 1)])
+def test_attn_fp8_one_head_per_workgroup_form_per_token_k_scales(num_seq_q, heads, block_size, shape, key):
+    """quant_type 0 with 17 ... 32 q rows per kv head on the same form: the 64 K scales of a wave-iteration are two 128-byte
+    pieces of the head's tail rows (one page of 64 tokens, or two of 32), V scales per head."""
+    test_attn_fp8_one_head_per_workgroup_form(num_seq_q, heads, block_size, shape, key, k_per_token=True)
 
 
 @pytest.mark.gpu
