@@ -149,8 +149,8 @@ def assign_attention_decode_task(
     three byte ranges are copied into the device workspace); both give byte-identical maps.
 
     `min_process_len` (KV tokens one workgroup processes at least) shapes the map's bins for the kernels that consume
-    the map (HND pages, per-token K scales, odd kv-head counts).  The head-pair kernels (NHD pages, even kv-head count:
-    csrc/attention_decode_v2.hip) plan their ranges in closed form inside the launch - the map's bins and split
+    the map (<= 16 q rows per kv head on HND pages or with an odd kv-head count).  The head-pair kernels (NHD pages, even
+    kv-head count; 17-32 q rows per kv head on any layout: csrc/attention_decode_v2.hip) plan their ranges in closed form inside the launch - the map's bins and split
     decisions do not apply there - and honour this lower bound through header int 6 of the map, where the scheduler
     records it (csrc/sched_task_info.h)."""
     if num_seq_kvcache.device.type == "cpu":

@@ -143,8 +143,10 @@ int hpc_attention_decode_bf16_async(void* y_ptr, void* workspace, const int* tas
  * row and load - two heads of a token - deep prefetch, the schedule planned in-kernel from the lengths in the
  * closed form of the scheduler above: of the task map that path consumes header int 6 = the scheduler call's
  * min_process_len - a workgroup's range is never shorter than that many KV tokens - while the map's bins and
- * split decisions do not apply there); an odd kv head count - incl. a single kv head - HND pages and
- * per-token K scales run the first-generation kernel from the task map;
+ * split decisions do not apply there; since round 6 per-token K scales on NHD pages run there too, and calls with
+ * 17 ... 32 q rows per kv head - speculative steps, num_seq_q 3 / 4 at 8 q heads per kv head - run the same pipeline with ONE
+ * kv head per workgroup, on NHD and HND pages, both quant types, pages of 32 / 64 tokens); with <= 16 q rows an odd kv head
+ * count - incl. a single kv head - and HND pages run the first-generation kernel from the task map;
  * num_seq_kvcache_ptr may be NULL, then the task map drives the first-generation kernel as for bf16. */
 int hpc_attention_decode_fp8_async(void* y_ptr, void* workspace, const int* task_map_ptr,
                                    const void* q_ptr, const void* kcache_ptr,
