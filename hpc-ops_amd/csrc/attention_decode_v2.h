@@ -34,6 +34,7 @@ struct Args {
   int xcd_map;    // development key 38: eight 3-bit entries, workgroup 8 j + x serves pair (e & 3) of range 2 j + (e >> 2), e = entry x
   int dev_sleep;  // development key 39: workgroups of even head pairs sleep this many x 64 clocks per wave-iteration
   int dev_merge_dup = 0;  // development key 58 = 1: the last arriver loads (and folds with weight zero) a duplicate for a missing second chunk
+  int dev_nosnap = 0;     // development key 61 = 1: short requests of an underloaded launch may be split (rounds 2-5)
   int dev_slice;  // development key 37 = s + 1: every workgroup streams slice s of the token rows (timing only; results are wrong)
   long k_block_stride, k_token_stride;  // bytes
   long v_block_stride, v_token_stride;

@@ -359,6 +359,14 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
 
   // The range is converted to real tiles once: it starts at tile c_rt0 of request c_b and ends in front of tile
   // e_rt of request e_b (a boundary inside a request's overhead units is a boundary at that request's first tile).
+  // Round 6: when the FLOOR sizes the ranges (per_s_even <= per_floor: the launch has fewer tiles than it could spread - 64 x 512
+  // tokens, a handful of short requests beside one long one) a request of <= kSnap tiles is never split: a boundary inside it
+  // moves to its nearer end.  Such a launch is a chain of round trips, not a stream - a short request cut in two costs two task
+  // ends, a partial, a ticket and a merge for a few wave-iterations of work, and the workgroups the imbalance would hurt are
+  // idle anyway (reference benchmark case uniform_512, 8 / 64 heads: 32.4 us -> see profiles/round6_decode_ab.txt, call 10).
+  // Both neighbours of a boundary compute the same snap (same function, same x); finish_task knows such a request has one chunk.
+  constexpr int kSnap = 16;
+  const bool snap = per_s_even <= per_floor && !(kHpcDevBuild && a.dev_nosnap);
   auto locate = [&](int x, int& b_out, int& rt_out, int& cc_out) __attribute__((always_inline)) {
     if (x >= Th) {
       b_out = B;
@@ -375,6 +383,27 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
       if (x < pos + t) break;
       pos += t;
       ++b;
+    }
+    if (snap && x > pos) {
+      // underloaded launch (`snap`, below): a boundary inside a short request moves to the nearer end of that request
+      const int t = cost_of(b);
+      if (t - kOvh <= kSnap) {
+        if (2 * (x - pos) >= t) {  // to its end = the start of the next non-empty request
+          pos += t;
+          ++b;
+          while (b < B && cost_of(b) == 0) ++b;
+          if (b >= B) {
+            b_out = B;
+            rt_out = 0;
+            cc_out = Th;
+            return;
+          }
+        }
+        b_out = b;
+        rt_out = 0;
+        cc_out = pos;
+        return;
+      }
     }
     b_out = b;
     rt_out = x - pos > kOvh ? x - pos - kOvh : 0;
@@ -807,8 +836,9 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     const int db = q0_b;
     const int d_tiles = (q0_ltot + 63) >> 6;
     // tile t of the request sits at cost position req0 + kOvh + t
-    const int first_rng = range_of(q0_cc + kOvh);
-    const int nchunks = range_of(q0_cc + kOvh + d_tiles - 1) - first_rng + 1;
+    const bool whole = snap && d_tiles <= kSnap;  // never split (see locate)
+    const int first_rng = whole ? rng : range_of(q0_cc + kOvh);
+    const int nchunks = whole ? 1 : range_of(q0_cc + kOvh + d_tiles - 1) - first_rng + 1;
     const int ichunk = rng - first_rng;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
@@ -1500,6 +1530,7 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
   a.xcd_map = hpc_dev_tuning_get(38);
   a.dev_sleep = hpc_dev_tuning_get(39);
   a.dev_merge_dup = hpc_dev_tuning_get(58) == 1;
+  a.dev_nosnap = hpc_dev_tuning_get(61) == 1;
   // the second workgroup of every CU on the slice across address bit 9 (see the kernel): slices of 256 B (fp8 pairs) -> pair
   // index bit 1, of 512 B (bf16 pairs, fp8 quads) -> bit 0.  Measured per shape (profiles/round5_decode_pair_map_ab.txt):
   // fp8 8 / 64 heads +4-6 %, 16 / 128 heads +4 % (bit 8: +2 %, bit 10: 0), bf16 8 / 64 +1-2.5 % (bit 10: 0); with two pairs

@@ -59,6 +59,7 @@
 //   key 58 decode v2: 1 = the last arriver of a split request loads its first chunk again when the trip's second chunk does not exist (rounds 3-5)
 //   key 60 fp8 decode, one kv head per workgroup with <= 32 q rows (attention_decode_v2.hip, kSolo): 0 = for 17 ... 32 q rows per kv head,
 //          1 = never (the first generation's two-block form), 2 = also for <= 16 q rows on HND pages / with odd kv-head counts
+//   key 61 decode v2: 1 = range boundaries of an underloaded launch are not moved to the ends of short requests (rounds 2-5)
 //   others: see the launchers that read them
 #pragma once
 

@@ -159,6 +159,56 @@ def test_attn_fp8_head_pair_kernel_hnd_form(num_seq_q, heads, block_size):
 
 @pytest.mark.dev
 @pytest.mark.gpu
+@pytest.mark.parametrize("key", [0, 1])
+def test_attn_fp8_underloaded_launch_does_not_split_short_requests(key):
+    """A launch with fewer tiles than it could spread (here 40 requests of 200 ... 700 tokens on 4 kv heads: the plan's floor of
+    8 tiles sizes the ranges) moves every range boundary that falls inside a request of <= 16 tiles to that request's nearer
+    end (round 6, attention_decode_v2.hip: `snap`): nothing is split, so no fp32 partial is written - the poisoned partial
+    region of the cached workspace stays untouched.  Development key 61 = 1 keeps the split plan of rounds 2-5 (partials
+    appear).  Both equal the oracle; the reference benchmark's uniform_512 case went 31.9 -> 23.5 us on 8 / 64 heads."""
+    import hpc
+    from oracle import attention as oattn
+
+    hpc.release_decode_workspaces()
+    torch.manual_seed(7)
+    lens = torch.randint(200, 700, (40,), dtype=torch.int32)
+    heads, P = (4, 32), 64
+    q8, q_scale, kv, block_ids, nblocks = _case(40, 1, lens, P, heads, False)
+    kv8 = kv.to(torch.float8_e4m3fn)
+    ks, vs = torch.rand(1) + 0.5, torch.rand(1) + 0.5
+    gt = oattn.ref_attn_fp8(q8, kv8[:, :, :P], block_ids, nblocks, 1, lens, q_scale, ks, vs, False)
+    kvd = kv8.cuda()
+    lens_in = (lens + 1).cuda()
+    args = (q8.cuda(), kvd[:, 0, :P], kvd[:, 1, :P], block_ids.cuda(), lens_in, q_scale.cuda(), ks.cuda(), vs.cuda())
+    zero = hpc._C.lib.hpc_attention_decode_workspace_zero_bytes()
+    tm = hpc.get_attention_decode_task_workspace(40, int(lens.max()) + 1, heads[0], min_process_len=64)
+    hpc.assign_attention_decode_task(lens_in, tm, heads[0], 1, True, min_process_len=64)
+
+    def run():
+        y = hpc.attention_decode_fp8(*args, mtp=0, new_kv_included=True,
+                                     quant_type=hpc.QuantType.QPERTOKEN_PERHEAD_KPERTENSOR_VPERTENSOR, splitk=True, task_map=tm)
+        torch.cuda.synchronize()
+        assert allclose(gt, y.cpu(), atol=0.2)
+
+    dev_set(61, key)
+    try:
+        run()  # creates the cached scratch
+        cached = torch.ops.hpc._decode_workspaces()
+        assert len(cached) >= 1
+        for ws in cached:
+            ws[zero:].view(torch.int32).fill_(0x7FC12345)
+        torch.cuda.synchronize()
+        run()
+        touched = sum(int((ws[zero:].view(torch.int32) != 0x7FC12345).sum()) for ws in cached)
+        assert (touched == 0) if key == 0 else (touched > 0)
+        run()  # the arrival counters were left zero
+    finally:
+        dev_set(61, 0)
+        hpc.release_decode_workspaces()
+
+
+@pytest.mark.dev
+@pytest.mark.gpu
 @pytest.mark.parametrize("num_seq_q,heads,block_size,shape,key", [(3, (8, 64), 64, "NHD", 0), (4, (4, 32), 32, "HND", 0), (4, (1, 8), 64, "NHD", 0),
                                                                   (3, (2, 16), 32, "NHD", 0), (2, (3, 24), 64, "NHD", 2), (1, (2, 8), 64, "HND", 2),
                                                                   (4, (3, 12), 32, "NHD", 2), (3, (2, 16), 64, "NHD", 1), (4, (4, 32), 64, "HND", 1)])
