@@ -2,7 +2,9 @@
 development key 60 = 2 also below that) against the first generation (key 60 = 1), per-tensor and per-token K scales, NHD / HND
 pages of 32 / 64 tokens, both new_kv_included settings, random batches with empty, short and long requests.  The two kernels
 split requests at different points, so outputs agree to fp rounding of the merges, not bit for bit: max |dy| <= 0.03 at |y| ~ 1.
-usage: python tools/fuzz_decode_forms.py [cases=40] [seed=0]"""
+usage: python tools/fuzz_decode_forms.py [cases=40] [seed=0] [mode=pair]
+mode=pair: the head-pair form itself (product: even head counts, <= 16 q rows, NHD pages - incl. underloaded launches whose short
+requests are kept whole, round 6) against the first generation (development key 12 = 1)."""
 import os
 os.environ.setdefault("HPC_AMD_DEV", "1")
 import math, random, sys
@@ -14,6 +16,7 @@ from hpc import _C
 dev = torch.device("cuda", 0)
 kw = dict(a.split("=") for a in sys.argv[1:])
 n_cases, seed = int(kw.get("cases", 40)), int(kw.get("seed", 0))
+PAIR = kw.get("mode") == "pair"
 rnd = random.Random(seed)
 f8 = torch.float8_e4m3fn
 worst = 0.0
@@ -25,10 +28,16 @@ for case in range(n_cases):
     if low: sq = rnd.choice([1, 2]) if g == 8 else rnd.choice([1, 2, 4])
     P = rnd.choice([32, 64])
     hnd = rnd.random() < 0.5
-    ktok = rnd.random() < 0.4
+    if PAIR:
+        hkv, g = rnd.choice([(8, 8), (4, 8), (2, 8), (16, 8), (2, 4), (6, 4)])
+        hq = hkv * g
+        sq = rnd.choice([1, 2]) if g == 8 else rnd.choice([1, 2, 4])
+        P, hnd = rnd.choice([16, 32, 64]), False
+    ktok = rnd.random() < 0.4 and P >= 32
     nkv = rnd.random() < 0.7
     B = rnd.choice([1, 2, 5, 17, 64, 150])
-    kinds = [rnd.choice(["zero", "tiny", "short", "mid", "long"]) for _ in range(B)]
+    kinds = [rnd.choice(["zero", "tiny", "short", "mid", "long"] if not (PAIR and rnd.random() < 0.5) else ["zero", "tiny", "short", "short"]) for _ in range(B)]
+    if PAIR and rnd.random() < 0.5: kinds = [rnd.choice(["tiny", "short"]) for _ in range(B)]   # underloaded launches
     lens = torch.tensor([{"zero": 0, "tiny": rnd.randint(1, 70), "short": rnd.randint(60, 700), "mid": rnd.randint(700, 5000),
                           "long": rnd.randint(5000, 40000 if B <= 17 else 12000)}[k] for k in kinds], dtype=torch.int32)
     torch.manual_seed(seed * 1000 + case)
@@ -67,11 +76,11 @@ for case in range(n_cases):
     hpc.assign_attention_decode_task(lens_in, tm, hkv, sq, nkv, 64)
     outs = {}
     for key in (1, 2, 0):
-        _C.lib.hpc_dev_tuning_set(60, key)
+        _C.lib.hpc_dev_tuning_set(12 if PAIR else 60, (1 if key == 1 else 0) if PAIR else key)
         for _ in range(2):  # twice: counters left zero
             outs[key] = hpc.attention_decode_fp8(q8, kd[:, :P], vd, bid, lens_in, q_scale, ks, vs, sq - 1, nkv, qt, True, tm).float()
         torch.cuda.synchronize()
-    _C.lib.hpc_dev_tuning_set(60, 0)
+    _C.lib.hpc_dev_tuning_set(60, 0); _C.lib.hpc_dev_tuning_set(12, 0)
     live = (lens + (0 if nkv else 0) > -1)  # every request has >= sq new tokens when nkv; rows of empty requests compare too
     d2 = float((outs[2] - outs[1]).abs().max()); d0 = float((outs[0] - outs[1]).abs().max())
     fin = bool(torch.isfinite(outs[2]).all() and torch.isfinite(outs[0]).all())
