@@ -1,3 +1,7 @@
+"""Development tool: bf16 decode at num_seq_q 1 ... 4 (C3 length mix and uniform 8k, 8 / 64 heads, NHD pages): num_seq_q 1 / 2 run the
+head-pair form, 3 / 4 (24 / 32 q rows per kv head) the first generation's two-block form - round 6: 0.77 / 0.75 against 0.67 / 0.66
+on the mix, 0.795 / 0.80 against 0.755 on uniform 8k (gpurun_out/r6_bf16_sq.log).
+usage: python tools/tune_bf16_sq.py"""
 import os, sys, math
 sys.path.insert(0, "hpc-ops_amd"); sys.path.insert(0, ".")
 import torch, bench, hpc
