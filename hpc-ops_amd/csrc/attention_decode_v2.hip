@@ -223,20 +223,25 @@ constexpr int kFMasked = 32;  // some token of the WI is invisible to some q row
 //        The head's rows sit at k / v_head_stride * head, tokens at k / v_token_stride: NHD and HND pages alike.
 template <int kAux, bool kBf16 = false, bool kProf = false, bool kQuad = false, bool kKtok = false, bool kHnd = false, bool kSolo = false>
 __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
-  static_assert(!kSolo || (!kBf16 && !kQuad && !kHnd), "one head per workgroup: fp8");
+  static_assert(!kSolo || (!kQuad && !kHnd), "one head per workgroup: fp8 (both quant types) or bf16");
+  static_assert(!(kSolo && kBf16 && kKtok), "bf16 has no scales");
   static_assert(!(kBf16 && kQuad), "the quad form is fp8");
   static_assert(!kKtok || (!kBf16 && !kQuad), "per-token K scales: the fp8 head-pair form");
   static_assert(!kHnd || (!kBf16 && !kQuad && !kKtok), "HND pages: the fp8 head-pair form with per-tensor scales");
   __shared__ float s_ks[kKtok ? kWaves : 1][64];
-  constexpr bool kWide = kBf16 || kQuad;     // 512-byte stage rows, 16-token wave-iterations
+  constexpr bool kWide = (kBf16 && !kSolo) || kQuad;  // 512-byte stage rows, 16-token wave-iterations
+  // kSolo + kBf16 (round 6): one kv head's 256-byte rows, 32 tokens per wave-iteration - the fp8 pair form's stage geometry
+  // ([32 rows][256 B], four rows per load instruction, the same K image) with the bf16 form's arithmetic; the V image has its own
+  // key (slot = chunk ^ 2 (t % 4): the 4 rows x 2 chunks x 2 halves of a transposing b16 read fall on 16 different 8-byte places)
+  constexpr bool kBSolo = kBf16 && kSolo;
   __shared__ __attribute__((aligned(1024))) uint8_t s_wave[kWaves][kWaveLds];  // stage addresses are (base) ^ (bits 4-7)
   __shared__ float s_m[2][kWaves][16];
   __shared__ float s_l[2][kWaves][16];
   __shared__ int s_ticket[2];
   constexpr int kH = kSolo ? 1 : kQuad ? 4 : 2;  // kv heads per workgroup
-  constexpr int kW = kSolo ? 64 : kWide ? 16 : 32;        // tokens (= stage rows) per wave-iteration
-  constexpr int kRowB = kSolo ? 128 : kWide ? 512 : 256;  // bytes of a stage row: the workgroup's heads of a token
-  constexpr int kRpi = (kHnd || kSolo) ? 8 : kWide ? 2 : 4;  // rows per load instruction (64 lanes x 16 B = 1 KB; HND / solo: 8 tokens of one head)
+  constexpr int kW = kBSolo ? 32 : kSolo ? 64 : kWide ? 16 : 32;        // tokens (= stage rows) per wave-iteration
+  constexpr int kRowB = kBSolo ? 256 : kSolo ? 128 : kWide ? 512 : 256;  // bytes of a stage row: the workgroup's heads of a token
+  constexpr int kRpi = kBSolo ? 4 : (kHnd || kSolo) ? 8 : kWide ? 2 : 4;  // rows per load instruction (64 lanes x 16 B = 1 KB; HND / fp8 solo: 8 tokens of one head)
   constexpr int kCpr = 64 / kRpi;            // 16-byte chunks per row
 
   const int tid = threadIdx.x;
@@ -588,13 +593,16 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   //      16 + 4 g + j, fall on 8 different slots): writes: lane (r8 = lane / 8, c = lane % 8) of instruction (tb, q) holds chunk c of
   //      row tb * 32 + q * 8 + r8; K reads: lane (n, g), row tb * 16 + n, chunks g and g + 4; V transpose reads: k-step s, lane
   //      (i, g): stage row 32 s + 16 (j / 4) + 4 g + j % 4 with j = i / 2, 8-byte half i % 2, chunk jj
-  const uint32_t w0_inv = kSolo ? lds0 + (lane >> 3) * kRowB + (((lane & 7) ^ (lane >> 3)) * 16)
+  const uint32_t w0_inv = (kSolo && !kBf16) ? lds0 + (lane >> 3) * kRowB + (((lane & 7) ^ (lane >> 3)) * 16)
                           : kHnd ? lds0 + (lane >> 3) * kRowB + (((lane & 7) ^ (lane >> 3)) * 16)
                           : kWide ? lds0 + (lane >> 5) * kRowB + (((lane & 31) ^ (lane >> 5)) * 16)
                                   : lds0 + (lane >> 4) * kRowB + (((lane & 15) ^ (lane >> 4)) * 16);
-  const uint32_t w1_inv = lds0 + kVOff + (lane >> 5) * kRowB + (((lane & 31) ^ ((lane >> 5) << 1)) * 16);  // bf16 V stage
-  const uint32_t r0_inv = kSolo ? lds0 + n * kRowB + ((g ^ (n & 7)) * 16) : lds0 + n * kRowB + ((g ^ n) * 16);
-  const uint32_t t0_inv = kBf16 ? lds0 + kVOff + btok * kRowB + (((((lane & 3) >> 1) ^ bkey)) * 16) + (lane & 1) * 8
+  const uint32_t w1_inv = kBSolo ? lds0 + kVOff + (lane >> 4) * kRowB + (((lane & 15) ^ ((lane >> 4) << 1)) * 16)   // bf16, one head: V stage
+                                 : lds0 + kVOff + (lane >> 5) * kRowB + (((lane & 31) ^ ((lane >> 5) << 1)) * 16);  // bf16 V stage
+  const uint32_t r0_inv = (kSolo && !kBf16) ? lds0 + n * kRowB + ((g ^ (n & 7)) * 16) : lds0 + n * kRowB + ((g ^ n) * 16);
+  // bf16, one head: lane (i, g) of a transposing b16 read: row 4 g + i / 4 (+ 16 tb), chunk 2 jj + (i % 4) / 2, half i % 2
+  const uint32_t t0_inv = kBSolo ? lds0 + kVOff + btok * kRowB + (((((lane & 3) >> 1) ^ ((btok & 3) << 1))) * 16) + (lane & 1) * 8
+                          : kBf16 ? lds0 + kVOff + btok * kRowB + (((((lane & 3) >> 1) ^ bkey)) * 16) + (lane & 1) * 8
                           : kSolo ? lds0 + kVOff + ttok * kRowB + ((((ttok & 7) ^ (((ttok >> 4) & 1) << 2))) * 16) + (lane & 1) * 8
                           : kQuad ? lds0 + kVOff + qtok * kRowB + ((((g >> 1) << 3) ^ qtok) * 16) + (lane & 1) * 8
                                   : lds0 + kVOff + ttok * kRowB + ((((ttok & 15) ^ ((ttok >> 4) << 3))) * 16) + (lane & 1) * 8;
@@ -613,6 +621,16 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
   // workgroup's q heads - the kH * G q heads of its kv heads are contiguous - bounded to
   // the request's Sq rows: lanes of the rows past rows_valid read zeros.
   auto load_q = [&](int db) __attribute__((always_inline)) {
+    if constexpr (kBSolo) {  // tile hh = q rows 16 hh + n of the kv head (a.ldq in bytes)
+      const i32x4 rq = srd_of(qbase + static_cast<long>(db) * Sq * a.ldq + (pr << a.g_shift) * 256,
+                              static_cast<unsigned>((Sq - 1) * a.ldq + G * 256));
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int r = 16 * hh + n;
+        ld_q4(qf[hh], (r >> a.g_shift) * a.ldq + (r & (G - 1)) * 256 + g * 16, rq);
+      }
+      return;
+    }
     if constexpr (kBf16) {  // a.ldq in bytes; one descriptor for the pair's 2 G q heads (256 B each)
       const int q_voff = (n >> a.g_shift) * a.ldq + (n & (G - 1)) * 256 + g * 16;
       const i32x4 rq = srd_of(qbase + static_cast<long>(db) * Sq * a.ldq + ((pr * kH) << a.g_shift) * 256,
@@ -944,7 +962,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     auto write_k = [&](int tb) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if constexpr (kSolo)
+        if constexpr (kSolo && !kBf16)
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q >> 1) << 2) * 16)) + (tb * 32 + q * 8) * kRowB)) = kr[tb][q];
         else if constexpr (kHnd)
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ ((((q >> 1) << 3) ^ ((q & 1) << 3) ^ (tb << 3)) * 16)) + (tb * 16 + (q & 1) * 8) * kRowB)) = kr[tb][q];
@@ -957,7 +975,9 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     auto write_v = [&](int tb) __attribute__((always_inline)) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        if constexpr (kSolo)
+        if constexpr (kBSolo)
+          *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>(w1 + (tb * 16 + q * 4) * kRowB)) = vr[tb][q];
+        else if constexpr (kSolo)
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ (((q >> 1) << 2) * 16)) + kVOff + (tb * 32 + q * 8) * kRowB)) = vr[tb][q];
         else if constexpr (kHnd)
           *reinterpret_cast<lds_u32x4*>(static_cast<uint32_t>((w0 ^ ((((q >> 1) << 3) ^ ((q & 1) << 3) ^ (tb << 3)) * 16)) + kVOff + (tb * 16 + (q & 1) * 8) * kRowB)) = vr[tb][q];
@@ -1029,7 +1049,87 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     step(p2_tok, p2_fl, p2_pid0, p2_pid1);  // the WI after the one just issued: its page ids are on their way while this one computes
     if constexpr (kProf) { const uint64_t t = now(); pf_is += t - pf_last; pf_last = t; }
 
-    if constexpr (kBf16) {
+    if constexpr (kBSolo) {
+      // S^T = K Q^T: four K = 32 MFMAs per 16-token block and q-row half; a block's K fragments serve both halves
+      f32x4 sacc[2][2];
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const u32x4 kk = *reinterpret_cast<const lds_u32x4*>(static_cast<uint32_t>((r0 ^ (((j << 2) ^ (tb << 3)) * 16)) + tb * 16 * kRowB));
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh)
+            acc[hh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kk), __builtin_bit_cast(bf16x8, qf[hh][j]), acc[hh], 0, 0, 0);
+        }
+        sacc[0][tb] = acc[0];
+        sacc[1][tb] = acc[1];
+      }
+      v4i16 pf[2][2];
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sacc[hh][tb][r] *= row_scale[hh];
+      if (d_fl & kFMasked) {  // wave-uniform: only the WIs that hold a request's last tokens
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int sq_row = (16 * hh + n) >> a.g_shift;
+          const int lim = (q0_end - 1 < q0_ltot - Sq + sq_row) ? q0_end - 1 : q0_ltot - Sq + sq_row;
+#pragma unroll
+          for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[hh][tb][r] = (d_tok + tb * 16 + g * 4 + r) <= lim ? sacc[hh][tb][r] : kNegInf;
+        }
+      }
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        float mt = kNegInf;
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mt = __builtin_fmaxf(mt, sacc[hh][tb][r]);
+        mt = row4_max(mt);
+        const float m_new = fmaxf(m_run[hh], mt);
+        const float m_use = m_new == kNegInf ? 0.f : m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+          float prb[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            prb[r] = __builtin_amdgcn_exp2f(sacc[hh][tb][r] - m_use);
+            psum += prb[r];
+          }
+          pf[hh][tb] = __builtin_bit_cast(v4i16, u32x2{pack_bf16x2(prb[0], prb[1]), pack_bf16x2(prb[2], prb[3])});
+        }
+        if (__builtin_amdgcn_ballot_w64(m_new != m_run[hh]) != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(m_run[hh] - m_use);
+          l_run[hh] *= alpha;
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) o[hh][jj] *= alpha;
+          m_run[hh] = m_new;
+        }
+        l_run[hh] += psum;
+      }
+      // O^T += V^T P^T: per 16-token block eight transposing reads (16 dims each) that feed both halves
+#pragma unroll
+      for (int tb = 0; tb < 2; ++tb) {
+        v4i16 vt[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          vt[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              reinterpret_cast<lds_v4i16*>(static_cast<uint32_t>((t0 ^ ((u << 1) * 16)) + tb * 16 * kRowB)));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            o[hh][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(vt[u], pf[hh][tb], o[hh][u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else if constexpr (kBf16) {
       // S^T = K Q^T: four K = 32 MFMAs per head (lane (n, g): 8 dims of row n per k-step on both sides)
       f32x4 sacc[2];
 #pragma unroll
@@ -1174,7 +1274,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
               pack64(static_cast<uint32_t>(vt[u][0]), static_cast<uint32_t>(vt[u][1])), pack64(pf[p][0], pf[p][1]), o[p][u], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-    } else if constexpr (kSolo) {
+    } else if constexpr (kSolo && !kBf16) {
       // S^T = K Q^T: one K = 128 MFMA per 16-token block and q-row half; the K fragments of a block serve both halves
       f32x4 sacc[2][4];
 #pragma unroll
@@ -1438,13 +1538,13 @@ int mode_of(Args& a, int num_head_q, int block_size, int64_t k_head_stride, int6
                            (!a.ktok || a.ks_head_stride == 128);
     const bool ks_ok = !a.ktok || (a.ks_block_stride > 0 && a.ks_block_stride < (1ll << 32) && (a.ks_row_stride % 4) == 0 &&
                                    (a.ks_head_stride % 4) == 0);
-    const bool shape_ok = !a.bf16 && ks_ok && a.lens != nullptr && rows <= 32 && (block_size == 64 || block_size == 32) &&
+    const bool shape_ok = ks_ok && a.lens != nullptr && rows <= 32 && (block_size == 64 || block_size == 32 || (a.bf16 && block_size == 16)) &&
                           (a.k_token_stride % 16) == 0 && (a.v_token_stride % 16) == 0 && (k_head_stride % 16) == 0 &&
                           (v_head_stride % 16) == 0 && (a.k_block_stride % 16) == 0 && (a.v_block_stride % 16) == 0 &&
                           a.k_block_stride > 0 && a.v_block_stride > 0 && a.k_block_stride < (1ll << 32) &&
                           a.v_block_stride < (1ll << 32) && a.k_token_stride * 32 < (1ll << 31) && a.v_token_stride * 32 < (1ll << 31) &&
                           a.num_batch <= 64 * 16 && static_cast<int64_t>(a.num_batch) * a.num_head_kv * 4 <= kCounterBytes;
-    const bool wanted = k60 == 2 ? !pair_case : (k60 == 0 && rows > 16);
+    const bool wanted = k60 == 3 ? true : k60 == 2 ? !pair_case : (k60 == 0 && rows > 16);  // 3: every eligible call (A/B against the pair forms)
     if (shape_ok && wanted) return 3;
   }
   const bool hnd = !a.bf16 && !a.ktok && a.k_token_stride == 128 && a.v_token_stride == 128 && k_head_stride >= 128 * block_size &&
@@ -1513,7 +1613,9 @@ int launch(Args a, void* counters, void* partials, int num_wg, int mode, hipStre
         a.mate_from = cus;
       }
     }
-    if (a.ktok)
+    if (a.bf16)
+      decode2_kernel<2, true, false, false, false, false, true><<<num_wg, kThreads, 0, stream>>>(a);
+    else if (a.ktok)
       decode2_kernel<2, false, false, false, true, false, true><<<num_wg, kThreads, 0, stream>>>(a);
     else if (kHpcDevBuild && a.prof)
       decode2_kernel<2, false, true, false, false, false, true><<<num_wg, kThreads, 0, stream>>>(a);

@@ -58,7 +58,8 @@
 //          K = 32 MFMAs (bit-identical to 1) instead of one K = 128 MFMA per k-block (bit-identical to the 256 x 256 kernel)
 //   key 58 decode v2: 1 = the last arriver of a split request loads its first chunk again when the trip's second chunk does not exist (rounds 3-5)
 //   key 60 fp8 decode, one kv head per workgroup with <= 32 q rows (attention_decode_v2.hip, kSolo): 0 = for 17 ... 32 q rows per kv head,
-//          1 = never (the first generation's two-block form), 2 = also for <= 16 q rows on HND pages / with odd kv-head counts
+//          1 = never (the first generation's two-block form), 2 = also for <= 16 q rows on HND pages / with odd kv-head counts,
+//          3 = every eligible call (A/B against the pair forms); bf16 calls follow the same key
 //   key 61 decode v2: 1 = range boundaries of an underloaded launch are not moved to the ends of short requests (rounds 2-5)
 //   others: see the launchers that read them
 #pragma once

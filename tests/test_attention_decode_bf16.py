@@ -151,6 +151,29 @@ def test_attn_bf16_speculative_rows_product(num_seq_q, kv_head_q_head, kvcache_s
         _run(len(lens), num_seq_q, lens, 64, kv_head_q_head, new_kv_included, False, True, kvcache_shape, min_process_len=mpl)
 
 
+@pytest.mark.dev
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_seq_q,heads,block_size,shape,key", [(3, (8, 64), 64, "NHD", 0), (4, (4, 32), 16, "HND", 0), (3, (1, 8), 32, "NHD", 0),
+                                                                  (4, (2, 16), 32, "HND", 0), (2, (3, 24), 16, "NHD", 3), (1, (2, 8), 64, "HND", 3),
+                                                                  (3, (8, 64), 64, "NHD", 1), (4, (4, 32), 16, "HND", 1)])
+def test_attn_bf16_one_head_per_workgroup_form(num_seq_q, heads, block_size, shape, key):
+    """bf16 with 17 ... 32 q rows per kv head (num_seq_q 3 / 4 at 8 q heads per kv head) runs ONE kv head per workgroup on the
+    head-pair kernel's pipeline since round 6 (attention_decode_v2.hip, kSolo + kBf16: the fp8 pair form's stage geometry - 32
+    rows of 256 B - with the bf16 arithmetic, both q-row halves on the same K / V; C3 mix 286 -> 258 us, uniform 8k 354 -> 327).
+    Development key 60 = 3 sends every eligible call there (odd head counts, <= 16 rows, pages of 16), key 60 = 1 keeps the first
+    generation's two-block form under test.  Split, short and empty requests; both new_kv_included settings; twice."""
+    import hpc  # noqa: F401
+    from utils import dev_set
+
+    lens = torch.tensor([20000, 3, 9000, 130, 64, 63, 65, 4097, 700, 1, 127, 129, 31000, 2, 0, 255, 256, 257], dtype=torch.int32)
+    dev_set(60, key)
+    try:
+        for new_kv_included in (True, False, True):
+            _run(len(lens), num_seq_q, lens, block_size, heads, new_kv_included, False, True, shape)
+    finally:
+        dev_set(60, 0)
+
+
 @pytest.mark.gpu
 def test_attn_bf16_errors():
     import hpc

@@ -4,7 +4,7 @@ in scratch - and the hand-counted vmcnt pipeline assumes that no load destinatio
 pushes a form over the budget would still pass every parity test and quietly lose its second workgroup (or spill inside the
 wave-iteration).  This test pins the budget per shipped instantiation:
   decode2_kernel<2, bf16, prof, quad, ktok, hnd, solo>: the fp8 head-pair form (the headline), its bf16 form, per-token K scales,
-  one kv head per workgroup (17-32 q rows) with per-tensor and with per-token K scales."""
+  one kv head per workgroup (17-32 q rows) with per-tensor scales, with per-token K scales, and in bf16."""
 import importlib.util
 import re
 import shutil
@@ -30,6 +30,7 @@ SHIPPED = {
     "ILi2ELb0ELb0ELb0ELb1ELb0ELb0EE": ("fp8 head pairs, per-token K scales", 236, 0),
     "ILi2ELb0ELb0ELb0ELb0ELb0ELb1EE": ("fp8 one head per workgroup", 256, 0),
     "ILi2ELb0ELb0ELb0ELb1ELb0ELb1EE": ("fp8 one head per workgroup, per-token K scales", 256, 4),
+    "ILi2ELb1ELb0ELb0ELb0ELb0ELb1EE": ("bf16 one head per workgroup", 244, 0),
 }
 
 
