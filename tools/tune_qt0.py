@@ -27,7 +27,10 @@ def time_sq(sq, hnd=False):
     import math
     B, P, D, Hkv, Hq = 64, 64, 128, 8, 64
     f8 = torch.float8_e4m3fn
-    lens = bench.c3_lens()
+    case = os.environ.get("QT0_CASE", "mixed")
+    lens = {"mixed": bench.c3_lens(), "uniform8k": torch.full((B,), 8192, dtype=torch.int32),
+            "skewed_mix": torch.tensor([128] * 32 + [4096] * 32, dtype=torch.int32),
+            "uniform512": torch.full((B,), 512, dtype=torch.int32)}[case]
     torch.manual_seed(41); torch.cuda.manual_seed(41)
     nbl = (lens + P - 1) // P
     total = int(nbl.sum()); pool = int(total * 1.2) + B + 8
@@ -63,7 +66,7 @@ def time_sq(sq, hnd=False):
 
 
 if os.environ.get("QT0_SQ"):
-    for cfg in ("60=1", "0=0", "60=1", "0=0"):
+    for cfg in (os.environ.get("QT0_CFGS", "60=1|0=0|60=1|0=0").split("|")):
         pairs = [tuple(int(x) for x in kv.split("=")) for kv in cfg.split(",") if kv]
         for k, v in pairs: _C.lib.hpc_dev_tuning_set(k, v)
         for sq in (int(x) for x in os.environ["QT0_SQ"].split(",")):
