@@ -33,6 +33,7 @@ struct Args {
   int no_half_tile = 0;  // development (key 21): 1 = the 256 x 256 kernel runs its full body only, 2 = no tail body (<= 64 rows)
   int nt_single = 1;     // 256 x 256 kernel, tail body: non-temporal weight loads for a group's ONLY (<= 64-row) token tile
   int tail_regs = 0;     // development (key 26): 1 = the register-streamed tail body instead of the LDS-ring one
+  int item_scan_old = 0; // development (key 43): 1 = the item lookup's scans / lane reads through ds_bpermute (rounds 2-5) instead of DPP + v_readlane
   int ext_rows = 0;      // 256 x 256 kernel: 1 = a group's short tail rides along with its full tiles (group_gemm_p8.hip::locate_item)
   int item_order = 0;    // 256 x 256 kernel: 0 = tail tiles in place, 1 = full tiles first, tail tiles last (group_gemm_p8.hip::locate_item)
   void* prof = nullptr;  // development: s_memtime log of the 256 x 256 kernel's section boundaries (hpc_dev_p8_prof_buffer)

@@ -108,16 +108,32 @@ struct Item {
   int ext0, ext_cnt;         // ride-along rows of this tile: group rows [ext0, ext0 + ext_cnt), ext_cnt = 0: none
   bool valid;
 };
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+// Inclusive wave scan on the DPP path (round 6: six v_add with a DPP source instead of six ds_bpermute round trips + selects -
+// every workgroup of the kernel runs this lookup before its first request for data): Hillis-Steele within the rows of 16
+// (row_shr 1, 2, 4, 8: lanes without a source add 0), then lane 15 of row 0 / 2 into row 1 / 3 (row_bcast:15, rows 0xA) and
+// lane 31 into rows 2 and 3 (row_bcast:31, rows 0xC).
+__device__ __forceinline__ int wave_incl_scan(int v, int lane, bool old_path = false) {
+  if (kHpcDevBuild && old_path) {  // development key 43 = 1: the ds_bpermute form of rounds 2-5
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int u = __shfl_up(v, o, 64);
-    v += lane >= o ? u : 0;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(v, o, 64);
+      v += lane >= o ? u : 0;
+    }
+    return v;
   }
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);  // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);  // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);  // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);  // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
   return v;
 }
+__device__ __forceinline__ int lane_of(int v, int l, bool old_path = false) {  // l wave-uniform
+  return (kHpcDevBuild && old_path) ? __shfl(v, l, 64) : __builtin_amdgcn_readlane(v, l);
+}
 __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, const int* cu_seqlens, int num_group,
-                                            int nt, int lane, int lin, int order, int ext_on) {
+                                            int nt, int lane, int lin, int order, int ext_on, bool old_path = false) {
   Item it = {0, 0, 0, 0, 0, 0, 0, false};
   const int x = lin & 7, j = lin >> 3;
   // round 0 of every per-group quantity is loaded once, side by side
@@ -140,13 +156,9 @@ __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, co
   for (int g0 = 0; g0 < num_group; g0 += 64) {
     int f, h;
     split(g0, f, h);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      f += __shfl_xor(f, o, 64);
-      h += __shfl_xor(h, o, 64);
-    }
-    tot_f += f;
-    tot_h += h;
+    const int both = lane_of(wave_incl_scan(f | (h << 20), lane, old_path), 63, old_path);  // full tiles of 64 groups < 2^20
+    tot_f += both & 0xfffff;
+    tot_h += both >> 20;
   }
   int idx, kind;  // kind 0: every 256-token tile of a group (order 0), 1: full tiles only, 2: tail tiles only
   if (order == 0) {
@@ -174,12 +186,12 @@ __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, co
     int f, h;
     split(g0, f, h);
     const int t = kind == 0 ? f + h : (kind == 1 ? f : h);
-    const int inc = wave_incl_scan(t, lane);
+    const int inc = wave_incl_scan(t, lane, old_path);
     const unsigned long long hit = __ballot(g0 + lane < num_group && idx < (base + inc) * nt);
     if (hit) {
       const int l = __builtin_ctzll(hit);
-      const int tl = __shfl(t, l, 64), fl = __shfl(f, l, 64), hl = __shfl(h, l, 64);
-      const int rem = idx - (base + __shfl(inc, l, 64) - tl) * nt;
+      const int tl = lane_of(t, l, old_path), fl = lane_of(f, l, old_path), hl = lane_of(h, l, old_path);
+      const int rem = idx - (base + lane_of(inc, l, old_path) - tl) * nt;
       it.e = g0 + l;
       if (kind == 2) {
         it.wt = rem;
@@ -189,8 +201,8 @@ __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, co
         it.mt = rem % tl;
       }
       if (g0 == 0) {
-        it.m_cnt = __shfl(len_first, l, 64);
-        it.m0 = __shfl(row_first, l, 64);
+        it.m_cnt = lane_of(len_first, l, old_path);
+        it.m0 = lane_of(row_first, l, old_path);
       } else {
         it.m_cnt = as_const(seqlens)[it.e];
         it.m0 = as_const(cu_seqlens)[it.e];
@@ -205,7 +217,7 @@ __device__ __forceinline__ Item locate_item(cint_ptr cut, const int* seqlens, co
       it.valid = true;
       return it;
     }
-    base += __shfl(inc, 63, 64);
+    base += lane_of(inc, 63, old_path);
   }
   return it;
 }
@@ -1580,7 +1592,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_fp8_p8_kernel(const Args a, 
   __shared__ __attribute__((aligned(1024))) uint8_t s_mem[kLds];
   const int nt = a.N / kBN;  // kAct: N = 2 * inter, tile tn = columns [tn * 128, +128) of gate and of up
   const Item it = locate_item(as_const(cu_tiles), a.seqlens, a.cu_seqlens, num_group, nt, threadIdx.x & 63, blockIdx.x,
-                              a.item_order, !kNoDma && !kKTail ? a.ext_rows : 0);
+                              a.item_order, !kNoDma && !kKTail ? a.ext_rows : 0, a.item_scan_old != 0);
   if (!it.valid) return;
   const int e = __builtin_amdgcn_readfirstlane(it.e);
   const int m_cnt = __builtin_amdgcn_readfirstlane(it.m_cnt);
@@ -1648,6 +1660,7 @@ int hpc_ggemm_launch_p8(const hpc::ggemm::Args& a_in, const int* cu_tiles, int n
   // round5_moe_kernel_choice.txt; the stream is not bound by the bytes in flight at that point.  Removed.)
   a.nt_single = hpc_dev_tuning_get(24) != 1;
   a.tail_regs = hpc_dev_tuning_get(26) == 1;
+  a.item_scan_old = hpc_dev_tuning_get(43) == 1;
   // a group's short tail (<= 16 rows per full tile it has) rides along with its full tiles instead of running as a tail
   // item (blockwise scales; development key 49 = 1: tail items for every tail, the dispatch of round 5)
   a.ext_rows = hpc_dev_tuning_get(49) != 1;

@@ -61,6 +61,7 @@
 //          1 = never (the first generation's two-block form), 2 = also for <= 16 q rows on HND pages / with odd kv-head counts,
 //          3 = every eligible call (A/B against the pair forms); bf16 calls follow the same key
 //   key 61 decode v2: 1 = range boundaries of an underloaded launch are not moved to the ends of short requests (rounds 2-5)
+//   key 43 256x256 grouped GEMM: 1 = the work-item lookup's wave scans and lane reads through ds_bpermute (rounds 2-5) instead of DPP adds + v_readlane
 //   others: see the launchers that read them
 #pragma once
 
