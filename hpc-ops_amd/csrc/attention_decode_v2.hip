@@ -286,14 +286,17 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
       chunk_sum += t > 0 ? t + kOvh : 0;
     }
   }
+  // inclusive wave scan on the DPP path (round 6: six v_add with a DPP source instead of six ds_bpermute round trips in front of the
+  // first page-id load): Hillis-Steele within the rows of 16, then lane 15 of rows 0 / 2 into rows 1 / 3, lane 31 into rows 2, 3
   int incl = chunk_sum;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);  // row_shr:1
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);  // row_shr:2
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);  // row_shr:4
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);  // row_shr:8
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+  incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
   const int chunk_start = incl - chunk_sum;
-  const int Th = sgpr(__shfl(incl, 63, 64));       // total cost per head pair
+  const int Th = __builtin_amdgcn_readlane(incl, 63);  // total cost per head pair
   const int npair = a.num_head_kv / kH;
   if (Th == 0) return;
   // Workgroup -> (range r, pair p) with the pair index MINOR: workgroups r * npair .. r * npair + npair - 1 stream
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(kThreads, 2) void decode2_kernel(const Args a) {
     }
     const uint64_t le = __ballot(chunk_start <= x);
     const int cl = 63 - __builtin_clzll(le);  // last lane whose chunk starts at or before x
-    int pos = sgpr(__shfl(chunk_start, cl, 64));
+    int pos = __builtin_amdgcn_readlane(chunk_start, cl);  // cl is wave-uniform (from the ballot)
     int b = cl * kpl;
     while (true) {  // position x lies in this chunk (empty requests cost nothing and are stepped over)
       const int t = cost_of(b);
