@@ -562,7 +562,9 @@ def extra_decode(dev, hpc):
     for name, lens_c, heads, hnd in (("uniform8k_nhd", torch.full((B,), 8192, dtype=torch.int32), (8, 64), False),
                                      ("mixed_hnd", c3_lens(), (8, 64), True),
                                      ("mixed_nhd_1kv_8q", c3_lens(), (1, 8), False),
-                                     ("uniform8k_nhd_1kv_8q", torch.full((B,), 8192, dtype=torch.int32), (1, 8), False)):
+                                     ("uniform8k_nhd_1kv_8q", torch.full((B,), 8192, dtype=torch.int32), (1, 8), False),
+                                     # the reference benchmark's shortest case (bench_attention_decode_fp8.py:57-67): an underloaded launch
+                                     ("uniform512_nhd", torch.full((B,), 512, dtype=torch.int32), (8, 64), False)):
         wc = dict(C3, num_head_kv=heads[0], num_head_q=heads[1])
         inp = c3_inputs(dev, wc, lens=lens_c)
         if hnd:
